@@ -1,0 +1,340 @@
+"""Known-answer tests K1..K13 for the CPU oracle.
+
+The reference ships no tests or golden vectors for the fusion path ("parity unpinned"),
+so the oracle is pinned by answers derived by hand from the cited shader lines
+(paths under /root/reference/src/Shaders unless noted).
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+
+IDENT = np.eye(4, dtype=np.float32).T.reshape(16).copy()
+
+
+def cfg_small(W=160, H=96, border=0.0, **kw):
+    return ol.make_config(W, H, 100.0, 100.0, W / 2 - 0.5, H / 2 - 0.5,
+                          stereo_border=border, preprocess=0, **kw)
+
+
+def surfel(x, y, z, conf=0.9, sem=0, rgb=(10, 20, 30), t0=1.0, t1=1.0, n=(0, 0, 1), r=0.05):
+    s = np.zeros(12, np.float32)
+    s[0:3] = (x, y, z)
+    s[3] = conf
+    bits = np.uint32((sem << 24) | (rgb[0] << 16) | (rgb[1] << 8) | rgb[2])
+    s[4] = np.array([bits], np.uint32).view(np.float32)[0]
+    s[6], s[7] = t0, t1
+    s[8:11] = n
+    s[11] = r
+    return s
+
+
+def plane_frame(cfg, z_mm, sem_val=0):
+    W, H = cfg.width, cfg.height
+    rgb = np.zeros((H, W, 3), np.uint8)
+    rgb[..., 0], rgb[..., 1], rgb[..., 2] = 200, 100, 50
+    depth = np.full((H, W), z_mm, np.uint16)
+    sem = np.full((H, W), sem_val, np.uint8)
+    return rgb, depth, sem
+
+
+def bits(f):
+    return int(np.array([f], np.float32).view(np.uint32)[0])
+
+
+# ---------------------------------------------------------------- K1 color.glsl:19-37
+def test_k1_encode_color():
+    L = ol.lib()
+    assert bits(L.smo_encode_color(1.0, 0.0, 0.0, 5)) == 0x05FF0000
+    assert bits(L.smo_encode_color(0.0, 1.0, 0.0, 0)) == 0x0000FF00
+    assert bits(L.smo_encode_color(10 / 255.0, 20 / 255.0, 30 / 255.0, 18)) == 0x120A141E
+    # every u8 survives the b/255.f -> round(c*255) round trip
+    for b in range(256):
+        f = float(np.float32(b) / np.float32(255.0))
+        assert bits(L.smo_encode_color(f, f, f, 0)) == (b << 16 | b << 8 | b)
+
+
+# ---------------------------------------------------------------- K2 geometry.glsl:12-24, surfels.glsl:19-32
+def test_k2_plane_normal_radius():
+    cfg = cfg_small()
+    o = ol.Oracle(cfg)
+    rgb, depth, sem = plane_frame(cfg, 4000)
+    o.process_frame(rgb, depth, sem, IDENT)     # reference frame only
+    o.process_frame(rgb, depth, sem, IDENT)     # all new
+    m = o.download_model()
+    assert m.shape[0] > 0
+    np.testing.assert_array_equal(m[:, 8:11], np.tile(np.float32([0, 0, 1]), (m.shape[0], 1)))
+    z = np.float32(4.0)
+    inv_f = np.float32(1.0 / 100.0)
+    mean_focal = (np.float32(1.0) / inv_f + np.float32(1.0) / inv_f) / np.float32(2.0)
+    radius = (z / mean_focal) * np.float32(1.41421356237)
+    np.testing.assert_array_equal(m[:, 11], np.full(m.shape[0], radius, np.float32))
+    assert abs(float(radius) - 4.0 * math.sqrt(2) / 100.0) < 1e-6
+    np.testing.assert_array_equal(m[:, 3], np.float32(0.9))
+    np.testing.assert_array_equal(m[:, 5], 0.0)
+    np.testing.assert_array_equal(m[:, 2], z)
+    # getRadius: cap at 2x when the normal is nearly perpendicular to the ray
+    L = ol.lib()
+    r0 = L.smo_get_radius(4.0, 1.0, 0.01, 0.01)
+    assert L.smo_get_radius(4.0, 0.1, 0.01, 0.01) == pytest.approx(2 * r0, rel=1e-6)
+    assert L.smo_get_radius(4.0, 0.0, 0.01, 0.01) == pytest.approx(2 * r0, rel=1e-6)
+    assert L.smo_get_radius(4.0, float("nan"), 0.01, 0.01) == pytest.approx(2 * r0, rel=1e-6)
+
+
+# ---------------------------------------------------------------- K3/K4 data.vert:33-52,87-88 ; src/GlobalModel.cpp:67-74
+def test_k3_k4_checkerboard_neighbours_order():
+    cfg = cfg_small(W=32, H=24)
+    o = ol.Oracle(cfg)
+    rgb, depth, sem = plane_frame(cfg, 5000)
+    depth[10, 7] = 0          # hole at (i=7, j=10)
+    o.process_frame(rgb, depth, sem, IDENT)
+    o.process_frame(rgb, depth, sem, IDENT)
+    m = o.download_model()
+    # recover pixel of each new surfel from its position (identity pose, z = 5)
+    i = np.rint(m[:, 0] / m[:, 2] * cfg.fx + cfg.cx - 0.5).astype(int)
+    j = np.rint(m[:, 1] / m[:, 2] * cfg.fy + cfg.cy - 0.5).astype(int)
+    assert np.all((i + j) % 2 == 1)
+    emitted = set(zip(i.tolist(), j.tolist()))
+    for bad in [(7, 10), (6, 10), (8, 10), (7, 9), (7, 11)]:
+        assert bad not in emitted
+    expect = [(a, b) for a in range(32) for b in range(24)
+              if (a + b) % 2 == 1 and (a, b) not in [(7, 10), (6, 10), (8, 10), (7, 9), (7, 11)]]
+    assert list(zip(i.tolist(), j.tolist())) == expect      # x-outer / y-inner (K4)
+    c = o.counts()
+    assert c["count"] == len(expect) == c["unstable_count"] == c["data_count"]
+
+
+def test_k3_stereo_border_after_metricise():
+    cfg = cfg_small(W=160, H=48, border=80.0)
+    o = ol.Oracle(cfg)
+    rgb, depth, sem = plane_frame(cfg, 5000)
+    o.process_frame(rgb, depth, sem, IDENT)
+    dm = o.download_depth(0)
+    assert np.all(dm[:, :80] == 0) and np.all(dm[:, 80:] == np.float32(5.0))
+    o.process_frame(rgb, depth, sem, IDENT)
+    m = o.download_model()
+    i = np.rint(m[:, 0] / m[:, 2] * cfg.fx + cfg.cx - 0.5).astype(int)
+    assert i.min() == 81      # column 80 has a zero left neighbour
+
+
+def test_metricise_range():
+    cfg = cfg_small(W=8, H=1)
+    raw = np.array([[0, 1000, 1001, 29998, 29999, 30000, 65535, 5000]], np.uint16)
+    out = ol.metricise(cfg, raw)
+    exp = np.float32([0, 0, 1001, 29998, 0, 0, 0, 5000]) / np.float32(1000.0)
+    np.testing.assert_array_equal(out[0], exp)
+
+
+# ---------------------------------------------------------------- K5 index_map.vert:59, GL_LESS gui/GUI.cpp:32
+def test_k5_zbuffer_nearest_and_tie():
+    cfg = cfg_small()
+    o = ol.Oracle(cfg)
+    model = np.stack([
+        surfel(0, 0, 9.0),              # id 0 (dummy, elsewhere in depth)
+        surfel(0.5, 0.25, 6.0),         # id 1
+        surfel(0.5 * 4 / 6, 0.25 * 4 / 6, 4.0),   # id 2 same pixel, nearer
+        surfel(-0.5, 0.25, 5.0),        # id 3
+        surfel(-0.5, 0.25, 5.0),        # id 4 identical -> lower id wins
+    ])
+    o.upload_model(model)
+    o.stage_predict_indices(IDENT, 2, 30.0, 200)
+    idx, vc, ct, nr = o.download_index_map()
+    idx = idx.reshape(cfg.height, cfg.width)
+    def pix(s):
+        return (int(math.floor(s[1] / s[2] * cfg.fy + cfg.cy)), int(math.floor(s[0] / s[2] * cfg.fx + cfg.cx)))
+    assert pix(model[1]) == pix(model[2])
+    assert idx[pix(model[2])] == 2
+    assert idx[pix(model[3])] == 3
+    assert (idx > 0).sum() == 2           # id 0's pixel reads as "no surfel" (A5)
+    p = pix(model[2])[0] * cfg.width + pix(model[2])[1]
+    np.testing.assert_array_equal(vc[p], np.float32([model[2][0], model[2][1], 4.0, 0.9]))
+    np.testing.assert_array_equal(nr[p], np.float32([0, 0, 1, 0.05]))
+    # far plane: z >= far is not drawn
+    o.upload_model(np.stack([surfel(0, 0, 9), surfel(0, 0, 30.0), surfel(0.3, 0, 29.99)]))
+    o.stage_predict_indices(IDENT, 2, 30.0, 200)
+    idx = o.download_index_map()[0]
+    assert set(np.unique(idx).tolist()) == {0, 2}
+
+
+# ---------------------------------------------------------------- K6 data.vert:142, conflict.geom:15
+def test_k6_surfel_zero_never_fuses_never_conflicts():
+    cfg = cfg_small()
+    o = ol.Oracle(cfg)
+    rgb, depth, sem = plane_frame(cfg, 4000)
+    o.process_frame(rgb, depth, sem, IDENT)
+    o.process_frame(rgb, depth, sem, IDENT)
+    n1 = o.counts()["count"]
+    first = o.download_model()[0].copy()
+    # same frame again: everything fuses except surfel 0, whose pixel spawns a duplicate
+    o.process_frame(rgb, depth, sem, IDENT)
+    c = o.counts()
+    assert c["fused_count"] == n1 - 1 and c["unstable_count"] == 1 and c["count"] == n1 + 1
+    m = o.download_model()
+    np.testing.assert_array_equal(m[0], first)           # untouched: conf 0.9, time 1
+    # farther depth: every in-view surfel conflicts except id 0
+    rgb2, depth2, sem2 = plane_frame(cfg, 4001)
+    o.process_frame(rgb2, depth2, sem2, IDENT)
+    c2 = o.counts()
+    assert c2["conflict_count"] == n1          # ids 1..n1 (the duplicate included), not id 0
+    m2 = o.download_model()
+    np.testing.assert_array_equal(m2[0], first)
+
+
+# ---------------------------------------------------------------- K7 data.vert:151,177-194
+def test_k7_static_plane_fuses():
+    cfg = cfg_small()
+    o = ol.Oracle(cfg)
+    rgb, depth, sem = plane_frame(cfg, 4000, sem_val=7)
+    o.process_frame(rgb, depth, sem, IDENT)
+    o.process_frame(rgb, depth, sem, IDENT)
+    a = o.download_model()
+    rgb_b = rgb.copy()
+    rgb_b[..., 0] = 17
+    o.process_frame(rgb_b, depth, sem, IDENT)
+    b = o.download_model()
+    n = a.shape[0]
+    np.testing.assert_array_equal(b[1:n, 3], np.float32(0.9) + np.float32(0.9))
+    np.testing.assert_array_equal(b[1:n, 6], 1.0)        # initTime kept
+    np.testing.assert_array_equal(b[1:n, 7], 2.0)        # time updated
+    np.testing.assert_array_equal(b[1:n, 11], a[1:n, 11])
+    np.testing.assert_array_equal(b[1:n, 8:11], a[1:n, 8:11])
+    assert bits(b[1, 4]) == (7 << 24 | 17 << 16 | 100 << 8 | 50)   # colour := new colour
+    np.testing.assert_allclose(b[1:n, 0:3], a[1:n, 0:3], rtol=0, atol=1e-6)
+    assert o.counts()["conflict_count"] == 0
+
+
+# ---------------------------------------------------------------- K8 conflict.vert:64-73, back_map.geom:17
+def test_k8_farther_depth_culls():
+    cfg = cfg_small()
+    o = ol.Oracle(cfg)
+    rgb, depth, sem = plane_frame(cfg, 4000)
+    o.process_frame(rgb, depth, sem, IDENT)
+    o.process_frame(rgb, depth, sem, IDENT)
+    n1 = o.counts()["count"]
+    rgb2, depth2, sem2 = plane_frame(cfg, 4001)
+    o.process_frame(rgb2, depth2, sem2, IDENT)
+    c = o.counts()
+    assert c["conflict_count"] == n1 - 1
+    assert c["offset"] == 1                      # only surfel 0 survives the cull
+    assert c["unstable_count"] == n1 and c["count"] == n1 + 1
+    # closer depth never conflicts
+    o2 = ol.Oracle(cfg)
+    o2.process_frame(rgb, depth, sem, IDENT)
+    o2.process_frame(rgb, depth, sem, IDENT)
+    rgb3, depth3, sem3 = plane_frame(cfg, 3999)
+    o2.process_frame(rgb3, depth3, sem3, IDENT)
+    assert o2.counts()["conflict_count"] == 0 and o2.counts()["offset"] == n1
+
+
+# ---------------------------------------------------------------- K9/K10 conflict.vert:51-59
+def test_k9_k10_zero_depth_and_sky():
+    cfg = cfg_small()
+    model = np.stack([surfel(0, 0, 9.0), surfel(0.2, 0.1, 5.0, conf=0.9), surfel(-0.2, 0.1, 5.0, conf=1.8)])
+    dm = np.zeros((cfg.height, cfg.width), np.float32)
+    sem = np.zeros((cfg.height, cfg.width), np.uint8)
+    o = ol.Oracle(cfg)
+    o.upload_model(model)
+    o.set_frame(depth_metric=dm, sem=sem)
+    o.stage_process_conflict(IDENT, 1.0, 30.0, 0.0, 0)
+    assert o.counts()["conflict_count"] == 2           # zero depth => far+20 => conflict
+    o.stage_update_conflict(); o.stage_back_mapping()
+    m = o.download_model()
+    assert m.shape[0] == 2 and m[1, 3] == np.float32(1.8) - np.float32(1.0)
+    # clean mode: zero depth is NOT far
+    o.upload_model(model)
+    o.stage_process_conflict(IDENT, 1.0, 15.0, 0.1, 1)
+    assert o.counts()["conflict_count"] == 0
+    # sky pixel => conflict in either mode, whatever the depth
+    sem[:] = 10
+    dm[:] = 2.0
+    o.set_frame(depth_metric=dm, sem=sem)
+    o.stage_process_conflict(IDENT, 1.0, 15.0, 0.1, 1)
+    assert o.counts()["conflict_count"] == 2
+    # range gate: surfel at z >= max is not tested
+    o.stage_process_conflict(IDENT, 1.0, 5.0, 0.0, 0)
+    assert o.counts()["conflict_count"] == 0
+
+
+# ---------------------------------------------------------------- K11 index_map.vert:45
+def test_k11_time_window():
+    cfg = cfg_small()
+    model = np.stack([surfel(0, 0, 9.0), surfel(0.2, 0.1, 5.0, t0=1, t1=1), surfel(-0.2, 0.1, 5.0, t0=1, t1=100)])
+    o = ol.Oracle(cfg)
+    o.upload_model(model)
+    o.stage_predict_indices(IDENT, 250, 30.0, 200)
+    idx = o.download_index_map()[0]
+    assert set(np.unique(idx).tolist()) == {0, 2}       # 250-1 > 200 -> id 1 absent
+    o.stage_predict_indices(IDENT, 201, 30.0, 200)      # 201-1 == 200 -> not > -> present
+    assert set(np.unique(o.download_index_map()[0]).tolist()) == {0, 1, 2}
+    dm = np.zeros((cfg.height, cfg.width), np.float32)
+    o.set_frame(depth_metric=dm, sem=np.zeros_like(dm, dtype=np.uint8))
+    o.stage_process_conflict(IDENT, 1.0, 30.0, 0.0, 0)
+    assert o.counts()["conflict_count"] == 2            # conflict pass has no time test
+
+
+# ---------------------------------------------------------------- K12 src/SurfelMapping.cpp:142-154
+def test_k12_first_call_reference_only():
+    cfg = cfg_small()
+    o = ol.Oracle(cfg)
+    o.process_frame(*plane_frame(cfg, 4000), IDENT)
+    c = o.counts()
+    assert c["count"] == 0 and c["tick"] == 1
+
+
+# ---------------------------------------------------------------- K13 data.vert:54-57,158
+def test_k13_acos_domain():
+    L = ol.lib()
+    assert math.isnan(L.smo_acosf(np.float32(1.0000001)))
+    assert math.isnan(L.smo_acosf(-1.5))
+    assert math.isnan(L.smo_acosf(float("nan")))
+    assert L.smo_acosf(1.0) == 0.0
+    xs = np.linspace(-1, 1, 4001, dtype=np.float32)
+    got = np.array([L.smo_acosf(float(x)) for x in xs], np.float64)
+    np.testing.assert_allclose(got, np.arccos(xs.astype(np.float64)), atol=5e-7)
+
+
+def test_expf_accuracy():
+    L = ol.lib()
+    xs = np.linspace(-5, 1, 2001, dtype=np.float32)
+    got = np.array([L.smo_expf(float(x)) for x in xs], np.float64)
+    np.testing.assert_allclose(got, np.exp(xs.astype(np.float64)), rtol=3e-7)
+    assert L.smo_expf(0.0) == 1.0
+
+
+def test_invert4_rigid():
+    a = math.radians(20)
+    m = np.eye(4)
+    m[0, 0], m[0, 2], m[2, 0], m[2, 2] = math.cos(a), math.sin(a), -math.sin(a), math.cos(a)
+    m[:3, 3] = (1, -2, 3)
+    inv = ol.invert4(m.T.astype(np.float32).reshape(16)).reshape(4, 4).T
+    np.testing.assert_allclose(inv, np.linalg.inv(m), atol=1e-6)
+    np.testing.assert_array_equal(ol.invert4(IDENT), IDENT)
+
+
+# ---------------------------------------------------------------- frame invariants
+def test_frame_invariants_moving_camera():
+    from surfelmapping_amd import synth
+    cam = dict(width=320, height=120, fx=180.0, fy=180.0, cx=159.5, cy=59.5)
+    seq = synth.make_sequence(cam, synth.kitti_trajectory(6), seed=3)
+    cfg = ol.make_config(**cam, preprocess=0, stereo_border=20.0)
+    o = ol.Oracle(cfg)
+    prev = 0
+    for k, fr in enumerate(seq):
+        o.process_frame(*fr)
+        c = o.counts()
+        assert c["tick"] == k + 1
+        if k == 0:
+            continue
+        assert c["count"] == c["offset"] + c["unstable_count"]
+        assert c["data_count"] == c["fused_count"] + c["unstable_count"]
+        assert c["conflict_count"] <= max(prev - 1, 0)
+        m = o.download_model()
+        assert np.all(m[:, 5] == 0) and np.all(m[:, 3] > 0)
+        assert np.all(m[:, 6] <= m[:, 7]) and np.all(m[:, 7] <= k)
+        nn = np.linalg.norm(m[:, 8:11].astype(np.float64), axis=1)
+        np.testing.assert_allclose(nn, 1.0, atol=1e-6)
+        prev = c["count"]
+    assert prev > 0
