@@ -1,0 +1,161 @@
+/*
+ * sm_c_api.h -- C-ABI of the MI355X-native surfel-fusion core (libsurfelmapping_hip.so).
+ *
+ * The reference (SUSTech-SLAM-XYZZY/SurfelMapping) has no plugin/FFI layer: its boundary is
+ * the C++ class surface build_map.cpp / load_map.cpp / gui/GUI.cpp compile against.  This
+ * header is the thin C boundary the drop-in C++ facade (surfelmapping_amd/csrc/facade/) calls;
+ * every entry point names the reference interface it replaces (file:line under
+ * /root/reference).  Plain pointers and sizes only; no torch / HIP types in signatures.
+ *
+ * Threading: one sm_ctx = one HIP device + one stream; calls on a ctx are not re-entrant.
+ * Host-buffer entry points are synchronous (the reference glFinish()es after every pass,
+ * e.g. src/GlobalModel.cpp:341); *_device / *_async entry points only enqueue.
+ */
+#ifndef SM_C_API_H
+#define SM_C_API_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SM_API_VERSION 1
+
+/* error codes (reference: void returns + CheckGlDieOnError(); bool for map IO) */
+enum {
+    SM_OK = 0,
+    SM_E_ARG = -1,          /* null / inconsistent argument (reference would segfault: src/SurfelMapping.cpp:130) */
+    SM_E_CAPACITY = -2,     /* model would exceed MAX_VERTICES (unchecked in src/GlobalModel.cpp:627-629) */
+    SM_E_UNSUPPORTED = -3,
+    SM_E_HIP = -4,          /* a HIP runtime call failed; see sm_last_error() */
+    SM_E_NO_DEVICE = -5     /* no gfx950 device visible: the product has NO CPU fallback */
+};
+
+/* Config singleton values (src/Config.cpp:32-37) + the magic numbers of the hot path
+ * (src/SurfelMapping.cpp:197,261; src/IndexMap.cpp:21). */
+typedef struct sm_config {
+    int32_t width, height;         /* Config::W(), Config::H() */
+    float fx, fy, cx, cy;          /* Config::fx() ... */
+    float near_clip;               /* 1.0  Config::nearClip() */
+    float far_clip;                /* 30.0 Config::farClip()  */
+    float fuse_thresh;             /* 0.0  Config::surfelFuseDistanceThreshFactor() */
+    int32_t max_sqrt_vertices;     /* 5000 Config::maxSqrtVertices(); capacity = its square */
+    int32_t time_delta;            /* 200  src/SurfelMapping.cpp:197 */
+    float stereo_border;           /* 80   src/SurfelMapping.cpp:261 */
+    int32_t preprocess;            /* 0: metricise only (p0a); 1: full chain p0a..p0e */
+    int32_t conflict_cap;          /* 1: only the first W*H conflicts take effect (conflictVbo size, src/GlobalModel.cpp:54-57) */
+    int32_t device;                /* HIP device ordinal */
+    int32_t enable_timing;         /* 1: record hipEvents per stage (sm_stage_timings) */
+} sm_config;
+
+/* GlobalModel counters (src/GlobalModel.cpp:860-888) + tick (src/SurfelMapping.h:100) */
+typedef struct sm_counts {
+    uint32_t count;           /* getModel().second    */
+    uint32_t offset;          /* getOffset()          */
+    uint32_t data_count;      /* getData().second     */
+    uint32_t conflict_count;  /* getConflict().second */
+    uint32_t unstable_count;  /* getUnstable().second */
+    uint32_t fused_count;     /* data entries that update an existing surfel (F) */
+    uint32_t visible_count;   /* surfels that passed the index-map view test (V) */
+    int32_t tick;
+} sm_counts;
+
+/* Stage timings in milliseconds, labelled with the reference's TICK/TOCK names
+ * (src/SurfelMapping.cpp:120-250, src/GlobalModel.cpp:258,350,519,583). */
+typedef struct sm_timings {
+    float preprocess;         /* "Preprocess"         */
+    float conflict;           /* "Conflict" (conflict test + cull + compaction) */
+    float index_map;          /* "indexMap" (0 when fused into the cull kernel) */
+    float data_association;   /* "Data::Association"  */
+    float concatenate;        /* "Concatenate"        */
+    float run;                /* "Run" whole frame    */
+    /* dominant kernel (conflict-cull-compact-splat): last launch, for the roofline */
+    float cull_kernel;
+    float assoc_kernel;
+} sm_timings;
+
+enum { SM_TEX_DEPTH_METRIC = 0, SM_TEX_DEPTH_FILTERED = 1, SM_TEX_LAST = 2 };
+
+typedef struct sm_ctx sm_ctx;
+
+int sm_api_version(void);
+const char *sm_last_error(void);
+
+/* Config::getInstance(fx,fy,cx,cy,rows,cols) defaults: src/Config.cpp:7-38 */
+int sm_default_config(sm_config *c, int width, int height, float fx, float fy, float cx, float cy);
+
+/* SurfelMapping::SurfelMapping() (src/SurfelMapping.cpp:12-25): allocates all device buffers. */
+sm_ctx *sm_create(const sm_config *c);
+/* SurfelMapping::~SurfelMapping() (src/SurfelMapping.cpp:27-49) */
+void sm_destroy(sm_ctx *s);
+
+/* SurfelMapping::processFrame (src/SurfelMapping.h:31-34, src/SurfelMapping.cpp:115-251).
+ * rgb H*W*3 u8 (R first), depth_mm H*W u16 (0 invalid), semantic H*W u8, pose = column-major
+ * 4x4 camera->world (Eigen::Matrix4f storage).  Inputs are borrowed for the call only. */
+int sm_process_frame(sm_ctx *s, const uint8_t *rgb, const uint16_t *depth_mm,
+                     const uint8_t *semantic, const float *pose16);
+/* Same, inputs already resident in device memory of this ctx's GPU; enqueue only. */
+int sm_process_frame_device(sm_ctx *s, const uint8_t *d_rgb, const uint16_t *d_depth_mm,
+                            const uint8_t *d_semantic, const float *pose16);
+/* Wait for all enqueued work; refresh counters; returns a sticky device-side error. */
+int sm_sync(sm_ctx *s);
+
+/* SurfelMapping::cleanPoints (src/SurfelMapping.cpp:496-532) */
+int sm_clean_points(sm_ctx *s, const uint16_t *depth_mm, const uint8_t *semantic,
+                    const float *pose16);
+/* SurfelMapping::reset (src/SurfelMapping.cpp:436-441) */
+int sm_reset(sm_ctx *s);
+
+/* GlobalModel::getModel/getData/getConflict/getUnstable/getOffset counts */
+int sm_get_counts(sm_ctx *s, sm_counts *out);
+/* GlobalModel::downloadMap payload (src/GlobalModel.cpp:905-911): AoS, 12 floats/surfel */
+int sm_download_model_aos(sm_ctx *s, float *dst12, uint32_t cap, uint32_t *n);
+/* GlobalModel::uploadMap payload (src/GlobalModel.cpp:995-1002) */
+int sm_upload_model_aos(sm_ctx *s, const float *src12, uint32_t n);
+/* GlobalModel::downloadMap / uploadMap files (src/GlobalModel.cpp:901-1011) */
+int sm_save_map(sm_ctx *s, const char *path, int32_t start_id, int32_t end_id);
+int sm_load_map(sm_ctx *s, const char *path, int32_t *start_id, int32_t *end_id);
+/* IndexMap::indexTex/vertConfTex/colorTimeTex/normalRadTex read-back (src/IndexMap.h:70-88),
+ * row-major H*W; any pointer may be NULL. */
+int sm_download_index_map(sm_ctx *s, int32_t *id, float *vert_conf4, float *color_time4,
+                          float *norm_rad4);
+/* SurfelMapping::getTexture(DEPTH_METRIC / DEPTH_FILTERED / "LAST") read-back, row-major */
+int sm_download_depth(sm_ctx *s, int which, float *dst);
+
+/* ---- per-pass entry points (GlobalModel / IndexMap methods), synchronous ---- */
+/* Upload RGB / metric depth / semantic textures directly (bypasses p0). */
+int sm_set_frame(sm_ctx *s, const uint8_t *rgb, const float *depth_metric,
+                 const uint8_t *semantic);
+int sm_set_tick(sm_ctx *s, int32_t tick);
+/* GlobalModel::processConflict + updateConflict (src/GlobalModel.cpp:396-515): conflict test,
+ * in-place confidence decrement marks; sets conflict_count. */
+int sm_stage_conflict(sm_ctx *s, const float *pose16, float min_depth, float max_depth,
+                      float fuse_thresh, int is_clean);
+/* GlobalModel::backMapping + buildModelMap (src/GlobalModel.cpp:517-579,639-681): stable
+ * compaction of surfels with conf > 0; sets count = offset. */
+int sm_stage_cull(sm_ctx *s);
+/* IndexMap::predictIndices (src/IndexMap.cpp:138-198) */
+int sm_stage_splat(sm_ctx *s, const float *pose16, int32_t time, float depth_cutoff,
+                   int32_t time_delta);
+/* GlobalModel::dataAssociate + updateFuse + backMapping + concatenate + buildModelMap
+ * (src/GlobalModel.cpp:246-394,581-637) */
+int sm_stage_associate_fuse(sm_ctx *s, const float *pose16, int32_t time, float depth_min,
+                            float depth_max);
+
+/* Stopwatch::getTimings() equivalent (src/Utils/Stopwatch.h:85-88) -- needs enable_timing */
+int sm_stage_timings(sm_ctx *s, sm_timings *out);
+
+/* ---- device-memory helpers for callers that stage frames in HBM ---- */
+void *sm_device_alloc(sm_ctx *s, size_t bytes);
+int sm_device_free(sm_ctx *s, void *p);
+int sm_device_upload(sm_ctx *s, void *dst_device, const void *src_host, size_t bytes);
+/* raw device pointer of the 64-bit depth|id key map (W*H, column-major) for the multi-GPU
+ * min-reduction, and the entry points that bracket it */
+void *sm_key_map_device_ptr(sm_ctx *s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SM_C_API_H */

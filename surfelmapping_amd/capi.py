@@ -1,0 +1,277 @@
+"""ctypes binding of the C-ABI in include/sm_c_api.h (libsurfelmapping_hip.so).
+
+This is plumbing only: every call goes straight to the HIP library.  There is NO CPU
+fallback -- if the shared library is missing or no GPU is visible, calls fail loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libsurfelmapping_hip.so")
+
+SM_OK, SM_E_ARG, SM_E_CAPACITY, SM_E_UNSUPPORTED, SM_E_HIP, SM_E_NO_DEVICE = 0, -1, -2, -3, -4, -5
+TEX_DEPTH_METRIC, TEX_DEPTH_FILTERED, TEX_LAST = 0, 1, 2
+
+# every extern "C" symbol include/sm_c_api.h declares
+SYMBOLS = (
+    "sm_api_version", "sm_last_error", "sm_default_config", "sm_create", "sm_destroy",
+    "sm_process_frame", "sm_process_frame_device", "sm_sync", "sm_clean_points", "sm_reset",
+    "sm_get_counts", "sm_download_model_aos", "sm_upload_model_aos", "sm_save_map", "sm_load_map",
+    "sm_download_index_map", "sm_download_depth", "sm_set_frame", "sm_set_tick",
+    "sm_stage_conflict", "sm_stage_cull", "sm_stage_splat", "sm_stage_associate_fuse",
+    "sm_stage_timings", "sm_device_alloc", "sm_device_free", "sm_device_upload",
+    "sm_key_map_device_ptr",
+)
+
+
+class SmConfig(C.Structure):
+    _fields_ = [
+        ("width", C.c_int32), ("height", C.c_int32),
+        ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float),
+        ("near_clip", C.c_float), ("far_clip", C.c_float), ("fuse_thresh", C.c_float),
+        ("max_sqrt_vertices", C.c_int32), ("time_delta", C.c_int32),
+        ("stereo_border", C.c_float), ("preprocess", C.c_int32), ("conflict_cap", C.c_int32),
+        ("device", C.c_int32), ("enable_timing", C.c_int32),
+    ]
+
+
+class SmCounts(C.Structure):
+    _fields_ = [
+        ("count", C.c_uint32), ("offset", C.c_uint32), ("data_count", C.c_uint32),
+        ("conflict_count", C.c_uint32), ("unstable_count", C.c_uint32),
+        ("fused_count", C.c_uint32), ("visible_count", C.c_uint32), ("tick", C.c_int32),
+    ]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+class SmTimings(C.Structure):
+    _fields_ = [(n, C.c_float) for n in (
+        "preprocess", "conflict", "index_map", "data_association", "concatenate", "run",
+        "cull_kernel", "assoc_kernel")]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+class SurfelMapError(RuntimeError):
+    def __init__(self, what, rc, detail=""):
+        super().__init__(f"{what} failed: rc={rc} {detail}".strip())
+        self.rc = rc
+
+
+_lib = None
+
+
+def load():
+    """dlopen the HIP library (no compute).  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(make -C surfelmapping_amd/csrc). surfelmapping_amd has no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, u32p = C.c_void_p, C.POINTER(C.c_uint32)
+    L.sm_api_version.restype = C.c_int
+    L.sm_last_error.restype = C.c_char_p
+    L.sm_default_config.argtypes = [C.POINTER(SmConfig), C.c_int, C.c_int] + [C.c_float] * 4
+    L.sm_create.restype = vp
+    L.sm_create.argtypes = [C.POINTER(SmConfig)]
+    L.sm_destroy.restype = None
+    L.sm_destroy.argtypes = [vp]
+    L.sm_process_frame.argtypes = [vp, vp, vp, vp, vp]
+    L.sm_process_frame_device.argtypes = [vp, vp, vp, vp, vp]
+    L.sm_sync.argtypes = [vp]
+    L.sm_clean_points.argtypes = [vp, vp, vp, vp]
+    L.sm_reset.argtypes = [vp]
+    L.sm_get_counts.argtypes = [vp, C.POINTER(SmCounts)]
+    L.sm_download_model_aos.argtypes = [vp, vp, C.c_uint32, u32p]
+    L.sm_upload_model_aos.argtypes = [vp, vp, C.c_uint32]
+    L.sm_save_map.argtypes = [vp, C.c_char_p, C.c_int32, C.c_int32]
+    L.sm_load_map.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    L.sm_download_index_map.argtypes = [vp, vp, vp, vp, vp]
+    L.sm_download_depth.argtypes = [vp, C.c_int, vp]
+    L.sm_set_frame.argtypes = [vp, vp, vp, vp]
+    L.sm_set_tick.argtypes = [vp, C.c_int32]
+    L.sm_stage_conflict.argtypes = [vp, vp, C.c_float, C.c_float, C.c_float, C.c_int]
+    L.sm_stage_cull.argtypes = [vp]
+    L.sm_stage_splat.argtypes = [vp, vp, C.c_int32, C.c_float, C.c_int32]
+    L.sm_stage_associate_fuse.argtypes = [vp, vp, C.c_int32, C.c_float, C.c_float]
+    L.sm_stage_timings.argtypes = [vp, C.POINTER(SmTimings)]
+    L.sm_device_alloc.restype = vp
+    L.sm_device_alloc.argtypes = [vp, C.c_size_t]
+    L.sm_device_free.argtypes = [vp, vp]
+    L.sm_device_upload.argtypes = [vp, vp, vp, C.c_size_t]
+    L.sm_key_map_device_ptr.restype = vp
+    L.sm_key_map_device_ptr.argtypes = [vp]
+    for name in SYMBOLS:
+        getattr(L, name)          # AttributeError here = the library does not match the header
+    _lib = L
+    return L
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def make_config(width, height, fx, fy, cx, cy, **over) -> SmConfig:
+    c = SmConfig()
+    load().sm_default_config(C.byref(c), width, height, fx, fy, cx, cy)
+    for k, v in over.items():
+        if not hasattr(c, k):
+            raise KeyError(k)
+        setattr(c, k, v)
+    return c
+
+
+class SurfelMap:
+    """Host-side handle mirroring SurfelMapping / GlobalModel / IndexMap of the reference
+    (src/SurfelMapping.h:31-96, src/GlobalModel.h:22-120, src/IndexMap.h:34-88)."""
+
+    def __init__(self, cfg: SmConfig):
+        self._L = load()
+        self.cfg = cfg
+        self.W, self.H = cfg.width, cfg.height
+        self.P = self.W * self.H
+        self._h = self._L.sm_create(C.byref(cfg))
+        if not self._h:
+            raise SurfelMapError("sm_create", SM_E_NO_DEVICE, self._L.sm_last_error().decode())
+
+    def _chk(self, rc, what, allow=(0,)):
+        if rc not in allow:
+            raise SurfelMapError(what, rc, self._L.sm_last_error().decode())
+        return rc
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.sm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- SurfelMapping
+    def process_frame(self, rgb, depth, sem, pose, allow=(0,)):
+        rgb = np.ascontiguousarray(rgb, np.uint8)
+        depth = None if depth is None else np.ascontiguousarray(depth, np.uint16)
+        sem = None if sem is None else np.ascontiguousarray(sem, np.uint8)
+        pose = np.ascontiguousarray(pose, np.float32)
+        return self._chk(self._L.sm_process_frame(self._h, _ptr(rgb), _ptr(depth), _ptr(sem), _ptr(pose)),
+                         "sm_process_frame", allow)
+
+    def process_frame_device(self, d_rgb, d_depth, d_sem, pose):
+        pose = np.ascontiguousarray(pose, np.float32)
+        return self._chk(self._L.sm_process_frame_device(self._h, d_rgb, d_depth, d_sem, _ptr(pose)),
+                         "sm_process_frame_device")
+
+    def sync(self, allow=(0,)):
+        return self._chk(self._L.sm_sync(self._h), "sm_sync", allow)
+
+    def clean_points(self, depth, sem, pose):
+        depth = np.ascontiguousarray(depth, np.uint16)
+        sem = np.ascontiguousarray(sem, np.uint8)
+        pose = np.ascontiguousarray(pose, np.float32)
+        self._chk(self._L.sm_clean_points(self._h, _ptr(depth), _ptr(sem), _ptr(pose)), "sm_clean_points")
+
+    def reset(self):
+        self._chk(self._L.sm_reset(self._h), "sm_reset")
+
+    # -- GlobalModel
+    def counts(self) -> dict:
+        c = SmCounts()
+        self._chk(self._L.sm_get_counts(self._h, C.byref(c)), "sm_get_counts")
+        return c.as_dict()
+
+    def download_model(self) -> np.ndarray:
+        n = C.c_uint32()
+        self._chk(self._L.sm_download_model_aos(self._h, None, 0, C.byref(n)), "sm_download_model_aos")
+        out = np.zeros((n.value, 12), np.float32)
+        self._chk(self._L.sm_download_model_aos(self._h, _ptr(out), n.value, C.byref(n)), "sm_download_model_aos")
+        return out
+
+    def upload_model(self, m):
+        m = np.ascontiguousarray(m, np.float32)
+        self._chk(self._L.sm_upload_model_aos(self._h, _ptr(m), m.shape[0]), "sm_upload_model_aos")
+
+    def save_map(self, path, start_id=0, end_id=0):
+        self._chk(self._L.sm_save_map(self._h, os.fsencode(path), start_id, end_id), "sm_save_map")
+
+    def load_map(self, path):
+        a, b = C.c_int32(), C.c_int32()
+        self._chk(self._L.sm_load_map(self._h, os.fsencode(path), C.byref(a), C.byref(b)), "sm_load_map")
+        return a.value, b.value
+
+    # -- IndexMap
+    def download_index_map(self):
+        P = self.P
+        idx = np.zeros(P, np.int32)
+        vc = np.zeros((P, 4), np.float32)
+        ct = np.zeros((P, 4), np.float32)
+        nr = np.zeros((P, 4), np.float32)
+        self._chk(self._L.sm_download_index_map(self._h, _ptr(idx), _ptr(vc), _ptr(ct), _ptr(nr)),
+                  "sm_download_index_map")
+        return idx, vc, ct, nr
+
+    def download_depth(self, which=TEX_DEPTH_METRIC):
+        out = np.zeros((self.H, self.W), np.float32)
+        self._chk(self._L.sm_download_depth(self._h, which, _ptr(out)), "sm_download_depth")
+        return out
+
+    # -- per-pass entry points
+    def set_frame(self, rgb=None, depth_metric=None, sem=None):
+        rgb = None if rgb is None else np.ascontiguousarray(rgb, np.uint8)
+        dm = None if depth_metric is None else np.ascontiguousarray(depth_metric, np.float32)
+        sem = None if sem is None else np.ascontiguousarray(sem, np.uint8)
+        self._chk(self._L.sm_set_frame(self._h, _ptr(rgb), _ptr(dm), _ptr(sem)), "sm_set_frame")
+
+    def set_tick(self, tick):
+        self._chk(self._L.sm_set_tick(self._h, tick), "sm_set_tick")
+
+    def stage_conflict(self, pose, min_depth, max_depth, fuse_thresh=0.0, is_clean=0):
+        pose = np.ascontiguousarray(pose, np.float32)
+        self._chk(self._L.sm_stage_conflict(self._h, _ptr(pose), min_depth, max_depth, fuse_thresh, is_clean),
+                  "sm_stage_conflict")
+
+    def stage_cull(self):
+        self._chk(self._L.sm_stage_cull(self._h), "sm_stage_cull")
+
+    def stage_splat(self, pose, time, depth_cutoff, time_delta):
+        pose = np.ascontiguousarray(pose, np.float32)
+        self._chk(self._L.sm_stage_splat(self._h, _ptr(pose), time, depth_cutoff, time_delta), "sm_stage_splat")
+
+    def stage_associate_fuse(self, pose, time, dmin, dmax, allow=(0,)):
+        pose = np.ascontiguousarray(pose, np.float32)
+        return self._chk(self._L.sm_stage_associate_fuse(self._h, _ptr(pose), time, dmin, dmax),
+                         "sm_stage_associate_fuse", allow)
+
+    def timings(self) -> dict:
+        t = SmTimings()
+        self._chk(self._L.sm_stage_timings(self._h, C.byref(t)), "sm_stage_timings")
+        return t.as_dict()
+
+    # -- device staging helpers
+    def device_alloc(self, nbytes: int) -> int:
+        p = self._L.sm_device_alloc(self._h, nbytes)
+        if not p:
+            raise SurfelMapError("sm_device_alloc", SM_E_HIP, self._L.sm_last_error().decode())
+        return p
+
+    def device_free(self, p: int):
+        self._chk(self._L.sm_device_free(self._h, p), "sm_device_free")
+
+    def device_upload(self, dst: int, arr: np.ndarray):
+        arr = np.ascontiguousarray(arr)
+        self._chk(self._L.sm_device_upload(self._h, dst, _ptr(arr), arr.nbytes), "sm_device_upload")
+
+    def key_map_device_ptr(self) -> int:
+        return self._L.sm_key_map_device_ptr(self._h)

@@ -1,0 +1,819 @@
+// sm_api.hip -- C-ABI (include/sm_c_api.h) of the gfx950 surfel-fusion core: context, buffers,
+// frame sequencing (SurfelMapping::processFrame, /root/reference/src/SurfelMapping.cpp:115-251)
+// and launches of the kernels in sm_kernels.h.  No CPU fallback: without a HIP device
+// sm_create() fails with SM_E_NO_DEVICE.
+#include "../../include/sm_c_api.h"
+#include "sm_kernels.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace sm;
+
+namespace {
+
+thread_local std::string g_err;
+
+void set_err(const char *what, hipError_t e, const char *file, int line)
+{
+    char buf[512];
+    snprintf(buf, sizeof buf, "%s: %s (%s:%d)", what, hipGetErrorString(e), file, line);
+    g_err = buf;
+}
+
+#define HIPCK(expr)                                              \
+    do {                                                         \
+        hipError_t e_ = (expr);                                  \
+        if (e_ != hipSuccess) {                                  \
+            set_err(#expr, e_, __FILE__, __LINE__);              \
+            return SM_E_HIP;                                     \
+        }                                                        \
+    } while (0)
+
+constexpr int EV_RING = 256;
+constexpr int MAX_GRID = 2048;   // 256 CUs x 8 workgroups
+
+// general 4x4 inverse, column-major, cofactor expansion, inv = adj * (1/det), fp32
+// (the role of Eigen::Matrix4f::inverse() at src/GlobalModel.cpp:419, src/IndexMap.cpp:157)
+void invert4(const float *m, float *out)
+{
+    float a[16];
+    a[0] = m[5] * m[10] * m[15] - m[5] * m[11] * m[14] - m[9] * m[6] * m[15] + m[9] * m[7] * m[14] +
+           m[13] * m[6] * m[11] - m[13] * m[7] * m[10];
+    a[4] = -m[4] * m[10] * m[15] + m[4] * m[11] * m[14] + m[8] * m[6] * m[15] - m[8] * m[7] * m[14] -
+           m[12] * m[6] * m[11] + m[12] * m[7] * m[10];
+    a[8] = m[4] * m[9] * m[15] - m[4] * m[11] * m[13] - m[8] * m[5] * m[15] + m[8] * m[7] * m[13] +
+           m[12] * m[5] * m[11] - m[12] * m[7] * m[9];
+    a[12] = -m[4] * m[9] * m[14] + m[4] * m[10] * m[13] + m[8] * m[5] * m[14] - m[8] * m[6] * m[13] -
+            m[12] * m[5] * m[10] + m[12] * m[6] * m[9];
+    a[1] = -m[1] * m[10] * m[15] + m[1] * m[11] * m[14] + m[9] * m[2] * m[15] - m[9] * m[3] * m[14] -
+           m[13] * m[2] * m[11] + m[13] * m[3] * m[10];
+    a[5] = m[0] * m[10] * m[15] - m[0] * m[11] * m[14] - m[8] * m[2] * m[15] + m[8] * m[3] * m[14] +
+           m[12] * m[2] * m[11] - m[12] * m[3] * m[10];
+    a[9] = -m[0] * m[9] * m[15] + m[0] * m[11] * m[13] + m[8] * m[1] * m[15] - m[8] * m[3] * m[13] -
+           m[12] * m[1] * m[11] + m[12] * m[3] * m[9];
+    a[13] = m[0] * m[9] * m[14] - m[0] * m[10] * m[13] - m[8] * m[1] * m[14] + m[8] * m[2] * m[13] +
+            m[12] * m[1] * m[10] - m[12] * m[2] * m[9];
+    a[2] = m[1] * m[6] * m[15] - m[1] * m[7] * m[14] - m[5] * m[2] * m[15] + m[5] * m[3] * m[14] +
+           m[13] * m[2] * m[7] - m[13] * m[3] * m[6];
+    a[6] = -m[0] * m[6] * m[15] + m[0] * m[7] * m[14] + m[4] * m[2] * m[15] - m[4] * m[3] * m[14] -
+           m[12] * m[2] * m[7] + m[12] * m[3] * m[6];
+    a[10] = m[0] * m[5] * m[15] - m[0] * m[7] * m[13] - m[4] * m[1] * m[15] + m[4] * m[3] * m[13] +
+            m[12] * m[1] * m[7] - m[12] * m[3] * m[5];
+    a[14] = -m[0] * m[5] * m[14] + m[0] * m[6] * m[13] + m[4] * m[1] * m[14] - m[4] * m[2] * m[13] -
+            m[12] * m[1] * m[6] + m[12] * m[2] * m[5];
+    a[3] = -m[1] * m[6] * m[11] + m[1] * m[7] * m[10] + m[5] * m[2] * m[11] - m[5] * m[3] * m[10] -
+           m[9] * m[2] * m[7] + m[9] * m[3] * m[6];
+    a[7] = m[0] * m[6] * m[11] - m[0] * m[7] * m[10] - m[4] * m[2] * m[11] + m[4] * m[3] * m[10] +
+           m[8] * m[2] * m[7] - m[8] * m[3] * m[6];
+    a[11] = -m[0] * m[5] * m[11] + m[0] * m[7] * m[9] + m[4] * m[1] * m[11] - m[4] * m[3] * m[9] -
+            m[8] * m[1] * m[7] + m[8] * m[3] * m[5];
+    a[15] = m[0] * m[5] * m[10] - m[0] * m[6] * m[9] - m[4] * m[1] * m[10] + m[4] * m[2] * m[9] +
+            m[8] * m[1] * m[6] - m[8] * m[2] * m[5];
+    const float det = m[0] * a[0] + m[1] * a[4] + m[2] * a[8] + m[3] * a[12];
+    const float rdet = 1.0f / det;
+    for (int i = 0; i < 16; ++i) out[i] = a[i] * rdet;
+}
+
+}  // namespace
+
+struct sm_ctx {
+    sm_config cfg{};
+    int W = 0, H = 0, P = 0;
+    uint32_t cap = 0;                 // MAX_VERTICES
+    hipStream_t stream = nullptr;
+    Model M{};
+    DevState *d_state = nullptr;
+    DevState *h_state = nullptr;      // pinned mirror
+    // column-major frame images
+    float *d_depthT = nullptr, *d_filteredT = nullptr, *d_lastT = nullptr;
+    uint32_t *d_rgbsT = nullptr;
+    uint64_t *d_keyT = nullptr;
+    // row-major staging of the caller's inputs
+    uint8_t *d_rgb = nullptr, *d_sem = nullptr;
+    uint16_t *d_depth_raw = nullptr;
+    float *d_depth_f32 = nullptr;
+    float *d_xs = nullptr, *d_ys = nullptr;
+    // cull scratch
+    uint64_t *d_cm = nullptr, *d_dm = nullptr, *d_zm = nullptr;
+    uint32_t *d_tile_cnt = nullptr, *d_tile_allow = nullptr, *d_tile_keep = nullptr;
+    // association scratch
+    uint64_t *d_newmask = nullptr;
+    uint32_t *d_blk_new = nullptr, *d_blk_fused = nullptr, *d_blk_prefix = nullptr;
+    int n_pix_blocks = 0;
+    uint32_t n_odd_pixels = 0;
+    // export staging
+    void *d_export = nullptr;
+    size_t export_bytes = 0;
+    // host frame state (src/SurfelMapping.h:100-103)
+    int tick = 0;
+    bool ref_set = false;
+    float curr_pose[16], last_pose[16];
+    uint32_t count_bound = 0;         // host upper bound of the device-side count (grid sizing)
+    bool pending_cull = false;
+    uint32_t count_before_cull = 0;
+    sm_counts counts{};
+    std::vector<void *> user_allocs;
+    // timing
+    hipEvent_t ev[6][EV_RING];        // 0/1 frame, 2/3 cull kernel, 4/5 assoc kernel
+    bool ev_ok = false;
+    uint64_t ev_frames = 0, ev_read = 0;
+};
+
+namespace {
+
+template <typename T>
+int dalloc(T **p, size_t n)
+{
+    HIPCK(hipMalloc((void **)p, std::max<size_t>(n, 1) * sizeof(T)));
+    return SM_OK;
+}
+
+int alloc_set(SurfelSet &s, size_t cap)
+{
+    int rc;
+    if ((rc = dalloc(&s.pos_conf, cap))) return rc;
+    if ((rc = dalloc(&s.norm_rad, cap))) return rc;
+    if ((rc = dalloc(&s.color, cap))) return rc;
+    if ((rc = dalloc(&s.init_time, cap))) return rc;
+    if ((rc = dalloc(&s.time, cap))) return rc;
+    return SM_OK;
+}
+
+void free_set(SurfelSet &s)
+{
+    (void)hipFree(s.pos_conf); (void)hipFree(s.norm_rad); (void)hipFree(s.color);
+    (void)hipFree(s.init_time); (void)hipFree(s.time);
+}
+
+FrameParams make_params(const sm_ctx *s, const float *pose)
+{
+    FrameParams fp;
+    memset(&fp, 0, sizeof fp);
+    memcpy(fp.pose, pose, 64);
+    invert4(pose, fp.t_inv);
+    const sm_config &c = s->cfg;
+    fp.fx = c.fx; fp.fy = c.fy; fp.cx = c.cx; fp.cy = c.cy;
+    fp.inv_fx = (float)(1.0 / (double)c.fx);
+    fp.inv_fy = (float)(1.0 / (double)c.fy);
+    fp.cols = (float)c.width; fp.rows = (float)c.height;
+    fp.W = c.width; fp.H = c.height; fp.P = s->P;
+    fp.min_depth = c.near_clip; fp.max_depth = c.far_clip;
+    fp.conflict_thresh = c.fuse_thresh;
+    fp.fuse_thresh = c.fuse_thresh;
+    fp.stereo_border = c.stereo_border;
+    fp.is_clean = 0;
+    fp.time = s->tick;
+    fp.time_delta = c.time_delta;
+    fp.depth_cutoff = c.far_clip;
+    fp.conflict_cap = c.conflict_cap ? (uint32_t)s->P : 0xFFFFFFFFu;
+    fp.max_vertices = s->cap;
+    return fp;
+}
+
+int grid_surfels(const sm_ctx *s)
+{
+    const uint64_t tiles = ((uint64_t)s->count_bound + TILE - 1) / TILE;
+    return (int)std::min<uint64_t>(std::max<uint64_t>(tiles, 1), MAX_GRID);
+}
+
+int push_state(sm_ctx *s)
+{
+    HIPCK(hipMemcpyAsync(s->d_state, s->h_state, sizeof(DevState), hipMemcpyHostToDevice, s->stream));
+    HIPCK(hipStreamSynchronize(s->stream));
+    return SM_OK;
+}
+
+int pull_state(sm_ctx *s)
+{
+    HIPCK(hipMemcpyAsync(s->h_state, s->d_state, sizeof(DevState), hipMemcpyDeviceToHost, s->stream));
+    HIPCK(hipStreamSynchronize(s->stream));
+    const DevState &d = *s->h_state;
+    s->counts.count = s->pending_cull ? s->count_before_cull : d.count;
+    s->counts.offset = d.offset;
+    s->counts.data_count = d.data_count;
+    s->counts.conflict_count = d.conflict_count;
+    s->counts.unstable_count = d.unstable_count;
+    s->counts.fused_count = d.fused_count;
+    s->counts.visible_count = d.visible_count;
+    s->counts.tick = s->tick;
+    s->count_bound = std::max(d.count, d.cull_n * (s->pending_cull ? 1u : 0u));
+    return SM_OK;
+}
+
+int take_error(sm_ctx *s)
+{
+    if (s->h_state->error != 0) {
+        const int e = s->h_state->error;
+        s->h_state->error = 0;
+        HIPCK(hipMemcpyAsync(&s->d_state->error, &s->h_state->error, sizeof(int32_t), hipMemcpyHostToDevice, s->stream));
+        HIPCK(hipStreamSynchronize(s->stream));
+        g_err = e == SM_E_CAPACITY ? "model capacity (MAX_VERTICES) exceeded; frame's new surfels dropped" : "device-side error";
+        return e;
+    }
+    return SM_OK;
+}
+
+// ---- launches ----
+
+int launch_prep(sm_ctx *s, const uint8_t *rgb, const uint16_t *raw, const uint8_t *sem, const float *dm,
+                const FrameParams &fp, bool clear_keys)
+{
+    const int tiles = ((s->W + 63) / 64) * ((s->H + 63) / 64);
+    hipLaunchKernelGGL(k_prep, dim3(tiles), dim3(256), 0, s->stream, rgb, raw, sem, dm, s->d_depthT, s->d_rgbsT,
+                       clear_keys ? s->d_keyT : nullptr, fp);
+    HIPCK(hipGetLastError());
+    return SM_OK;
+}
+
+int launch_conflict(sm_ctx *s, const FrameParams &fp)
+{
+    hipLaunchKernelGGL(k_conflict, dim3(grid_surfels(s)), dim3(256), 0, s->stream, s->M, s->d_state, fp, s->d_depthT,
+                       s->d_rgbsT, s->d_cm, s->d_dm, s->d_zm, s->d_tile_cnt);
+    HIPCK(hipGetLastError());
+    hipLaunchKernelGGL(k_scan_cull, dim3(1), dim3(1024), 0, s->stream, s->d_state, fp, s->d_cm, s->d_dm, s->d_zm,
+                       s->d_tile_cnt, s->d_tile_allow, s->d_tile_keep);
+    HIPCK(hipGetLastError());
+    return SM_OK;
+}
+
+int launch_compact(sm_ctx *s, const FrameParams &fp, bool splat, bool timed)
+{
+    const int slot = (int)(s->ev_frames % EV_RING);
+    if (timed && s->ev_ok) HIPCK(hipEventRecord(s->ev[2][slot], s->stream));
+    if (splat)
+        hipLaunchKernelGGL(k_compact<true>, dim3(grid_surfels(s)), dim3(256), 0, s->stream, s->M, s->d_state, fp, s->d_cm,
+                           s->d_dm, s->d_zm, s->d_tile_cnt, s->d_tile_allow, s->d_tile_keep, s->d_keyT);
+    else
+        hipLaunchKernelGGL(k_compact<false>, dim3(grid_surfels(s)), dim3(256), 0, s->stream, s->M, s->d_state, fp, s->d_cm,
+                           s->d_dm, s->d_zm, s->d_tile_cnt, s->d_tile_allow, s->d_tile_keep, s->d_keyT);
+    HIPCK(hipGetLastError());
+    if (timed && s->ev_ok) HIPCK(hipEventRecord(s->ev[3][slot], s->stream));
+    return SM_OK;
+}
+
+int launch_associate(sm_ctx *s, const FrameParams &fp, bool timed)
+{
+    const int slot = (int)(s->ev_frames % EV_RING);
+    if (timed && s->ev_ok) HIPCK(hipEventRecord(s->ev[4][slot], s->stream));
+    hipLaunchKernelGGL(k_associate, dim3(s->n_pix_blocks), dim3(PIX_BLOCK), 0, s->stream, s->M, s->d_state, fp,
+                       s->d_depthT, s->d_rgbsT, s->d_keyT, s->d_xs, s->d_ys, s->d_newmask, s->d_blk_new, s->d_blk_fused);
+    HIPCK(hipGetLastError());
+    if (timed && s->ev_ok) HIPCK(hipEventRecord(s->ev[5][slot], s->stream));
+    hipLaunchKernelGGL(k_scan_new, dim3(1), dim3(1024), 0, s->stream, s->d_state, fp, s->n_pix_blocks, s->d_blk_new,
+                       s->d_blk_fused, s->d_blk_prefix);
+    HIPCK(hipGetLastError());
+    hipLaunchKernelGGL(k_append, dim3(s->n_pix_blocks), dim3(PIX_BLOCK), 0, s->stream, s->M, s->d_state, fp, s->d_depthT,
+                       s->d_rgbsT, s->d_xs, s->d_ys, s->d_newmask, s->d_blk_prefix);
+    HIPCK(hipGetLastError());
+    return SM_OK;
+}
+
+void bump_bound(sm_ctx *s)
+{
+    s->count_bound = (uint32_t)std::min<uint64_t>((uint64_t)s->count_bound + s->n_odd_pixels, s->cap);
+}
+
+// SurfelMapping::processFrame body after the textures are on the device
+// (src/SurfelMapping.cpp:130-251); enqueue only.
+int enqueue_frame(sm_ctx *s, const uint8_t *d_rgb, const uint16_t *d_raw, const uint8_t *d_sem, const float *pose)
+{
+    if (s->pending_cull) { g_err = "sm_stage_conflict without sm_stage_cull"; return SM_E_ARG; }
+    memcpy(s->curr_pose, pose, 64);
+    FrameParams fp = make_params(s, pose);
+    const int slot = (int)(s->ev_frames % EV_RING);
+    const bool fusing = s->ref_set && s->tick != 0;
+    if (fusing && s->ev_ok) HIPCK(hipEventRecord(s->ev[0][slot], s->stream));
+    int rc;
+    // metriciseDepth (+ filterDepth when preprocess=1)   src/SurfelMapping.cpp:136-139
+    if ((rc = launch_prep(s, d_rgb, d_raw, d_sem, nullptr, fp, true))) return rc;
+    if (s->cfg.preprocess) { g_err = "preprocess=1 (p0b..p0e) not built yet"; return SM_E_UNSUPPORTED; }
+    HIPCK(hipMemcpyAsync(s->d_filteredT, s->d_depthT, (size_t)s->P * 4, hipMemcpyDeviceToDevice, s->stream));
+    if (!s->ref_set) {                                    // src/SurfelMapping.cpp:142-154
+        HIPCK(hipMemcpyAsync(s->d_lastT, s->d_filteredT, (size_t)s->P * 4, hipMemcpyDeviceToDevice, s->stream));
+        memcpy(s->last_pose, s->curr_pose, 64);
+        s->ref_set = true;
+        s->tick++;
+        return SM_OK;
+    }
+    if (s->tick == 0) {                                   // src/SurfelMapping.cpp:161-169 (after reset())
+        g_err = "tick==0 re-initialisation from the raw feedback cloud is not built yet";
+        return SM_E_UNSUPPORTED;
+    }
+    if ((rc = launch_conflict(s, fp))) return rc;          // :178-187
+    if ((rc = launch_compact(s, fp, true, true))) return rc;   // :189-197 (cull + mirror + index map)
+    if ((rc = launch_associate(s, fp, true))) return rc;   // :212-239
+    bump_bound(s);
+    HIPCK(hipMemcpyAsync(s->d_lastT, s->d_filteredT, (size_t)s->P * 4, hipMemcpyDeviceToDevice, s->stream));  // :244
+    memcpy(s->last_pose, s->curr_pose, 64);
+    if (s->ev_ok) { HIPCK(hipEventRecord(s->ev[1][slot], s->stream)); s->ev_frames++; }
+    s->tick++;
+    return SM_OK;
+}
+
+int upload_inputs(sm_ctx *s, const uint8_t *rgb, const uint16_t *depth, const uint8_t *sem)
+{
+    const size_t P = (size_t)s->P;
+    if (rgb) HIPCK(hipMemcpyAsync(s->d_rgb, rgb, P * 3, hipMemcpyHostToDevice, s->stream));
+    if (depth) HIPCK(hipMemcpyAsync(s->d_depth_raw, depth, P * 2, hipMemcpyHostToDevice, s->stream));
+    if (sem) HIPCK(hipMemcpyAsync(s->d_sem, sem, P, hipMemcpyHostToDevice, s->stream));
+    return SM_OK;
+}
+
+int ensure_export(sm_ctx *s, size_t bytes)
+{
+    if (bytes <= s->export_bytes) return SM_OK;
+    if (s->d_export) (void)hipFree(s->d_export);
+    s->d_export = nullptr; s->export_bytes = 0;
+    HIPCK(hipMalloc(&s->d_export, bytes));
+    s->export_bytes = bytes;
+    return SM_OK;
+}
+
+}  // namespace
+
+// =============================================================================================
+extern "C" {
+
+int sm_api_version(void) { return SM_API_VERSION; }
+
+const char *sm_last_error(void) { return g_err.c_str(); }
+
+int sm_default_config(sm_config *c, int width, int height, float fx, float fy, float cx, float cy)
+{
+    if (!c) return SM_E_ARG;
+    memset(c, 0, sizeof *c);
+    c->width = width; c->height = height;
+    c->fx = fx; c->fy = fy; c->cx = cx; c->cy = cy;
+    c->near_clip = 1.0f;
+    c->far_clip = 30.0f;
+    c->fuse_thresh = 0.0f;
+    c->max_sqrt_vertices = 5000;
+    c->time_delta = 200;
+    c->stereo_border = 80.0f;
+    c->preprocess = 1;
+    c->conflict_cap = 1;
+    c->device = 0;
+    c->enable_timing = 0;
+    return SM_OK;
+}
+
+sm_ctx *sm_create(const sm_config *c)
+{
+    if (!c || c->width <= 0 || c->height <= 0 || c->max_sqrt_vertices <= 0 ||
+        (uint64_t)c->width * c->height > (1u << 30) || (uint64_t)c->max_sqrt_vertices * c->max_sqrt_vertices > 0x7FFFFFFFull) {
+        g_err = "sm_create: bad config";
+        return nullptr;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || c->device >= ndev) {
+        g_err = "sm_create: no HIP device visible (this library has no CPU fallback)";
+        return nullptr;
+    }
+    if (hipSetDevice(c->device) != hipSuccess) { g_err = "hipSetDevice failed"; return nullptr; }
+    sm_ctx *s = new sm_ctx();
+    s->cfg = *c;
+    s->W = c->width; s->H = c->height; s->P = c->width * c->height;
+    s->cap = (uint32_t)c->max_sqrt_vertices * (uint32_t)c->max_sqrt_vertices;
+    for (int i = 0; i < 16; ++i) s->curr_pose[i] = s->last_pose[i] = (i % 5 == 0) ? 1.0f : 0.0f;
+    const size_t P = (size_t)s->P, cap = s->cap;
+    const size_t nwords = (cap + 63) / 64 + TILE_WORDS, ntiles = (cap + TILE - 1) / TILE + 1;
+    s->n_pix_blocks = (s->P + PIX_BLOCK - 1) / PIX_BLOCK;
+    bool ok = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) == hipSuccess;
+    ok = ok && alloc_set(s->M.s[0], cap) == SM_OK && alloc_set(s->M.s[1], cap) == SM_OK;
+    ok = ok && dalloc(&s->d_state, 1) == SM_OK;
+    ok = ok && hipHostMalloc((void **)&s->h_state, sizeof(DevState), hipHostMallocDefault) == hipSuccess;
+    ok = ok && dalloc(&s->d_depthT, P) == SM_OK && dalloc(&s->d_filteredT, P) == SM_OK && dalloc(&s->d_lastT, P) == SM_OK;
+    ok = ok && dalloc(&s->d_rgbsT, P) == SM_OK && dalloc(&s->d_keyT, P) == SM_OK;
+    ok = ok && dalloc(&s->d_rgb, P * 3) == SM_OK && dalloc(&s->d_sem, P) == SM_OK && dalloc(&s->d_depth_raw, P) == SM_OK;
+    ok = ok && dalloc(&s->d_depth_f32, P) == SM_OK;
+    ok = ok && dalloc(&s->d_xs, (size_t)s->W) == SM_OK && dalloc(&s->d_ys, (size_t)s->H) == SM_OK;
+    ok = ok && dalloc(&s->d_cm, nwords) == SM_OK && dalloc(&s->d_dm, nwords) == SM_OK && dalloc(&s->d_zm, nwords) == SM_OK;
+    ok = ok && dalloc(&s->d_tile_cnt, ntiles * 3) == SM_OK && dalloc(&s->d_tile_allow, ntiles) == SM_OK &&
+         dalloc(&s->d_tile_keep, ntiles) == SM_OK;
+    ok = ok && dalloc(&s->d_newmask, (P + 63) / 64 + 4) == SM_OK;
+    ok = ok && dalloc(&s->d_blk_new, (size_t)s->n_pix_blocks) == SM_OK && dalloc(&s->d_blk_fused, (size_t)s->n_pix_blocks) == SM_OK &&
+         dalloc(&s->d_blk_prefix, (size_t)s->n_pix_blocks) == SM_OK;
+    if (!ok) { if (g_err.empty()) g_err = "sm_create: allocation failed"; sm_destroy(s); return nullptr; }
+
+    // pixel-centre coordinates exactly as data.vert sees them:
+    // texcoord = float((i+0.5)/(double)(float)W) (src/GlobalModel.cpp:71-72), x = texcoord*cols (data.vert:62-63)
+    std::vector<float> xs(s->W), ys(s->H);
+    const float cols = (float)s->W, rows = (float)s->H;
+    const float px = 1.0f / cols, py = 1.0f / rows;
+    bool clamp_ok = true;
+    auto tex = [](float t, int n) { float f = std::floor(t * (float)n); if (!(f >= 0.0f)) return 0; if (f > (float)(n - 1)) return n - 1; return (int)f; };
+    uint32_t odd = 0;
+    for (int i = 0; i < s->W; ++i) {
+        const float tc = (float)((i + 0.5) / (double)cols);
+        xs[i] = tc * cols;
+        clamp_ok = clamp_ok && tex(tc, s->W) == i && tex(tc - px, s->W) == std::max(i - 1, 0) &&
+                   tex(tc + px, s->W) == std::min(i + 1, s->W - 1) && (int)xs[i] == i;
+    }
+    for (int j = 0; j < s->H; ++j) {
+        const float tc = (float)((j + 0.5) / (double)rows);
+        ys[j] = tc * rows;
+        clamp_ok = clamp_ok && tex(tc, s->H) == j && tex(tc - py, s->H) == std::max(j - 1, 0) &&
+                   tex(tc + py, s->H) == std::min(j + 1, s->H - 1) && (int)ys[j] == j;
+    }
+    if (!clamp_ok) {   // the kernels index neighbours as i+-1 / j+-1; refuse sizes where fp32 texcoords disagree
+        g_err = "sm_create: texel addressing for this image size is not the simple clamp form";
+        sm_destroy(s);
+        return nullptr;
+    }
+    for (int i = 0; i < s->W; ++i) odd += (uint32_t)((s->H + ((i & 1) ? 1 : 0)) / 2);
+    s->n_odd_pixels = odd;
+    memset(s->h_state, 0, sizeof(DevState));
+    ok = hipMemcpy(s->d_xs, xs.data(), xs.size() * 4, hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(s->d_ys, ys.data(), ys.size() * 4, hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(s->d_state, s->h_state, sizeof(DevState), hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemset(s->d_depthT, 0, P * 4) == hipSuccess && hipMemset(s->d_filteredT, 0, P * 4) == hipSuccess &&
+         hipMemset(s->d_lastT, 0, P * 4) == hipSuccess && hipMemset(s->d_rgbsT, 0, P * 4) == hipSuccess &&
+         hipMemset(s->d_rgb, 0, P * 3) == hipSuccess && hipMemset(s->d_sem, 0, P) == hipSuccess &&
+         hipMemset(s->d_depth_raw, 0, P * 2) == hipSuccess && hipMemset(s->d_depth_f32, 0, P * 4) == hipSuccess;
+    ok = ok && hipDeviceSynchronize() == hipSuccess;
+    if (ok) {
+        hipLaunchKernelGGL(k_fill_keys, dim3((s->P + 255) / 256), dim3(256), 0, s->stream, s->d_keyT, s->P);
+        ok = hipStreamSynchronize(s->stream) == hipSuccess;
+    }
+    if (!ok) { g_err = "sm_create: device initialisation failed"; sm_destroy(s); return nullptr; }
+    if (c->enable_timing) {
+        s->ev_ok = true;
+        for (auto &row : s->ev)
+            for (auto &e : row)
+                if (hipEventCreate(&e) != hipSuccess) s->ev_ok = false;
+    }
+    return s;
+}
+
+void sm_destroy(sm_ctx *s)
+{
+    if (!s) return;
+    (void)hipSetDevice(s->cfg.device);
+    if (s->stream) (void)hipStreamSynchronize(s->stream);
+    free_set(s->M.s[0]); free_set(s->M.s[1]);
+    (void)hipFree(s->d_state);
+    if (s->h_state) (void)hipHostFree(s->h_state);
+    (void)hipFree(s->d_depthT); (void)hipFree(s->d_filteredT); (void)hipFree(s->d_lastT);
+    (void)hipFree(s->d_rgbsT); (void)hipFree(s->d_keyT);
+    (void)hipFree(s->d_rgb); (void)hipFree(s->d_sem); (void)hipFree(s->d_depth_raw); (void)hipFree(s->d_depth_f32);
+    (void)hipFree(s->d_xs); (void)hipFree(s->d_ys);
+    (void)hipFree(s->d_cm); (void)hipFree(s->d_dm); (void)hipFree(s->d_zm);
+    (void)hipFree(s->d_tile_cnt); (void)hipFree(s->d_tile_allow); (void)hipFree(s->d_tile_keep);
+    (void)hipFree(s->d_newmask); (void)hipFree(s->d_blk_new); (void)hipFree(s->d_blk_fused); (void)hipFree(s->d_blk_prefix);
+    if (s->d_export) (void)hipFree(s->d_export);
+    for (void *p : s->user_allocs) (void)hipFree(p);
+    if (s->ev_ok)
+        for (auto &row : s->ev)
+            for (auto &e : row) (void)hipEventDestroy(e);
+    if (s->stream) (void)hipStreamDestroy(s->stream);
+    delete s;
+}
+
+int sm_sync(sm_ctx *s)
+{
+    if (!s) return SM_E_ARG;
+    HIPCK(hipSetDevice(s->cfg.device));
+    int rc = pull_state(s);
+    if (rc) return rc;
+    return take_error(s);
+}
+
+int sm_process_frame_device(sm_ctx *s, const uint8_t *d_rgb, const uint16_t *d_depth_mm, const uint8_t *d_semantic,
+                            const float *pose16)
+{
+    if (!s || !d_rgb || !pose16) { g_err = "sm_process_frame_device: null argument"; return SM_E_ARG; }
+    HIPCK(hipSetDevice(s->cfg.device));
+    // a null depth / semantic keeps the previous texture (src/SurfelMapping.cpp:124-128)
+    return enqueue_frame(s, d_rgb, d_depth_mm ? d_depth_mm : s->d_depth_raw, d_semantic ? d_semantic : s->d_sem, pose16);
+}
+
+int sm_process_frame(sm_ctx *s, const uint8_t *rgb, const uint16_t *depth_mm, const uint8_t *semantic, const float *pose16)
+{
+    if (!s || !rgb || !pose16) { g_err = "sm_process_frame: null argument (rgb and pose are required)"; return SM_E_ARG; }
+    HIPCK(hipSetDevice(s->cfg.device));
+    int rc = upload_inputs(s, rgb, depth_mm, semantic);
+    if (rc) return rc;
+    rc = enqueue_frame(s, s->d_rgb, s->d_depth_raw, s->d_sem, pose16);
+    if (rc) return rc;
+    return sm_sync(s);
+}
+
+int sm_clean_points(sm_ctx *s, const uint16_t *depth_mm, const uint8_t *semantic, const float *pose16)
+{
+    if (!s || !depth_mm || !semantic || !pose16) { g_err = "sm_clean_points: null argument"; return SM_E_ARG; }
+    HIPCK(hipSetDevice(s->cfg.device));
+    if (s->pending_cull) { g_err = "sm_stage_conflict without sm_stage_cull"; return SM_E_ARG; }
+    int rc = upload_inputs(s, nullptr, depth_mm, semantic);
+    if (rc) return rc;
+    memcpy(s->curr_pose, pose16, 64);
+    FrameParams fp = make_params(s, pose16);
+    if ((rc = launch_prep(s, s->d_rgb, s->d_depth_raw, s->d_sem, nullptr, fp, false))) return rc;   // metriciseDepth only
+    fp.max_depth = s->cfg.far_clip - 15.0f;     // src/SurfelMapping.cpp:515
+    fp.conflict_thresh = 0.1f;                  // :516
+    fp.is_clean = 1;                            // :517
+    if ((rc = launch_conflict(s, fp))) return rc;
+    if ((rc = launch_compact(s, fp, false, false))) return rc;
+    return sm_sync(s);
+}
+
+int sm_reset(sm_ctx *s)
+{
+    if (!s) return SM_E_ARG;
+    HIPCK(hipSetDevice(s->cfg.device));
+    int rc = pull_state(s);
+    if (rc) return rc;
+    const uint32_t cur = s->h_state->cur;
+    memset(s->h_state, 0, sizeof(DevState));
+    s->h_state->cur = cur;
+    s->tick = 0;                                 // refFrameIsSet stays (src/SurfelMapping.cpp:436-441)
+    s->pending_cull = false;
+    if ((rc = push_state(s))) return rc;
+    return pull_state(s);
+}
+
+int sm_get_counts(sm_ctx *s, sm_counts *out)
+{
+    if (!s || !out) return SM_E_ARG;
+    *out = s->counts;
+    out->tick = s->tick;
+    return SM_OK;
+}
+
+int sm_download_model_aos(sm_ctx *s, float *dst12, uint32_t cap, uint32_t *n)
+{
+    if (!s || !n) return SM_E_ARG;
+    HIPCK(hipSetDevice(s->cfg.device));
+    int rc = pull_state(s);
+    if (rc) return rc;
+    const uint32_t cnt = s->pending_cull ? s->count_before_cull : s->h_state->count;
+    *n = cnt;
+    if (!dst12) return SM_OK;
+    if (cap < cnt) { g_err = "sm_download_model_aos: destination too small"; return SM_E_CAPACITY; }
+    if (s->pending_cull) { g_err = "sm_download_model_aos between sm_stage_conflict and sm_stage_cull"; return SM_E_ARG; }
+    const uint32_t CH = 1u << 22;                // 4 Mi surfels (192 MiB) per staging chunk
+    if ((rc = ensure_export(s, (size_t)std::min(cnt, CH) * 48))) return rc;
+    for (uint32_t first = 0; first < cnt; first += CH) {
+        const uint32_t m = std::min(CH, cnt - first);
+        hipLaunchKernelGGL(k_export_aos, dim3((m + 255) / 256), dim3(256), 0, s->stream, s->M, s->d_state, (float *)s->d_export, first, m);
+        HIPCK(hipGetLastError());
+        HIPCK(hipMemcpyAsync(dst12 + (size_t)first * 12, s->d_export, (size_t)m * 48, hipMemcpyDeviceToHost, s->stream));
+        HIPCK(hipStreamSynchronize(s->stream));
+    }
+    return SM_OK;
+}
+
+int sm_upload_model_aos(sm_ctx *s, const float *src12, uint32_t n)
+{
+    if (!s || (!src12 && n)) return SM_E_ARG;
+    HIPCK(hipSetDevice(s->cfg.device));
+    if (n > s->cap) { g_err = "sm_upload_model_aos: exceeds MAX_VERTICES"; return SM_E_CAPACITY; }
+    int rc = pull_state(s);
+    if (rc) return rc;
+    const uint32_t CH = 1u << 22;
+    if (n && (rc = ensure_export(s, (size_t)std::min(n, CH) * 48))) return rc;
+    for (uint32_t first = 0; first < n; first += CH) {
+        const uint32_t m = std::min(CH, n - first);
+        HIPCK(hipMemcpyAsync(s->d_export, src12 + (size_t)first * 12, (size_t)m * 48, hipMemcpyHostToDevice, s->stream));
+        hipLaunchKernelGGL(k_import_aos, dim3((m + 255) / 256), dim3(256), 0, s->stream, s->M, s->d_state, (const float *)s->d_export, first, m);
+        HIPCK(hipGetLastError());
+        HIPCK(hipStreamSynchronize(s->stream));
+    }
+    s->h_state->count = n;                       // src/GlobalModel.cpp:995
+    s->h_state->offset = n;
+    s->pending_cull = false;
+    if ((rc = push_state(s))) return rc;
+    return pull_state(s);
+}
+
+int sm_save_map(sm_ctx *s, const char *path, int32_t start_id, int32_t end_id)
+{
+    if (!s || !path) return SM_E_ARG;
+    uint32_t n = 0;
+    int rc = sm_download_model_aos(s, nullptr, 0, &n);
+    if (rc) return rc;
+    std::vector<float> buf((size_t)n * 12);
+    if ((rc = sm_download_model_aos(s, buf.data(), n, &n))) return rc;
+    FILE *f = fopen(path, "wb");
+    if (!f) { g_err = std::string(path) + " is not open!"; return SM_E_ARG; }
+    // u32 count | i32 startId | i32 endId | count*12 f32   (src/GlobalModel.cpp:927-932)
+    bool ok = fwrite(&n, 4, 1, f) == 1 && fwrite(&start_id, 4, 1, f) == 1 && fwrite(&end_id, 4, 1, f) == 1;
+    ok = ok && (n == 0 || fwrite(buf.data(), 48, n, f) == n);
+    ok = (fclose(f) == 0) && ok;
+    if (!ok) { g_err = std::string(path) + " saved err!!"; return SM_E_ARG; }
+    return SM_OK;
+}
+
+int sm_load_map(sm_ctx *s, const char *path, int32_t *start_id, int32_t *end_id)
+{
+    if (!s || !path) return SM_E_ARG;
+    FILE *f = fopen(path, "rb");
+    if (!f) { g_err = std::string(path) + " is not open!"; return SM_E_ARG; }
+    uint32_t n = 0; int32_t a = 0, b = 0;
+    bool ok = fread(&n, 4, 1, f) == 1 && fread(&a, 4, 1, f) == 1 && fread(&b, 4, 1, f) == 1;
+    std::vector<float> buf;
+    if (ok && n <= s->cap) { buf.resize((size_t)n * 12); ok = n == 0 || fread(buf.data(), 48, n, f) == n; }
+    fclose(f);
+    if (!ok) { g_err = std::string(path) + " read err!!"; return SM_E_ARG; }
+    if (n > s->cap) { g_err = "map larger than MAX_VERTICES"; return SM_E_CAPACITY; }
+    if (start_id) *start_id = a;
+    if (end_id) *end_id = b;
+    return sm_upload_model_aos(s, buf.data(), n);
+}
+
+int sm_download_index_map(sm_ctx *s, int32_t *id, float *vert_conf4, float *color_time4, float *norm_rad4)
+{
+    if (!s) return SM_E_ARG;
+    HIPCK(hipSetDevice(s->cfg.device));
+    const size_t P = (size_t)s->P;
+    int rc = ensure_export(s, P * 52);
+    if (rc) return rc;
+    char *base = (char *)s->d_export;
+    int32_t *d_id = (int32_t *)(base + P * 48);
+    float4 *d_vc = (float4 *)base, *d_ct = (float4 *)(base + P * 16), *d_nr = (float4 *)(base + P * 32);
+    FrameParams fp = make_params(s, s->curr_pose);
+    hipLaunchKernelGGL(k_export_index, dim3((s->P + 255) / 256), dim3(256), 0, s->stream, s->M, s->d_state, fp, s->d_keyT, d_id, d_vc, d_ct, d_nr);
+    HIPCK(hipGetLastError());
+    if (id) HIPCK(hipMemcpyAsync(id, d_id, P * 4, hipMemcpyDeviceToHost, s->stream));
+    if (vert_conf4) HIPCK(hipMemcpyAsync(vert_conf4, d_vc, P * 16, hipMemcpyDeviceToHost, s->stream));
+    if (color_time4) HIPCK(hipMemcpyAsync(color_time4, d_ct, P * 16, hipMemcpyDeviceToHost, s->stream));
+    if (norm_rad4) HIPCK(hipMemcpyAsync(norm_rad4, d_nr, P * 16, hipMemcpyDeviceToHost, s->stream));
+    HIPCK(hipStreamSynchronize(s->stream));
+    return SM_OK;
+}
+
+int sm_download_depth(sm_ctx *s, int which, float *dst)
+{
+    if (!s || !dst) return SM_E_ARG;
+    HIPCK(hipSetDevice(s->cfg.device));
+    const float *src = which == SM_TEX_DEPTH_METRIC ? s->d_depthT : which == SM_TEX_DEPTH_FILTERED ? s->d_filteredT
+                     : which == SM_TEX_LAST ? s->d_lastT : nullptr;
+    if (!src) return SM_E_ARG;
+    int rc = ensure_export(s, (size_t)s->P * 4);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_untranspose_f32, dim3((s->P + 255) / 256), dim3(256), 0, s->stream, src, (float *)s->d_export, s->W, s->H);
+    HIPCK(hipGetLastError());
+    HIPCK(hipMemcpyAsync(dst, s->d_export, (size_t)s->P * 4, hipMemcpyDeviceToHost, s->stream));
+    HIPCK(hipStreamSynchronize(s->stream));
+    return SM_OK;
+}
+
+// ---- per-pass entry points ----
+
+int sm_set_frame(sm_ctx *s, const uint8_t *rgb, const float *depth_metric, const uint8_t *semantic)
+{
+    if (!s) return SM_E_ARG;
+    HIPCK(hipSetDevice(s->cfg.device));
+    int rc = upload_inputs(s, rgb, nullptr, semantic);
+    if (rc) return rc;
+    if (depth_metric) HIPCK(hipMemcpyAsync(s->d_depth_f32, depth_metric, (size_t)s->P * 4, hipMemcpyHostToDevice, s->stream));
+    FrameParams fp = make_params(s, s->curr_pose);
+    // re-pack every plane from the staged inputs; depth only when given (else keep depthT)
+    const int tiles = ((s->W + 63) / 64) * ((s->H + 63) / 64);
+    hipLaunchKernelGGL(k_prep, dim3(tiles), dim3(256), 0, s->stream, s->d_rgb, (const uint16_t *)nullptr, s->d_sem,
+                       depth_metric ? s->d_depth_f32 : nullptr, depth_metric ? s->d_depthT : nullptr, s->d_rgbsT,
+                       (uint64_t *)nullptr, fp);
+    HIPCK(hipGetLastError());
+    HIPCK(hipStreamSynchronize(s->stream));
+    return SM_OK;
+}
+
+int sm_set_tick(sm_ctx *s, int32_t tick)
+{
+    if (!s) return SM_E_ARG;
+    s->tick = tick;
+    s->ref_set = true;
+    return SM_OK;
+}
+
+int sm_stage_conflict(sm_ctx *s, const float *pose16, float min_depth, float max_depth, float fuse_thresh, int is_clean)
+{
+    if (!s || !pose16) return SM_E_ARG;
+    HIPCK(hipSetDevice(s->cfg.device));
+    if (s->pending_cull) { g_err = "sm_stage_conflict called twice without sm_stage_cull"; return SM_E_ARG; }
+    int rc = pull_state(s);
+    if (rc) return rc;
+    memcpy(s->curr_pose, pose16, 64);
+    FrameParams fp = make_params(s, pose16);
+    fp.min_depth = min_depth; fp.max_depth = max_depth; fp.conflict_thresh = fuse_thresh; fp.is_clean = is_clean;
+    s->count_before_cull = s->h_state->count;
+    if ((rc = launch_conflict(s, fp))) return rc;
+    s->pending_cull = true;
+    return sm_sync(s);
+}
+
+int sm_stage_cull(sm_ctx *s)
+{
+    if (!s) return SM_E_ARG;
+    HIPCK(hipSetDevice(s->cfg.device));
+    if (!s->pending_cull) { g_err = "sm_stage_cull without sm_stage_conflict"; return SM_E_ARG; }
+    FrameParams fp = make_params(s, s->curr_pose);
+    int rc = launch_compact(s, fp, false, false);
+    if (rc) return rc;
+    s->pending_cull = false;
+    return sm_sync(s);
+}
+
+int sm_stage_splat(sm_ctx *s, const float *pose16, int32_t time, float depth_cutoff, int32_t time_delta)
+{
+    if (!s || !pose16) return SM_E_ARG;
+    HIPCK(hipSetDevice(s->cfg.device));
+    if (s->pending_cull) { g_err = "sm_stage_splat between sm_stage_conflict and sm_stage_cull"; return SM_E_ARG; }
+    int rc = pull_state(s);
+    if (rc) return rc;
+    memcpy(s->curr_pose, pose16, 64);
+    FrameParams fp = make_params(s, pose16);
+    fp.time = time; fp.depth_cutoff = depth_cutoff; fp.time_delta = time_delta;
+    HIPCK(hipMemsetAsync(&s->d_state->visible_count, 0, 4, s->stream));
+    hipLaunchKernelGGL(k_fill_keys, dim3((s->P + 255) / 256), dim3(256), 0, s->stream, s->d_keyT, s->P);
+    HIPCK(hipGetLastError());
+    const int grid = (int)std::min<uint64_t>(std::max<uint64_t>(((uint64_t)s->h_state->count + 255) / 256, 1), MAX_GRID);
+    hipLaunchKernelGGL(k_splat, dim3(grid), dim3(256), 0, s->stream, s->M, s->d_state, fp, s->d_keyT);
+    HIPCK(hipGetLastError());
+    return sm_sync(s);
+}
+
+int sm_stage_associate_fuse(sm_ctx *s, const float *pose16, int32_t time, float depth_min, float depth_max)
+{
+    if (!s || !pose16) return SM_E_ARG;
+    HIPCK(hipSetDevice(s->cfg.device));
+    if (s->pending_cull) { g_err = "sm_stage_associate_fuse between sm_stage_conflict and sm_stage_cull"; return SM_E_ARG; }
+    memcpy(s->curr_pose, pose16, 64);
+    FrameParams fp = make_params(s, pose16);
+    fp.time = time; fp.min_depth = depth_min; fp.max_depth = depth_max;
+    int rc = launch_associate(s, fp, false);
+    if (rc) return rc;
+    return sm_sync(s);
+}
+
+int sm_stage_timings(sm_ctx *s, sm_timings *out)
+{
+    if (!s || !out) return SM_E_ARG;
+    memset(out, 0, sizeof *out);
+    if (!s->ev_ok) { g_err = "sm_stage_timings: create the context with enable_timing=1"; return SM_E_UNSUPPORTED; }
+    HIPCK(hipSetDevice(s->cfg.device));
+    HIPCK(hipStreamSynchronize(s->stream));
+    uint64_t first = s->ev_read;
+    if (s->ev_frames - first > EV_RING) first = s->ev_frames - EV_RING;
+    double run = 0, cull = 0, assoc = 0;
+    uint64_t nfr = 0;
+    for (uint64_t f = first; f < s->ev_frames; ++f) {
+        const int slot = (int)(f % EV_RING);
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, s->ev[0][slot], s->ev[1][slot]) == hipSuccess) run += ms;
+        if (hipEventElapsedTime(&ms, s->ev[2][slot], s->ev[3][slot]) == hipSuccess) cull += ms;
+        if (hipEventElapsedTime(&ms, s->ev[4][slot], s->ev[5][slot]) == hipSuccess) assoc += ms;
+        nfr++;
+    }
+    s->ev_read = s->ev_frames;
+    if (nfr) {
+        out->run = (float)(run / nfr);
+        out->cull_kernel = (float)(cull / nfr);
+        out->assoc_kernel = (float)(assoc / nfr);
+        out->conflict = out->cull_kernel;
+        out->data_association = out->assoc_kernel;
+    }
+    return SM_OK;
+}
+
+void *sm_device_alloc(sm_ctx *s, size_t bytes)
+{
+    if (!s) return nullptr;
+    if (hipSetDevice(s->cfg.device) != hipSuccess) return nullptr;
+    void *p = nullptr;
+    if (hipMalloc(&p, std::max<size_t>(bytes, 1)) != hipSuccess) { g_err = "sm_device_alloc: hipMalloc failed"; return nullptr; }
+    s->user_allocs.push_back(p);
+    return p;
+}
+
+int sm_device_free(sm_ctx *s, void *p)
+{
+    if (!s || !p) return SM_E_ARG;
+    auto it = std::find(s->user_allocs.begin(), s->user_allocs.end(), p);
+    if (it == s->user_allocs.end()) return SM_E_ARG;
+    s->user_allocs.erase(it);
+    HIPCK(hipSetDevice(s->cfg.device));
+    HIPCK(hipStreamSynchronize(s->stream));
+    HIPCK(hipFree(p));
+    return SM_OK;
+}
+
+int sm_device_upload(sm_ctx *s, void *dst_device, const void *src_host, size_t bytes)
+{
+    if (!s || !dst_device || !src_host) return SM_E_ARG;
+    HIPCK(hipSetDevice(s->cfg.device));
+    HIPCK(hipMemcpyAsync(dst_device, src_host, bytes, hipMemcpyHostToDevice, s->stream));
+    HIPCK(hipStreamSynchronize(s->stream));
+    return SM_OK;
+}
+
+void *sm_key_map_device_ptr(sm_ctx *s) { return s ? (void *)s->d_keyT : nullptr; }
+
+}  // extern "C"

@@ -1,0 +1,212 @@
+// sm_device.h -- device-side data layout and scalar helpers of the gfx950 fusion core.
+//
+// Numeric contract (DESIGN.md "Arithmetic"): IEEE fp32, round-to-nearest-even, no FMA
+// contraction (-ffp-contract=off), correctly rounded / and sqrt, fixed evaluation order:
+//   mat*vec   r_i = ((m_i0*x + m_i1*y) + m_i2*z) + m_i3
+//   dot       (a.x*b.x + a.y*b.y) + a.z*b.z
+//   normalize v / sqrt(dot(v,v))
+//   min(a,b)  (b < a) ? b : a
+// Shader citations are file:line under /root/reference/src/Shaders.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace sm {
+
+constexpr uint64_t KEY_EMPTY = 0x7FFFFFFFFFFFFFFFull;  // positive as int64 too (RCCL min on either type)
+constexpr int TILE = 1024;                             // surfels per cull tile (16 ballot words)
+constexpr int TILE_WORDS = TILE / 64;
+constexpr int PIX_BLOCK = 256;                         // pixels per association block (4 ballot words)
+
+// One SoA surfel set: 44 B / surfel (the reference's AoS slot [5] "standby" is always 0
+// in the stored model: back_map.geom:23, unstable.vert:32).
+struct SurfelSet {
+    float4 *pos_conf;    // xyz world, confidence
+    float4 *norm_rad;    // unit normal world, radius
+    uint32_t *color;     // sem<<24 | r<<16 | g<<8 | b    (color.glsl:19-26)
+    float *init_time;
+    float *time;
+};
+
+struct Model {
+    SurfelSet s[2];      // ping-pong for the stable compaction
+};
+
+// Device-resident frame state: every kernel reads its sizes from here so that a frame needs
+// no host read-back (the reference blocks on 6 glGetQueryObjectuiv per frame).
+struct DevState {
+    uint32_t count;           // live surfels
+    uint32_t offset;          // survivors of the last cull
+    uint32_t cur;             // which SurfelSet holds the model
+    uint32_t cull_n;          // count before the pending cull
+    uint32_t cull_src, cull_dst;
+    uint32_t n_kill;
+    uint32_t conflict_count;
+    uint32_t data_count, unstable_count, fused_count;
+    uint32_t visible_count;
+    uint32_t append_n;        // new surfels the append kernel may write
+    int32_t error;            // sticky SM_E_*
+    uint32_t pad[2];
+};
+
+struct FrameParams {
+    float pose[16];           // camera -> world, column-major
+    float t_inv[16];          // world -> camera
+    float fx, fy, cx, cy;
+    float inv_fx, inv_fy;     // float(1.0/fx) : src/GlobalModel.cpp:273-276
+    float cols, rows;
+    int W, H, P;
+    float min_depth, max_depth;
+    float conflict_thresh;    // processConflict fuseThresh (0.0; 0.1 in clean mode)
+    float fuse_thresh;        // dataAssociate fuseThresh
+    float stereo_border;
+    int is_clean;
+    int time;
+    int time_delta;
+    float depth_cutoff;
+    uint32_t conflict_cap;    // W*H or 0xFFFFFFFF
+    uint32_t max_vertices;
+};
+
+__device__ __forceinline__ float min_glsl(float a, float b) { return (b < a) ? b : a; }
+
+// nearest + clamp-to-edge texel
+__device__ __forceinline__ int tex_idx(float t, int n)
+{
+    float f = floorf(t * (float)n);
+    if (!(f >= 0.0f)) return 0;
+    if (f > (float)(n - 1)) return n - 1;
+    return (int)f;
+}
+
+__device__ __forceinline__ float3 xform3(const float *m, float x, float y, float z)
+{
+    float3 r;
+    r.x = ((m[0] * x + m[4] * y) + m[8] * z) + m[12];
+    r.y = ((m[1] * x + m[5] * y) + m[9] * z) + m[13];
+    r.z = ((m[2] * x + m[6] * y) + m[10] * z) + m[14];
+    return r;
+}
+
+__device__ __forceinline__ float3 rot3(const float *m, float x, float y, float z)
+{
+    float3 r;
+    r.x = (m[0] * x + m[4] * y) + m[8] * z;
+    r.y = (m[1] * x + m[5] * y) + m[9] * z;
+    r.z = (m[2] * x + m[6] * y) + m[10] * z;
+    return r;
+}
+
+__device__ __forceinline__ float dot3(float3 a, float3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+
+__device__ __forceinline__ float3 cross3(float3 a, float3 b)
+{
+    float3 r;
+    r.x = a.y * b.z - a.z * b.y;
+    r.y = a.z * b.x - a.x * b.z;
+    r.z = a.x * b.y - a.y * b.x;
+    return r;
+}
+
+__device__ __forceinline__ float3 normalize3(float3 v)
+{
+    float l = sqrtf(dot3(v, v));
+    float3 r;
+    r.x = v.x / l; r.y = v.y / l; r.z = v.z / l;
+    return r;
+}
+
+// acos by a fixed rational kernel (DESIGN.md "Arithmetic"); NaN outside [-1,1]
+// (data.vert:54-57: NaN < 0.5 is false -> no association).
+__device__ __forceinline__ float acos_spec(float x)
+{
+    const float pS0 = 1.6666586697e-01f, pS1 = -4.2743422091e-02f, pS2 = -8.6563630030e-03f;
+    const float qS1 = -7.0662963390e-01f;
+    const float PIO2 = 1.57079637050628662109375f, PI = 3.1415927410125732421875f;
+    float ax = fabsf(x);
+    if (ax <= 0.5f) {
+        float z = x * x;
+        float r = (z * (pS0 + z * (pS1 + z * pS2))) / (1.0f + z * qS1);
+        return PIO2 - (x + x * r);
+    } else if (x > 0.0f) {
+        float z = (1.0f - x) * 0.5f;
+        float s = sqrtf(z);
+        float r = (z * (pS0 + z * (pS1 + z * pS2))) / (1.0f + z * qS1);
+        return 2.0f * (s + s * r);
+    } else {
+        float z = (1.0f + x) * 0.5f;
+        float s = sqrtf(z);
+        float r = (z * (pS0 + z * (pS1 + z * pS2))) / (1.0f + z * qS1);
+        return PI - 2.0f * (s + s * r);
+    }
+}
+
+__device__ __forceinline__ uint32_t round_u8(float v)
+{
+    float r = roundf(v);
+    if (!(r >= 0.0f)) return 0u;
+    if (r > 4294967040.0f) return 4294967040u;
+    return (uint32_t)r;
+}
+
+// color.glsl:19-26
+__device__ __forceinline__ uint32_t encode_color(float r, float g, float b, uint32_t sem)
+{
+    uint32_t srgb = sem;
+    srgb = (srgb << 8) + round_u8(r * 255.0f);
+    srgb = (srgb << 8) + round_u8(g * 255.0f);
+    srgb = (srgb << 8) + round_u8(b * 255.0f);
+    return srgb;
+}
+
+// surfels.glsl:19-32
+__device__ __forceinline__ float get_radius(float depth, float norm_z, float inv_fx, float inv_fy)
+{
+    float meanFocal = ((1.0f / fabsf(inv_fx)) + (1.0f / fabsf(inv_fy))) / 2.0f;
+    const float sqrt2 = 1.41421356237f;
+    float radius = (depth / meanFocal) * sqrt2;
+    float radius_n = radius / fabsf(norm_z);
+    return min_glsl(2.0f * radius, radius_n);
+}
+
+// exclusive scan of one value per thread over a 1024-thread block; lds needs 17 words
+__device__ __forceinline__ uint32_t block_scan_1024(uint32_t v, uint32_t *total, uint32_t *lds)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        uint32_t t = __shfl_up(inc, o);
+        if (lane >= o) inc += t;
+    }
+    if (lane == 63) lds[wave] = inc;
+    __syncthreads();
+    if (wave == 0) {
+        uint32_t w = lane < 16 ? lds[lane] : 0u;
+        uint32_t wi = w;
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+            uint32_t t = __shfl_up(wi, o);
+            if (lane >= o) wi += t;
+        }
+        if (lane < 16) lds[lane] = wi - w;
+        if (lane == 15) lds[16] = wi;
+    }
+    __syncthreads();
+    uint32_t excl = inc - v + lds[wave];
+    *total = lds[16];
+    __syncthreads();
+    return excl;
+}
+
+// the first `n` set bits of `m` (n may exceed popcount)
+__device__ __forceinline__ uint64_t first_n_bits(uint64_t m, uint32_t n)
+{
+    if (n >= (uint32_t)__popcll(m)) return m;
+    uint64_t rest = m;
+    for (uint32_t i = 0; i < n; ++i) rest &= rest - 1;   // clear the n lowest set bits
+    return m ^ rest;
+}
+
+}  // namespace sm

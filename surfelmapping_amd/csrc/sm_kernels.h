@@ -1,0 +1,658 @@
+// sm_kernels.h -- hand-written gfx950 kernels of the per-frame fusion hot path.
+// Included once by sm_api.hip.  Shader citations: /root/reference/src/Shaders/<file>:<line>.
+//
+// Frame images are held COLUMN-MAJOR (q = i*H + j, "x-outer / y-inner"): that is the order
+// in which the reference submits pixels to data.vert (src/GlobalModel.cpp:67-74) and hence the
+// order in which new surfels are appended, so association + ordered compaction become a 1-D
+// coalesced stream over q.
+#pragma once
+
+#include "sm_device.h"
+
+namespace sm {
+
+// ---------------------------------------------------------------------------------------------
+// p0a metricise (depth_metric.frag:15-35) + u8 RGB/semantic pack + LDS-tiled transpose to the
+// column-major frame layout + key-map clear.  64x64 pixel tile per 256-thread block.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_prep(const uint8_t *__restrict__ rgb,
+                                              const uint16_t *__restrict__ depth_raw,
+                                              const uint8_t *__restrict__ sem,
+                                              const float *__restrict__ depth_f32,  // optional: metric depth given directly
+                                              float *__restrict__ depthT, uint32_t *__restrict__ rgbsT,
+                                              uint64_t *__restrict__ keyT, FrameParams fp)
+{
+    __shared__ float s_d[64][65];
+    __shared__ uint32_t s_c[64][65];
+    const int W = fp.W, H = fp.H;
+    const int tiles_x = (W + 63) >> 6;
+    const int i0 = (blockIdx.x % tiles_x) << 6, j0 = (blockIdx.x / tiles_x) << 6;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const uint32_t lo = (uint32_t)(fp.min_depth * 1000.0f);
+    const uint32_t hi = (uint32_t)((fp.max_depth - 0.001f) * 1000.0f);
+#pragma unroll 4
+    for (int r = 0; r < 16; ++r) {
+        const int jl = ty + 4 * r;
+        const int i = i0 + tx, j = j0 + jl;
+        float d = 0.0f;
+        uint32_t c = 0;
+        if (i < W && j < H) {
+            const size_t p = (size_t)j * W + i;
+            if (depth_f32) {
+                d = depth_f32[p];
+            } else if (depth_raw) {
+                const uint32_t v = depth_raw[p];
+                if (!((float)i + 0.5f < fp.stereo_border)) {
+                    if (v > lo && v < hi) d = (float)v / 1000.0f;
+                }
+            }
+            uint32_t s = sem ? (uint32_t)sem[p] : 0u;
+            uint32_t cr = 0, cg = 0, cb = 0;
+            if (rgb) { cr = rgb[p * 3]; cg = rgb[p * 3 + 1]; cb = rgb[p * 3 + 2]; }
+            c = (s << 24) | (cr << 16) | (cg << 8) | cb;
+        }
+        s_d[jl][tx] = d;
+        s_c[jl][tx] = c;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int r = 0; r < 16; ++r) {
+        const int il = ty + 4 * r;
+        const int i = i0 + il, j = j0 + tx;
+        if (i < W && j < H) {
+            const size_t q = (size_t)i * H + j;
+            if (depthT) depthT[q] = s_d[tx][il];
+            if (rgbsT) rgbsT[q] = s_c[tx][il];
+            if (keyT) keyT[q] = KEY_EMPTY;
+        }
+    }
+}
+
+// column-major -> row-major read-back helper (tests / GUI textures)
+__global__ void k_untranspose_f32(const float *__restrict__ srcT, float *__restrict__ dst, int W, int H)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= W * H) return;
+    const int j = p / W, i = p - j * W;
+    dst[p] = srcT[(size_t)i * H + j];
+}
+
+__global__ void k_fill_keys(uint64_t *keyT, int P)
+{
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < P) keyT[q] = KEY_EMPTY;
+}
+
+// ---------------------------------------------------------------------------------------------
+// p2 conflict test (conflict.vert:25-83, conflict.geom:13-24) over the SoA model.
+// One wave = 64 consecutive surfels = one ballot word per mask:
+//   cm  conflict (and id > 0)          dm  would die if decremented: !(conf-1 > 0)
+//   zm  dead already: !(conf > 0)      (back_map.geom:17 culls on conf <= 0 / NaN)
+// plus per-tile counts (nconf, nkill = popc(zm | cm&dm), nzero).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_conflict(Model M, const DevState *__restrict__ st, FrameParams fp,
+                                                  const float *__restrict__ depthT,
+                                                  const uint32_t *__restrict__ rgbsT,
+                                                  uint64_t *__restrict__ cm, uint64_t *__restrict__ dm,
+                                                  uint64_t *__restrict__ zm, uint32_t *__restrict__ tile_cnt)
+{
+    __shared__ uint32_t s_red[4][3];
+    const uint32_t N = st->count;
+    const float4 *__restrict__ pc = M.s[st->cur].pos_conf;
+    const uint32_t ntiles = (N + TILE - 1) / TILE;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        uint32_t nconf = 0, nkill = 0, nzero = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const uint32_t word = tile * TILE_WORDS + r * 4 + wave;
+            const uint32_t k = word * 64u + lane;
+            const bool valid = k < N;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (valid) v = pc[k];
+            bool conflict = false;
+            if (valid) {
+                const float3 ph = xform3(fp.t_inv, v.x, v.y, v.z);
+                const float xl = ph.x / ph.z;
+                const float yl = ph.y / ph.z;
+                const float u = fp.fx * xl + fp.cx;
+                const float vv = fp.fy * yl + fp.cy;
+                if (!(u < fp.stereo_border || u > fp.cols || vv < 0.0f || vv > fp.rows ||
+                      ph.z <= fp.min_depth || ph.z >= fp.max_depth)) {
+                    const float lambda = sqrtf((xl * xl + yl * yl) + 1.0f);
+                    const int ti = tex_idx(u / fp.cols, fp.W), tj = tex_idx(vv / fp.rows, fp.H);
+                    const size_t q = (size_t)ti * fp.H + tj;
+                    float depth = depthT[q];
+                    const uint32_t sem = rgbsT[q] >> 24;
+                    if (sem == 10u) depth = fp.max_depth + 1.0f;
+                    if (fp.is_clean == 0 && depth == 0.0f) depth = fp.max_depth + 20.0f;
+                    conflict = (depth * lambda - ph.z * lambda > fp.conflict_thresh * ph.z) && (k > 0u);
+                }
+            }
+            const bool dies = valid && !(v.w - 1.0f > 0.0f);
+            const bool dead = valid && !(v.w > 0.0f);
+            const uint64_t cw = __ballot(conflict), dw = __ballot(dies), zw = __ballot(dead);
+            if (lane == 0 && (uint64_t)word * 64u < N) {
+                cm[word] = cw; dm[word] = dw; zm[word] = zw;
+            }
+            nconf += __popcll(cw);
+            nkill += __popcll(zw | (cw & dw));
+            nzero += __popcll(zw);
+        }
+        if (lane == 0) { s_red[wave][0] = nconf; s_red[wave][1] = nkill; s_red[wave][2] = nzero; }
+        __syncthreads();
+        if (threadIdx.x < 3) {
+            tile_cnt[tile * 3 + threadIdx.x] = s_red[0][threadIdx.x] + s_red[1][threadIdx.x] +
+                                               s_red[2][threadIdx.x] + s_red[3][threadIdx.x];
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Scan of the per-tile counts (single 1024-thread workgroup): applies the "first cap conflicts
+// only" rule (conflictVbo holds W*H records: src/GlobalModel.cpp:54-57), derives
+// the per-tile survivor prefix for the stable compaction (p4, back_map.geom:15-28) and publishes
+// the new count/offset in DevState.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_scan_cull(DevState *__restrict__ st, FrameParams fp,
+                                                    const uint64_t *__restrict__ cm,
+                                                    const uint64_t *__restrict__ dm,
+                                                    const uint64_t *__restrict__ zm,
+                                                    const uint32_t *__restrict__ tile_cnt,
+                                                    uint32_t *__restrict__ tile_allow,
+                                                    uint32_t *__restrict__ tile_keep_prefix)
+{
+    __shared__ uint32_t s_scan[17];
+    const uint32_t N = st->count;
+    const uint32_t ntiles = (N + TILE - 1) / TILE;
+    const uint32_t per = (ntiles + 1023u) / 1024u;
+    const uint32_t t0 = min(threadIdx.x * per, ntiles), t1 = min(t0 + per, ntiles);
+    // pass 1: conflicts
+    uint32_t csum = 0;
+    for (uint32_t t = t0; t < t1; ++t) csum += tile_cnt[t * 3];
+    uint32_t ctotal;
+    uint32_t cpre = block_scan_1024(csum, &ctotal, s_scan);
+    // pass 2: allowed conflicts + effective kills per tile
+    const uint32_t cap = fp.conflict_cap;
+    uint32_t ksum = 0;
+    for (uint32_t t = t0; t < t1; ++t) {
+        const uint32_t nconf = tile_cnt[t * 3];
+        uint32_t allow = nconf;
+        if (cpre >= cap) allow = 0;
+        else if (cap - cpre < nconf) allow = cap - cpre;
+        tile_allow[t] = allow;
+        uint32_t kills;
+        if (allow == nconf) kills = tile_cnt[t * 3 + 1];
+        else if (allow == 0) kills = tile_cnt[t * 3 + 2];
+        else {   // the one tile straddling the cap
+            kills = 0;
+            uint32_t rem = allow;
+            for (int w = 0; w < TILE_WORDS; ++w) {
+                const uint32_t word = t * TILE_WORDS + w;
+                if ((uint64_t)word * 64u >= N) break;
+                const uint64_t c = cm[word];
+                const uint64_t ce = first_n_bits(c, rem);
+                rem -= (uint32_t)__popcll(ce);
+                kills += (uint32_t)__popcll(zm[word] | (ce & dm[word]));
+            }
+        }
+        const uint32_t nvalid = min((uint32_t)TILE, N - t * TILE);
+        ksum += nvalid - kills;
+        cpre += nconf;
+    }
+    uint32_t ktotal;
+    uint32_t kpre = block_scan_1024(ksum, &ktotal, s_scan);
+    for (uint32_t t = t0; t < t1; ++t) {
+        const uint32_t nconf = tile_cnt[t * 3];
+        const uint32_t allow = tile_allow[t];
+        uint32_t kills;
+        if (allow == nconf) kills = tile_cnt[t * 3 + 1];
+        else if (allow == 0) kills = tile_cnt[t * 3 + 2];
+        else {
+            kills = 0;
+            uint32_t rem = allow;
+            for (int w = 0; w < TILE_WORDS; ++w) {
+                const uint32_t word = t * TILE_WORDS + w;
+                if ((uint64_t)word * 64u >= N) break;
+                const uint64_t c = cm[word];
+                const uint64_t ce = first_n_bits(c, rem);
+                rem -= (uint32_t)__popcll(ce);
+                kills += (uint32_t)__popcll(zm[word] | (ce & dm[word]));
+            }
+        }
+        tile_keep_prefix[t] = kpre;
+        kpre += min((uint32_t)TILE, N - t * TILE) - kills;
+    }
+    if (threadIdx.x == 0) {
+        const uint32_t kept = ktotal;
+        const uint32_t nk = N - kept;
+        st->cull_n = N;
+        st->n_kill = nk;
+        st->conflict_count = min(ctotal, cap);
+        st->cull_src = st->cur;
+        st->cull_dst = nk ? (st->cur ^ 1u) : st->cur;   // no cull -> stay in place
+        st->cur = st->cull_dst;
+        st->count = kept;                                 // src/GlobalModel.cpp:575
+        st->offset = kept;
+        st->visible_count = 0;
+    }
+}
+
+// z-buffered 1-px splat of one surfel (index_map.vert:38-64, index_map.frag:31-37;
+// rasterisation + GL_LESS on a 24-bit depth: SURVEY.md A3/A4): 64-bit atomicMin of d24<<32|id.
+__device__ __forceinline__ bool splat_one(const FrameParams &fp, float x, float y, float z, float t_last,
+                                          uint32_t id, uint64_t *__restrict__ keyT)
+{
+    const float3 ph = xform3(fp.t_inv, x, y, z);
+    if (ph.z >= fp.depth_cutoff * 1.5f || ph.z <= 0.0f || (float)fp.time - t_last > (float)fp.time_delta)
+        return false;
+    const float xn = ((((fp.fx * ph.x) / ph.z) + fp.cx) - (fp.cols * 0.5f)) / (fp.cols * 0.5f);
+    const float yn = ((((fp.fy * ph.y) / ph.z) + fp.cy) - (fp.rows * 0.5f)) / (fp.rows * 0.5f);
+    const float zn = ph.z / fp.depth_cutoff;
+    if (!(xn >= -1.0f && xn <= 1.0f && yn >= -1.0f && yn <= 1.0f && zn >= -1.0f && zn <= 1.0f)) return false;
+    const float xw = (fp.cols * 0.5f) * xn + (fp.cols * 0.5f);
+    const float yw = (fp.rows * 0.5f) * yn + (fp.rows * 0.5f);
+    const float fxw = floorf(xw), fyw = floorf(yw);
+    if (!(fxw >= 0.0f && fxw < fp.cols && fyw >= 0.0f && fyw < fp.rows)) return false;
+    const int px = (int)fxw, py = (int)fyw;
+    const float zw = 0.5f * zn + 0.5f;
+    const uint32_t d24 = (uint32_t)floor((double)zw * 16777215.0 + 0.5);
+    if (d24 >= 16777215u) return false;
+    const uint64_t key = ((uint64_t)d24 << 32) | (uint64_t)id;
+    atomicMin((unsigned long long *)&keyT[(size_t)px * fp.H + py], (unsigned long long)key);
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------
+// p3+p4+p5(+p6): apply the confidence decrement, stable-compact the survivors into the other
+// SoA set (or stay in place when nothing dies) and, fused, splat each survivor under its NEW id.
+// ---------------------------------------------------------------------------------------------
+template <bool SPLAT>
+__global__ __launch_bounds__(256) void k_compact(Model M, DevState *__restrict__ st, FrameParams fp,
+                                                 const uint64_t *__restrict__ cm,
+                                                 const uint64_t *__restrict__ dm,
+                                                 const uint64_t *__restrict__ zm,
+                                                 const uint32_t *__restrict__ tile_cnt,
+                                                 const uint32_t *__restrict__ tile_allow,
+                                                 const uint32_t *__restrict__ tile_keep_prefix,
+                                                 uint64_t *__restrict__ keyT)
+{
+    __shared__ uint64_t s_keep[TILE_WORDS], s_ceff[TILE_WORDS];
+    __shared__ uint32_t s_cpop[TILE_WORDS], s_kpre[TILE_WORDS];
+    __shared__ uint32_t s_vis[4];
+    const uint32_t N = st->cull_n;
+    const SurfelSet src = M.s[st->cull_src], dst = M.s[st->cull_dst];
+    const bool inplace = st->cull_src == st->cull_dst;
+    const uint32_t ntiles = (N + TILE - 1) / TILE;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t vis = 0;
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint32_t allow = tile_allow[tile], nconf = tile_cnt[tile * 3];
+        uint64_t c = 0, d = 0, z = 0, valid = 0;
+        if (threadIdx.x < TILE_WORDS) {
+            const uint32_t word = tile * TILE_WORDS + threadIdx.x;
+            const uint64_t base = (uint64_t)word * 64u;
+            if (base < N) {
+                c = cm[word]; d = dm[word]; z = zm[word];
+                const uint64_t rem = (uint64_t)N - base;
+                valid = rem >= 64 ? ~0ull : ((1ull << rem) - 1ull);
+            }
+            s_cpop[threadIdx.x] = (uint32_t)__popcll(c);
+        }
+        __syncthreads();
+        if (threadIdx.x < TILE_WORDS) {
+            uint64_t ce = c;
+            if (allow != nconf) {
+                uint32_t before = 0;
+                for (int w = 0; w < (int)threadIdx.x; ++w) before += s_cpop[w];
+                ce = before >= allow ? 0ull : first_n_bits(c, allow - before);
+            }
+            const uint64_t keep = ~(z | (ce & d)) & valid;
+            s_ceff[threadIdx.x] = ce;
+            s_keep[threadIdx.x] = keep;
+        }
+        __syncthreads();
+        if (threadIdx.x < TILE_WORDS) {
+            uint32_t before = 0;
+            for (int w = 0; w < (int)threadIdx.x; ++w) before += (uint32_t)__popcll(s_keep[w]);
+            s_kpre[threadIdx.x] = before;
+        }
+        __syncthreads();
+        const uint32_t base_id = tile_keep_prefix[tile];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int w = r * 4 + wave;
+            const uint64_t keepw = s_keep[w];
+            const uint32_t k = (tile * TILE_WORDS + w) * 64u + lane;
+            const bool kept = (keepw >> lane) & 1ull;
+            bool drew = false;
+            if (kept) {
+                const uint32_t nid = base_id + s_kpre[w] + (uint32_t)__popcll(keepw & ((1ull << lane) - 1ull));
+                float4 v = src.pos_conf[k];
+                const bool dec = (s_ceff[w] >> lane) & 1ull;
+                if (dec) v.w -= 1.0f;                    // conflict.vert:72
+                const float tl = src.time[k];
+                if (!inplace) {
+                    dst.pos_conf[nid] = v;
+                    dst.norm_rad[nid] = src.norm_rad[k];
+                    dst.color[nid] = src.color[k];
+                    dst.init_time[nid] = src.init_time[k];
+                    dst.time[nid] = tl;
+                } else if (dec) {
+                    src.pos_conf[k].w = v.w;
+                }
+                if (SPLAT) drew = splat_one(fp, v.x, v.y, v.z, tl, nid, keyT);
+            }
+            if (SPLAT) vis += (uint32_t)__popcll(__ballot(drew));
+        }
+        __syncthreads();
+    }
+    if (SPLAT) {
+        if (lane == 0) s_vis[wave] = vis;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const uint32_t t = s_vis[0] + s_vis[1] + s_vis[2] + s_vis[3];
+            if (t) atomicAdd(&st->visible_count, t);
+        }
+    }
+}
+
+// standalone p6 (IndexMap::predictIndices) over the current model
+__global__ __launch_bounds__(256) void k_splat(Model M, DevState *__restrict__ st, FrameParams fp,
+                                               uint64_t *__restrict__ keyT)
+{
+    __shared__ uint32_t s_vis[4];
+    const uint32_t N = st->count;
+    const SurfelSet cur = M.s[st->cur];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t vis = 0;
+    const uint32_t nchunks = (N + 255u) / 256u;
+    for (uint32_t b = blockIdx.x; b < nchunks; b += gridDim.x) {
+        const uint32_t k = b * 256u + threadIdx.x;
+        bool drew = false;
+        if (k < N) {
+            const float4 v = cur.pos_conf[k];
+            drew = splat_one(fp, v.x, v.y, v.z, cur.time[k], k, keyT);
+        }
+        vis += (uint32_t)__popcll(__ballot(drew));
+    }
+    if (lane == 0) s_vis[wave] = vis;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t t = s_vis[0] + s_vis[1] + s_vis[2] + s_vis[3];
+        if (t) atomicAdd(&st->visible_count, t);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// p8 data association (data.vert:59-234) for pixel q = i*H + j.
+// ---------------------------------------------------------------------------------------------
+struct LocalSurfel {
+    float3 pos;       // vPosLocal
+    float3 nrm;       // vNormLocal
+    float radius;     // radii_n
+    float cr, cg, cb; // color_n
+    uint32_t sem;
+    float xl, yl, lambda;
+};
+
+__device__ __forceinline__ float3 get_vertex(float z, float x, float y, const FrameParams &fp)
+{
+    // geometry.glsl:5-9
+    float3 r;
+    r.x = (x - fp.cx) * z * fp.inv_fx;
+    r.y = (y - fp.cy) * z * fp.inv_fy;
+    r.z = z;
+    return r;
+}
+
+__device__ __forceinline__ bool local_surfel(int q, const FrameParams &fp, const float *__restrict__ depthT,
+                                             const uint32_t *__restrict__ rgbsT, const float *__restrict__ xs,
+                                             const float *__restrict__ ys, LocalSurfel &L)
+{
+    const int H = fp.H, W = fp.W;
+    const int i = q / H, j = q - i * H;
+    const float x = xs[i], y = ys[j];
+    const float z = depthT[q];
+    // clamp-to-edge neighbours: at the border the neighbour depth is the pixel's own (A1)
+    const float zl = depthT[i > 0 ? q - H : q];
+    const float zu = depthT[j > 0 ? q - 1 : q];
+    const float zr = depthT[i < W - 1 ? q + H : q];
+    const float zd = depthT[j < H - 1 ? q + 1 : q];
+    // checkNeighbours data.vert:33-52 + range + checkerboard data.vert:87-88
+    if (zl == 0.0f || zu == 0.0f || zr == 0.0f || zd == 0.0f) return false;
+    if (!(z > fp.min_depth && z < fp.max_depth)) return false;
+    if ((((int)x + (int)y) % 2) != 1) return false;
+    L.xl = (x - fp.cx) * fp.inv_fx;
+    L.yl = (y - fp.cy) * fp.inv_fy;
+    L.lambda = sqrtf((L.xl * L.xl + L.yl * L.yl) + 1.0f);
+    L.pos = get_vertex(z, x, y, fp);
+    // getNormal geometry.glsl:12-24
+    const float3 xf = get_vertex(zr, x + 1.0f, y, fp);
+    const float3 xb = get_vertex(zl, x - 1.0f, y, fp);
+    const float3 yf = get_vertex(zd, x, y + 1.0f, fp);
+    const float3 yb = get_vertex(zu, x, y - 1.0f, fp);
+    const float3 del_x = make_float3(xb.x - xf.x, xb.y - xf.y, xb.z - xf.z);
+    const float3 del_y = make_float3(yb.x - yf.x, yb.y - yf.y, yb.z - yf.z);
+    L.nrm = normalize3(cross3(del_x, del_y));
+    const uint32_t c = rgbsT[q];
+    L.cr = (float)((c >> 16) & 0xFFu) / 255.0f;     // GL_RGB32F upload of u8 (A1)
+    L.cg = (float)((c >> 8) & 0xFFu) / 255.0f;
+    L.cb = (float)(c & 0xFFu) / 255.0f;
+    L.sem = c >> 24;
+    L.radius = get_radius(L.pos.z, L.nrm.z, fp.inv_fx, fp.inv_fy);
+    return true;
+}
+
+// Association + in-place fuse (p8 + p9 + p10).  Every surfel id occupies at most one key-map
+// pixel, so the read-modify-write of surfel `id` by this thread is race-free.
+// New surfels are only flagged here (ballot word per wave) and counted per block.
+__global__ __launch_bounds__(PIX_BLOCK) void k_associate(Model M, const DevState *__restrict__ st, FrameParams fp,
+                                                         const float *__restrict__ depthT,
+                                                         const uint32_t *__restrict__ rgbsT,
+                                                         const uint64_t *__restrict__ keyT,
+                                                         const float *__restrict__ xs, const float *__restrict__ ys,
+                                                         uint64_t *__restrict__ newmask,
+                                                         uint32_t *__restrict__ blk_new, uint32_t *__restrict__ blk_fused)
+{
+    __shared__ uint32_t s_n[4], s_f[4];
+    const SurfelSet cur = M.s[st->cur];
+    const int q = blockIdx.x * PIX_BLOCK + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    bool is_new = false, is_fused = false;
+    LocalSurfel L;
+    if (q < fp.P && local_surfel(q, fp, depthT, rgbsT, xs, ys, L)) {
+        is_new = true;
+        const uint64_t key = keyT[q];
+        const int32_t id = (int32_t)(uint32_t)(key & 0xFFFFFFFFull);
+        if (key != KEY_EMPTY && id > 0) {                                   // data.vert:142
+            const float4 pc = cur.pos_conf[id];
+            const uint32_t col = cur.color[id];
+            const uint32_t sem_o = col >> 24;
+            // index_map.vert:40,61 camera-frame attributes, recomputed from the model
+            const float3 vo = xform3(fp.t_inv, pc.x, pc.y, pc.z);
+            if (L.sem == sem_o && fabsf(vo.z * L.lambda - L.pos.z * L.lambda) <= fp.fuse_thresh) {   // data.vert:151
+                const float3 ray = make_float3(L.xl, L.yl, 1.0f);
+                const float3 cr = cross3(ray, vo);
+                const float dist = sqrtf(dot3(cr, cr)) / sqrtf(dot3(ray, ray));
+                const float4 nr = cur.norm_rad[id];
+                const float3 no = normalize3(rot3(fp.t_inv, nr.x, nr.y, nr.z));                       // index_map.vert:63
+                const float ang = acos_spec(dot3(no, L.nrm) / (sqrtf(dot3(no, no)) * sqrtf(dot3(L.nrm, L.nrm))));
+                if (dist < 1000.0f && fabsf(ang) < 0.5f) {                                           // data.vert:158
+                    is_new = false;
+                    is_fused = true;
+                    const float c_n = 0.9f, c_o = pc.w;
+                    const float w = c_n + c_o;
+                    float4 opc, onr;
+                    uint32_t ocol;
+                    if (L.radius < 1.5f * nr.w) {                                                     // data.vert:177-194
+                        const float pnx = ((c_n * L.pos.x) + (c_o * vo.x)) / w;
+                        const float pny = ((c_n * L.pos.y) + (c_o * vo.y)) / w;
+                        const float pnz = ((c_n * L.pos.z) + (c_o * vo.z)) / w;
+                        const float3 pw = xform3(fp.pose, pnx, pny, pnz);
+                        opc = make_float4(pw.x, pw.y, pw.z, w);
+                        const float ar = ((c_n * L.cr) + (c_o * L.cr)) / w;                          // sic data.vert:183
+                        const float ag = ((c_n * L.cg) + (c_o * L.cg)) / w;
+                        const float ab = ((c_n * L.cb) + (c_o * L.cb)) / w;
+                        ocol = encode_color(ar, ag, ab, L.sem);
+                        const float nx = ((c_n * L.nrm.x) + (c_o * no.x)) / w;
+                        const float ny = ((c_n * L.nrm.y) + (c_o * no.y)) / w;
+                        const float nz = ((c_n * L.nrm.z) + (c_o * no.z)) / w;
+                        const float3 nw = normalize3(rot3(fp.pose, nx, ny, nz));
+                        onr = make_float4(nw.x, nw.y, nw.z, (L.radius > nr.w) ? nr.w : L.radius);
+                    } else {                                                                          // data.vert:195-208
+                        const float3 pw = xform3(fp.pose, vo.x, vo.y, vo.z);
+                        opc = make_float4(pw.x, pw.y, pw.z, w);
+                        ocol = encode_color((float)((col >> 16) & 0xFFu) / 255.0f, (float)((col >> 8) & 0xFFu) / 255.0f,
+                                            (float)(col & 0xFFu) / 255.0f, L.sem);
+                        const float3 nw = normalize3(rot3(fp.pose, no.x, no.y, no.z));
+                        onr = make_float4(nw.x, nw.y, nw.z, nr.w);
+                    }
+                    cur.pos_conf[id] = opc;          // fuse.vert:17-49 scatter, in place
+                    cur.norm_rad[id] = onr;
+                    cur.color[id] = ocol;
+                    cur.time[id] = (float)fp.time;   // initTime kept (data.vert:187)
+                }
+            }
+        }
+    }
+    const uint64_t nw = __ballot(is_new), fw = __ballot(is_fused);
+    if (lane == 0) {
+        const int word = blockIdx.x * (PIX_BLOCK / 64) + wave;
+        if (word * 64 < fp.P) newmask[word] = nw;
+        s_n[wave] = (uint32_t)__popcll(nw);
+        s_f[wave] = (uint32_t)__popcll(fw);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        blk_new[blockIdx.x] = s_n[0] + s_n[1] + s_n[2] + s_n[3];
+        blk_fused[blockIdx.x] = s_f[0] + s_f[1] + s_f[2] + s_f[3];
+    }
+}
+
+// scan of the per-block new-surfel counts; publishes data/unstable/fused counts and the new
+// model count (GlobalModel::concatenate src/GlobalModel.cpp:629) with the capacity check the
+// reference lacks.
+__global__ __launch_bounds__(1024) void k_scan_new(DevState *__restrict__ st, FrameParams fp, int nblocks,
+                                                   const uint32_t *__restrict__ blk_new,
+                                                   const uint32_t *__restrict__ blk_fused,
+                                                   uint32_t *__restrict__ blk_prefix)
+{
+    __shared__ uint32_t s_scan[17];
+    const uint32_t nb = (uint32_t)nblocks;
+    const uint32_t per = (nb + 1023u) / 1024u;
+    const uint32_t b0 = min(threadIdx.x * per, nb), b1 = min(b0 + per, nb);
+    uint32_t ns = 0, fs = 0;
+    for (uint32_t b = b0; b < b1; ++b) { ns += blk_new[b]; fs += blk_fused[b]; }
+    uint32_t ntot, ftot;
+    uint32_t npre = block_scan_1024(ns, &ntot, s_scan);
+    block_scan_1024(fs, &ftot, s_scan);
+    for (uint32_t b = b0; b < b1; ++b) { blk_prefix[b] = npre; npre += blk_new[b]; }
+    if (threadIdx.x == 0) {
+        st->unstable_count = ntot;
+        st->fused_count = ftot;
+        st->data_count = ntot + ftot;
+        if ((uint64_t)st->offset + ntot > (uint64_t)fp.max_vertices) {
+            st->error = -2;          // SM_E_CAPACITY: append nothing instead of corrupting state
+            st->append_n = 0;
+            st->count = st->offset;
+        } else {
+            st->append_n = ntot;
+            st->count = st->offset + ntot;
+        }
+    }
+}
+
+// p11 concatenate (unstable.vert:13-34 + glCopyBufferSubData src/GlobalModel.cpp:627): the new
+// surfels are (re)computed here and written straight to their final slot, in pixel order.
+__global__ __launch_bounds__(PIX_BLOCK) void k_append(Model M, const DevState *__restrict__ st, FrameParams fp,
+                                                      const float *__restrict__ depthT,
+                                                      const uint32_t *__restrict__ rgbsT,
+                                                      const float *__restrict__ xs, const float *__restrict__ ys,
+                                                      const uint64_t *__restrict__ newmask,
+                                                      const uint32_t *__restrict__ blk_prefix)
+{
+    if (st->append_n == 0) return;
+    const SurfelSet cur = M.s[st->cur];
+    const int q = blockIdx.x * PIX_BLOCK + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int word0 = blockIdx.x * (PIX_BLOCK / 64);
+    const int nwords = (fp.P + 63) >> 6;
+    if (word0 + wave >= nwords) return;
+    const uint64_t mw = newmask[word0 + wave];
+    if (!((mw >> lane) & 1ull)) return;
+    uint32_t before = 0;
+    for (int w = 0; w < wave; ++w) before += (uint32_t)__popcll(newmask[word0 + w]);
+    const uint32_t slot = st->offset + blk_prefix[blockIdx.x] + before + (uint32_t)__popcll(mw & ((1ull << lane) - 1ull));
+    LocalSurfel L;
+    if (!local_surfel(q, fp, depthT, rgbsT, xs, ys, L)) return;   // cannot happen: flagged pixels are valid
+    // data.vert:210-225
+    const float3 pw = xform3(fp.pose, L.pos.x, L.pos.y, L.pos.z);
+    const float3 nw = normalize3(rot3(fp.pose, L.nrm.x, L.nrm.y, L.nrm.z));
+    cur.pos_conf[slot] = make_float4(pw.x, pw.y, pw.z, 0.9f);
+    cur.norm_rad[slot] = make_float4(nw.x, nw.y, nw.z, L.radius);
+    cur.color[slot] = encode_color(L.cr, L.cg, L.cb, L.sem);
+    cur.init_time[slot] = (float)fp.time;
+    cur.time[slot] = (float)fp.time;
+}
+
+// ---------------------------------------------------------------------------------------------
+// export helpers (not on the hot path)
+// ---------------------------------------------------------------------------------------------
+__global__ void k_export_aos(Model M, const DevState *__restrict__ st, float *__restrict__ dst, uint32_t first, uint32_t n)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const SurfelSet cur = M.s[st->cur];
+    const uint32_t k = first + t;
+    const float4 pc = cur.pos_conf[k], nr = cur.norm_rad[k];
+    float *o = dst + (size_t)t * 12;
+    o[0] = pc.x; o[1] = pc.y; o[2] = pc.z; o[3] = pc.w;
+    o[4] = __uint_as_float(cur.color[k]); o[5] = 0.0f; o[6] = cur.init_time[k]; o[7] = cur.time[k];
+    o[8] = nr.x; o[9] = nr.y; o[10] = nr.z; o[11] = nr.w;
+}
+
+__global__ void k_import_aos(Model M, const DevState *__restrict__ st, const float *__restrict__ src, uint32_t first, uint32_t n)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const SurfelSet cur = M.s[st->cur];
+    const uint32_t k = first + t;
+    const float *o = src + (size_t)t * 12;
+    cur.pos_conf[k] = make_float4(o[0], o[1], o[2], o[3]);
+    cur.color[k] = __float_as_uint(o[4]);
+    cur.init_time[k] = o[6];
+    cur.time[k] = o[7];
+    cur.norm_rad[k] = make_float4(o[8], o[9], o[10], o[11]);
+}
+
+// index-map textures (index_map.vert:61-63) materialised from the key map, row-major output
+__global__ void k_export_index(Model M, const DevState *__restrict__ st, FrameParams fp,
+                               const uint64_t *__restrict__ keyT, int32_t *__restrict__ id_out,
+                               float4 *__restrict__ vc, float4 *__restrict__ ct, float4 *__restrict__ nr)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= fp.P) return;
+    const int j = p / fp.W, i = p - j * fp.W;
+    const uint64_t key = keyT[(size_t)i * fp.H + j];
+    const SurfelSet cur = M.s[st->cur];
+    int32_t id = 0;
+    float4 a = make_float4(0, 0, 0, 0), b = a, c = a;
+    if (key != KEY_EMPTY) {
+        id = (int32_t)(uint32_t)(key & 0xFFFFFFFFull);
+        const float4 pc = cur.pos_conf[id];
+        const float3 ph = xform3(fp.t_inv, pc.x, pc.y, pc.z);
+        a = make_float4(ph.x, ph.y, ph.z, pc.w);
+        b = make_float4(__uint_as_float(cur.color[id]), 0.0f, cur.init_time[id], cur.time[id]);
+        const float4 n = cur.norm_rad[id];
+        const float3 nn = normalize3(rot3(fp.t_inv, n.x, n.y, n.z));
+        c = make_float4(nn.x, nn.y, nn.z, n.w);
+    }
+    if (id_out) id_out[p] = id;
+    if (vc) vc[p] = a;
+    if (ct) ct[p] = b;
+    if (nr) nr[p] = c;
+}
+
+}  // namespace sm

@@ -1,0 +1,211 @@
+"""GPU parity tests: the HIP path (through the C-ABI) against the CPU oracle on the same
+seeded inputs.  Bar: surfel count exact and every stored field bit-exact (both sides evaluate
+the same IEEE-fp32 expression trees; DESIGN.md "Arithmetic")."""
+import math
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from backends import assert_models_equal, make
+from surfelmapping_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+
+SMALL = dict(width=320, height=120, fx=180.0, fy=180.0, cx=159.5, cy=59.5)
+IDENT = np.eye(4, dtype=np.float32).T.reshape(16).copy()
+COUNT_KEYS = ("count", "offset", "data_count", "conflict_count", "unstable_count", "fused_count",
+              "visible_count", "tick")
+
+
+def pair(cam, **over):
+    args = (cam["width"], cam["height"], cam["fx"], cam["fy"], cam["cx"], cam["cy"])
+    over.setdefault("preprocess", 0)
+    o = make("oracle", *args, **over)
+    h = make("hip", *args, **over)
+    return o, h
+
+
+def check(o, h, what, counts=True, model=True):
+    if counts:
+        co, ch = o.counts(), h.counts()
+        assert {k: co[k] for k in COUNT_KEYS} == {k: ch[k] for k in COUNT_KEYS}, what
+    if model:
+        assert_models_equal(o.download_model(), h.download_model(), what)
+
+
+def run_sequence(o, h, seq, every=1):
+    for k, fr in enumerate(seq):
+        o.process_frame(*fr)
+        h.process_frame(*fr)
+        if k % every == 0 or k == len(seq) - 1:
+            check(o, h, f"frame {k}")
+
+
+def test_moving_camera_small():
+    seq = synth.make_sequence(SMALL, synth.kitti_trajectory(8), seed=3)
+    o, h = pair(SMALL, stereo_border=20.0, max_sqrt_vertices=600)
+    run_sequence(o, h, seq)
+    assert o.counts()["count"] > 10000 and o.counts()["conflict_count"] > 0
+
+
+def test_static_camera_fuses():
+    seq = synth.make_sequence(SMALL, [synth.pose_matrix(0, 0, 0)] * 5, seed=4)
+    o, h = pair(SMALL, stereo_border=20.0, max_sqrt_vertices=600)
+    run_sequence(o, h, seq)
+    assert o.counts()["fused_count"] > 1000
+
+
+def test_fuse_thresh_with_noise_exercises_both_fuse_branches():
+    poses = [synth.pose_matrix(0, 0, 0.05 * k, 0.2 * math.sin(k)) for k in range(8)]
+    seq = synth.make_sequence(SMALL, poses, seed=5, noise_mm=4.0)
+    o, h = pair(SMALL, stereo_border=20.0, fuse_thresh=0.05, max_sqrt_vertices=600)
+    run_sequence(o, h, seq)
+    c = o.counts()
+    assert c["fused_count"] > 500 and c["unstable_count"] > 500 and c["conflict_count"] > 100
+    m = o.download_model()
+    assert (m[:, 3] > 1.0).sum() > 500          # confidence accumulated
+
+
+def test_config1_vga_identity_three_calls():
+    """BASELINE configs[0]: 640x480, identity pose: call 1 reference only, 2 all new, 3 fuse."""
+    cam = synth.VGA
+    seq = synth.make_sequence(cam, [synth.pose_matrix(0, 0, 0)] * 3, seed=1)
+    o, h = pair(cam, max_sqrt_vertices=1000)
+    run_sequence(o, h, seq)
+    c = h.counts()
+    assert c["tick"] == 3 and c["fused_count"] > 0
+
+
+def test_kitti_full_size_sequence():
+    """BASELINE configs[1] shape: 1242x375 KITTI intrinsics, moving camera."""
+    cam = synth.KITTI
+    seq = synth.make_sequence(cam, synth.kitti_trajectory(7), seed=1)
+    o, h = pair(cam, max_sqrt_vertices=2000)
+    run_sequence(o, h, seq, every=2)
+    c = h.counts()
+    assert c["count"] == c["offset"] + c["unstable_count"] and c["count"] > 300000
+
+
+def test_index_map_stage_bit_exact():
+    seq = synth.make_sequence(SMALL, synth.kitti_trajectory(4), seed=6)
+    o, h = pair(SMALL, stereo_border=20.0, max_sqrt_vertices=600)
+    run_sequence(o, h, seq)
+    pose = synth.pose_to_colmajor(synth.pose_matrix(0.1, 0.0, 3.0, 1.0))
+    o.stage_predict_indices(pose, 5, 30.0, 200)
+    h.stage_predict_indices(pose, 5, 30.0, 200)
+    io, ih = o.download_index_map(), h.download_index_map()
+    np.testing.assert_array_equal(io[0], ih[0])
+    for a, b, name in zip(io[1:], ih[1:], ("vertConf", "colorTime", "normRad")):
+        np.testing.assert_array_equal(a.view(np.uint32), b.view(np.uint32), err_msg=name)
+    assert (io[0] > 0).sum() > 1000
+    assert o.counts()["visible_count"] == h.counts()["visible_count"]
+
+
+@pytest.mark.parametrize("cap", [1, 0])
+def test_conflict_cap_first_P_conflicts_only(cap):
+    """conflictVbo holds W*H records (src/GlobalModel.cpp:54-57): with more conflicts than pixels
+    only the first P in surfel order take effect."""
+    cam = dict(width=48, height=32, fx=40.0, fy=40.0, cx=23.5, cy=15.5)
+    o, h = pair(cam, stereo_border=0.0, conflict_cap=cap, max_sqrt_vertices=200)
+    rng = np.random.default_rng(7)
+    n = 20000
+    m = synth.seeded_model(n, tick=5, seed=9)
+    m[:, 0] = rng.uniform(-1.5, 1.5, n)
+    m[:, 1] = rng.uniform(-1.0, 1.0, n)
+    m[:, 2] = rng.uniform(3.0, 6.0, n)
+    m[::7, 3] = 0.0                      # dead-already surfels (conf <= 0)
+    o.upload_model(m)
+    h.upload_model(m)
+    dm = np.full((32, 48), 20.0, np.float32)     # everything measured farther -> conflicts
+    sem = np.zeros((32, 48), np.uint8)
+    o.set_frame(None, dm, sem)
+    h.set_frame(None, dm, sem)
+    o.stage_process_conflict(IDENT, 1.0, 30.0, 0.0, 0)
+    h.stage_process_conflict(IDENT, 1.0, 30.0, 0.0, 0)
+    assert o.counts()["conflict_count"] == h.counts()["conflict_count"]
+    if cap:
+        assert o.counts()["conflict_count"] == 48 * 32
+    else:
+        assert o.counts()["conflict_count"] > 48 * 32
+    o.stage_update_conflict(); o.stage_back_mapping(); o.stage_build_model_map()
+    h.stage_update_conflict(); h.stage_back_mapping(); h.stage_build_model_map()
+    check(o, h, f"cap={cap}", counts=False)
+    co, ch = o.counts(), h.counts()
+    assert co["count"] == ch["count"] and co["offset"] == ch["offset"]
+
+
+def test_clean_points():
+    seq = synth.make_sequence(SMALL, synth.kitti_trajectory(5), seed=8)
+    o, h = pair(SMALL, stereo_border=20.0, max_sqrt_vertices=600)
+    run_sequence(o, h, seq[:4])
+    rgb, d, s, p = seq[1]
+    o.clean_points(d, s, p)
+    h.clean_points(d, s, p)
+    check(o, h, "after cleanPoints")
+    run_sequence(o, h, seq[4:])
+
+
+def test_async_device_resident_frames_match_sync_path():
+    seq = synth.make_sequence(SMALL, synth.kitti_trajectory(6), seed=10)
+    o, h = pair(SMALL, stereo_border=20.0, max_sqrt_vertices=600)
+    P = SMALL["width"] * SMALL["height"]
+    bufs = []
+    for rgb, d, s, p in seq:
+        dr, dd, ds = h.device_alloc(P * 3), h.device_alloc(P * 2), h.device_alloc(P)
+        h.device_upload(dr, rgb); h.device_upload(dd, d); h.device_upload(ds, s)
+        bufs.append((dr, dd, ds, p))
+    for fr in seq:
+        o.process_frame(*fr)
+    for dr, dd, ds, p in bufs:
+        h.process_frame_device(dr, dd, ds, p)      # enqueue only, no host sync in between
+    h.sync()
+    check(o, h, "async")
+
+
+def test_map_save_load_roundtrip(tmp_path):
+    seq = synth.make_sequence(SMALL, synth.kitti_trajectory(3), seed=11)
+    o, h = pair(SMALL, stereo_border=20.0, max_sqrt_vertices=600)
+    run_sequence(o, h, seq)
+    path = str(tmp_path / "map.bin")
+    h.save_map(path, 3, 9)
+    raw = open(path, "rb").read()
+    n = int(np.frombuffer(raw[:4], np.uint32)[0])
+    assert n == o.counts()["count"] and len(raw) == 12 + n * 48
+    assert tuple(np.frombuffer(raw[4:12], np.int32)) == (3, 9)
+    assert_models_equal(np.frombuffer(raw[12:], np.float32).reshape(n, 12), o.download_model(), "file")
+    _, h2 = pair(SMALL, stereo_border=20.0, max_sqrt_vertices=600)
+    assert h2.load_map(path) == (3, 9)
+    assert_models_equal(h2.download_model(), o.download_model(), "reloaded")
+
+
+def test_capacity_is_reported_not_corrupted():
+    cam = dict(width=64, height=48, fx=50.0, fy=50.0, cx=31.5, cy=23.5)
+    o, h = pair(cam, stereo_border=0.0, max_sqrt_vertices=30)      # 900 surfels
+    rgb = np.zeros((48, 64, 3), np.uint8)
+    d = np.full((48, 64), 4000, np.uint16)
+    s = np.zeros((48, 64), np.uint8)
+    o.process_frame(rgb, d, s, IDENT); h.process_frame(rgb, d, s, IDENT)
+    rc_o = o.process_frame(rgb, d, s, IDENT, allow=(0, -2))
+    rc_h = h.process_frame(rgb, d, s, IDENT, allow=(0, -2))
+    assert rc_o == rc_h == capi.SM_E_CAPACITY
+    co, ch = o.counts(), h.counts()
+    assert co["count"] == ch["count"] == 0 and co["unstable_count"] == ch["unstable_count"] > 900
+
+
+def test_seeded_two_million_surfels_hd():
+    """BASELINE configs[2] shape at a size the oracle finishes in seconds: 1920x1080, pre-seeded
+    model, dense-depth frames."""
+    cam = synth.HD
+    n = 2_000_000
+    o, h = pair(cam, max_sqrt_vertices=2000, conflict_cap=0)
+    m = synth.seeded_model(n, tick=300, seed=2)
+    o.upload_model(m); h.upload_model(m)
+    o.set_tick(300); h.set_tick(300)
+    seq = synth.make_sequence(cam, synth.kitti_trajectory(3), seed=2)
+    for k, fr in enumerate(seq[1:]):
+        o.process_frame(*fr); h.process_frame(*fr)
+        check(o, h, f"hd frame {k}", model=(k == 1))
+    c = h.counts()
+    assert c["conflict_count"] > 1000 and c["visible_count"] > 10000
