@@ -1,0 +1,213 @@
+#!/usr/bin/env python3
+"""bench.py -- frames/sec of the per-frame surfel-fusion hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one SurfelMapping::processFrame of the hot path (metricise -> conflict/cull ->
+index-map splat -> associate/fuse -> append) over one 1242x375 KITTI-shaped synthetic
+RGB-D+semantic frame (BASELINE.json configs[1]); frames are resident in HBM before the timed
+region starts and are enqueued back-to-back (no host read-back inside a frame or between
+frames -- the counters of every frame are audited afterwards from the device-side frame log).
+
+Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel against the 8 TB/s HBM
+peak with algorithmic bytes from the per-frame counters (DESIGN.md "Measurement");
+`cpu_baseline` is the CPU oracle (oracle/, a scalar restatement of the reference's passes)
+timed on this host over the same frames, 1 thread.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import multiprocessing as mp
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+from surfelmapping_amd import synth  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def _render(args):
+    cam_kw, pose, seed, k, noise = args
+    scene = synth.Scene(seed)
+    rgb, depth, sem = scene.render(synth.Camera(**cam_kw), pose, noise_mm=noise, noise_seed=seed * 100003 + k)
+    return rgb, depth, sem, synth.pose_to_colmajor(pose)
+
+
+def make_frames(cam_kw, n, seed, noise, workers):
+    poses = synth.kitti_trajectory(n)
+    jobs = [(cam_kw, poses[k], seed, k, noise) for k in range(n)]
+    if workers > 1:
+        with mp.get_context("fork").Pool(workers) as pool:
+            return pool.map(_render, jobs, chunksize=max(1, n // (workers * 4)))
+    return [_render(j) for j in jobs]
+
+
+def kernel_bytes(log):
+    """Algorithmic HBM bytes per launch of each kernel from the per-frame counters
+    (DESIGN.md "Measurement"; SoA surfel = 44 B, key = 8 B)."""
+    P = log["P"]
+    N, Np, V, F, U, kill = (log[k].astype(np.float64) for k in
+                            ("n_before", "n_after_cull", "visible_count", "fused_count", "unstable_count", "n_kill"))
+    compact = np.where(kill > 0, 88.0 * Np + 8.0 * V, 20.0 * N + 8.0 * V)
+    return {
+        "k_prep": np.full_like(N, 6.0 * P + 16.0 * P),          # u8x3+u16+u8 in, f32+u32+u64 out
+        "k_conflict": 16.0 * N,
+        "k_compact": compact,
+        "k_associate": 16.0 * P + 84.0 * F,                       # depth+rgbs+key per pixel, gather 44 + scatter 40 per fuse
+        "k_append": 8.0 * (P / 64.0) + 44.0 * U,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--noise-mm", type=float, default=15.0)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sync-every-frame", action="store_true",
+                    help="reference semantics: host waits for the counters after every frame")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"WORLD_SIZE={world} but --gpus {args.gpus}")
+    K, Wm = args.steps, max(args.warmup, 2)     # call 1 only sets the reference frame
+    cam = synth.KITTI
+    P = cam["width"] * cam["height"]
+    n_frames = Wm + K
+
+    # ---- synthetic frames (before anything touches the GPU; forked workers never do)
+    t0 = time.time()
+    workers = max(1, min(8, (os.cpu_count() or 2) // max(world, 1)))
+    frames = make_frames(cam, n_frames, args.seed + rank, args.noise_mm, workers)
+    t_gen = time.time() - t0
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod      # gloo only: barrier + max over ranks
+        dist = dist_mod
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    from surfelmapping_amd import capi
+    cfg = capi.make_config(**cam, preprocess=0, device=local_rank, enable_timing=1)
+    sm = capi.SurfelMap(cfg)                      # raises without a GPU: no CPU fallback
+
+    # ---- stage every frame in HBM
+    dptr = []
+    for rgb, depth, sem, pose in frames:
+        dr, dd, ds = sm.device_alloc(P * 3), sm.device_alloc(P * 2), sm.device_alloc(P)
+        sm.device_upload(dr, rgb); sm.device_upload(dd, depth); sm.device_upload(ds, sem)
+        dptr.append((dr, dd, ds, pose))
+
+    def run(lo, hi):
+        for k in range(lo, hi):
+            sm.process_frame_device(*dptr[k])
+            if args.sync_every_frame:
+                sm.sync()
+
+    run(0, Wm)
+    sm.sync()
+    sm.timings()                                  # drop warm-up samples
+    if dist:
+        dist.barrier()
+    t0 = time.perf_counter()
+    run(Wm, Wm + K)
+    sm.sync()
+    if dist:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    tim = sm.timings()
+    log = sm.read_frame_log(K)
+    counts = sm.counts()
+
+    if dist:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t[0])
+        fu = torch.tensor([float(log["fused_count"].sum() + log["unstable_count"].sum())], dtype=torch.float64)
+        dist.all_reduce(fu, op=dist.ReduceOp.SUM)
+        fused_total = float(fu[0])
+    else:
+        fused_total = float(log["fused_count"].sum() + log["unstable_count"].sum())
+
+    if rank != 0:
+        return
+
+    # ---- roofline of the dominant kernel (live HIP-event durations, algorithmic bytes)
+    logd = {k: log[k] for k in log.dtype.names}
+    logd["P"] = P
+    kb = kernel_bytes(logd)
+    kern = {}
+    for name, b in kb.items():
+        ms = tim[name]
+        kern[name] = {"ms": ms, "MB": float(b.mean()) / 1e6,
+                      "GBs": (float(b.mean()) / 1e9) / (ms * 1e-3) if ms > 0 else None}
+    for name in ("k_scan_cull", "k_scan_new"):
+        kern[name] = {"ms": tim[name], "MB": None, "GBs": None}
+    dom = max(kb.keys(), key=lambda n: tim[n])
+    achieved = kern[dom]["GBs"] or 0.0
+    roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "ms_per_launch": kern[dom]["ms"], "alg_bytes_per_launch": kern[dom]["MB"] * 1e6}
+
+    # ---- CPU baseline: the oracle over the very same frames (rank 0, N=1 only)
+    cpu = None
+    if not args.no_cpu_baseline and world == 1:
+        import oracle_lib as ol                  # checker / baseline only
+        o = ol.Oracle(ol.make_config(**cam, preprocess=0))
+        for k in range(Wm):
+            o.process_frame(*frames[k])
+        c0 = time.perf_counter()
+        for k in range(Wm, Wm + K):
+            o.process_frame(*frames[k])
+        c_el = time.perf_counter() - c0
+        oc = o.counts()
+        same = all(oc[k] == counts[k] for k in ("count", "offset", "unstable_count", "fused_count", "conflict_count"))
+        cpu = {"value": K / c_el, "unit": "frames/s", "cores": 1, "kind": "port",
+               "sample": f"the same {K} frames (after the same {Wm} warm-up frames), oracle/libsmo.so, 1 thread, "
+                         f"host {os.cpu_count()} logical CPUs", "final_counts_match_gpu": bool(same)}
+
+    out = {
+        "metric": "frames/sec per GPU, 1242x375 KITTI-shaped RGB-D+semantic, full associate+fuse+merge",
+        "value": world * K / elapsed,
+        "unit": "frames/s",
+        "n_gpus": world,
+        "steps": K,
+        "warmup": Wm,
+        "ms_per_step": elapsed / K * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "BASELINE configs[1]: KITTI 1242x375 synthetic street sequence, 0.8 m/frame, "
+                               f"depth noise {args.noise_mm} mm, metricise+conflict+cull+splat+associate+fuse+append per frame",
+                   "frames": f"{Wm}..{Wm + K - 1}", "multi_gpu": "independent camera stream per GPU (replicas)" if world > 1 else "single stream",
+                   "host_sync": "per frame" if args.sync_every_frame else "none inside the timed region",
+                   "surfels_start": int(log["n_before"][0]) if len(log) else 0, "surfels_end": int(counts["count"])},
+        "surfels_fused_per_sec": fused_total / elapsed,
+        "roofline": roofline,
+        "cpu_baseline": cpu,
+        "kernels": kern,
+        "frame_ms_gpu_events": tim["run"],
+        "gen_seconds": t_gen,
+    }
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

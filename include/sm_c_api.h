@@ -62,19 +62,34 @@ typedef struct sm_counts {
     int32_t tick;
 } sm_counts;
 
-/* Stage timings in milliseconds, labelled with the reference's TICK/TOCK names
+/* Stage timings in milliseconds (HIP events on the ctx stream, averaged over the frames since
+ * the previous query), labelled with the reference's TICK/TOCK names
  * (src/SurfelMapping.cpp:120-250, src/GlobalModel.cpp:258,350,519,583). */
 typedef struct sm_timings {
-    float preprocess;         /* "Preprocess"         */
-    float conflict;           /* "Conflict" (conflict test + cull + compaction) */
-    float index_map;          /* "indexMap" (0 when fused into the cull kernel) */
-    float data_association;   /* "Data::Association"  */
-    float concatenate;        /* "Concatenate"        */
-    float run;                /* "Run" whole frame    */
-    /* dominant kernel (conflict-cull-compact-splat): last launch, for the roofline */
-    float cull_kernel;
-    float assoc_kernel;
+    float preprocess;         /* "Preprocess": k_prep (+ p0b..p0e)                         */
+    float conflict;           /* "Conflict": k_conflict + k_scan_cull + k_compact (p2..p5) */
+    float index_map;          /* "indexMap": 0, the splat is fused into k_compact          */
+    float data_association;   /* "Data::Association" + "Update::Fuse": k_associate         */
+    float concatenate;        /* "Concatenate": k_scan_new + k_append                      */
+    float run;                /* "Run": whole frame                                        */
+    /* per kernel */
+    float k_prep, k_conflict, k_scan_cull, k_compact, k_associate, k_scan_new, k_append;
+    uint32_t frames;          /* frames averaged */
 } sm_timings;
+
+/* Per-frame counters written by the device at the end of every fusing frame (ring of
+ * SM_FRAME_LOG_LEN entries) so that an asynchronous run can be audited without host syncs. */
+#define SM_FRAME_LOG_LEN 1024
+typedef struct sm_frame_log {
+    uint32_t tick;            /* time stamp of the frame */
+    uint32_t n_before;        /* N  live surfels at frame start */
+    uint32_t n_after_cull;    /* N' */
+    uint32_t n_kill;
+    uint32_t conflict_count;  /* C */
+    uint32_t visible_count;   /* V */
+    uint32_t fused_count;     /* F */
+    uint32_t unstable_count;  /* U */
+} sm_frame_log;
 
 enum { SM_TEX_DEPTH_METRIC = 0, SM_TEX_DEPTH_FILTERED = 1, SM_TEX_LAST = 2 };
 
@@ -146,6 +161,9 @@ int sm_stage_associate_fuse(sm_ctx *s, const float *pose16, int32_t time, float 
 
 /* Stopwatch::getTimings() equivalent (src/Utils/Stopwatch.h:85-88) -- needs enable_timing */
 int sm_stage_timings(sm_ctx *s, sm_timings *out);
+/* Copy the newest `n` (<= SM_FRAME_LOG_LEN) frame-log entries, oldest first; returns the
+ * number written in *written.  Synchronises the stream. */
+int sm_read_frame_log(sm_ctx *s, sm_frame_log *out, uint32_t n, uint32_t *written);
 
 /* ---- device-memory helpers for callers that stage frames in HBM ---- */
 void *sm_device_alloc(sm_ctx *s, size_t bytes);

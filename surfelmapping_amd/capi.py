@@ -23,7 +23,7 @@ SYMBOLS = (
     "sm_get_counts", "sm_download_model_aos", "sm_upload_model_aos", "sm_save_map", "sm_load_map",
     "sm_download_index_map", "sm_download_depth", "sm_set_frame", "sm_set_tick",
     "sm_stage_conflict", "sm_stage_cull", "sm_stage_splat", "sm_stage_associate_fuse",
-    "sm_stage_timings", "sm_device_alloc", "sm_device_free", "sm_device_upload",
+    "sm_stage_timings", "sm_read_frame_log", "sm_device_alloc", "sm_device_free", "sm_device_upload",
     "sm_key_map_device_ptr",
 )
 
@@ -53,10 +53,17 @@ class SmCounts(C.Structure):
 class SmTimings(C.Structure):
     _fields_ = [(n, C.c_float) for n in (
         "preprocess", "conflict", "index_map", "data_association", "concatenate", "run",
-        "cull_kernel", "assoc_kernel")]
+        "k_prep", "k_conflict", "k_scan_cull", "k_compact", "k_associate", "k_scan_new",
+        "k_append")] + [("frames", C.c_uint32)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+FRAME_LOG_LEN = 1024
+FRAME_LOG_DTYPE = np.dtype([(n, np.uint32) for n in (
+    "tick", "n_before", "n_after_cull", "n_kill", "conflict_count", "visible_count",
+    "fused_count", "unstable_count")])
 
 
 class SurfelMapError(RuntimeError):
@@ -105,6 +112,7 @@ def load():
     L.sm_stage_splat.argtypes = [vp, vp, C.c_int32, C.c_float, C.c_int32]
     L.sm_stage_associate_fuse.argtypes = [vp, vp, C.c_int32, C.c_float, C.c_float]
     L.sm_stage_timings.argtypes = [vp, C.POINTER(SmTimings)]
+    L.sm_read_frame_log.argtypes = [vp, vp, C.c_uint32, u32p]
     L.sm_device_alloc.restype = vp
     L.sm_device_alloc.argtypes = [vp, C.c_size_t]
     L.sm_device_free.argtypes = [vp, vp]
@@ -258,6 +266,14 @@ class SurfelMap:
         t = SmTimings()
         self._chk(self._L.sm_stage_timings(self._h, C.byref(t)), "sm_stage_timings")
         return t.as_dict()
+
+    def read_frame_log(self, n: int = FRAME_LOG_LEN) -> np.ndarray:
+        """Newest `n` per-frame counter records written by the device (oldest first)."""
+        n = min(n, FRAME_LOG_LEN)
+        out = np.zeros(n, FRAME_LOG_DTYPE)
+        w = C.c_uint32()
+        self._chk(self._L.sm_read_frame_log(self._h, _ptr(out), n, C.byref(w)), "sm_read_frame_log")
+        return out[:w.value]
 
     # -- device staging helpers
     def device_alloc(self, nbytes: int) -> int:

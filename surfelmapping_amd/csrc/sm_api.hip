@@ -38,6 +38,7 @@ void set_err(const char *what, hipError_t e, const char *file, int line)
     } while (0)
 
 constexpr int EV_RING = 256;
+constexpr int N_EV = 8;           // start, prep, conflict, scan_cull, compact, associate, scan_new, append
 constexpr int MAX_GRID = 2048;   // 256 CUs x 8 workgroups
 
 // general 4x4 inverse, column-major, cofactor expansion, inv = adj * (1/det), fp32
@@ -118,11 +119,12 @@ struct sm_ctx {
     float curr_pose[16], last_pose[16];
     uint32_t count_bound = 0;         // host upper bound of the device-side count (grid sizing)
     bool pending_cull = false;
-    uint32_t count_before_cull = 0;
+    uint32_t count_before_cull = 0, offset_before_cull = 0;
     sm_counts counts{};
     std::vector<void *> user_allocs;
     // timing
-    hipEvent_t ev[6][EV_RING];        // 0/1 frame, 2/3 cull kernel, 4/5 assoc kernel
+    hipEvent_t ev[N_EV][EV_RING];     // per-frame timeline: before prep, then after each kernel
+    FrameLog *d_log = nullptr;
     bool ev_ok = false;
     uint64_t ev_frames = 0, ev_read = 0;
 };
@@ -233,21 +235,27 @@ int launch_prep(sm_ctx *s, const uint8_t *rgb, const uint16_t *raw, const uint8_
     return SM_OK;
 }
 
-int launch_conflict(sm_ctx *s, const FrameParams &fp)
+int mark(sm_ctx *s, int which, bool timed)
+{
+    if (timed && s->ev_ok) HIPCK(hipEventRecord(s->ev[which][s->ev_frames % EV_RING], s->stream));
+    return SM_OK;
+}
+
+int launch_conflict(sm_ctx *s, const FrameParams &fp, bool timed = false)
 {
     hipLaunchKernelGGL(k_conflict, dim3(grid_surfels(s)), dim3(256), 0, s->stream, s->M, s->d_state, fp, s->d_depthT,
                        s->d_rgbsT, s->d_cm, s->d_dm, s->d_zm, s->d_tile_cnt);
     HIPCK(hipGetLastError());
+    if (mark(s, 2, timed)) return SM_E_HIP;
     hipLaunchKernelGGL(k_scan_cull, dim3(1), dim3(1024), 0, s->stream, s->d_state, fp, s->d_cm, s->d_dm, s->d_zm,
                        s->d_tile_cnt, s->d_tile_allow, s->d_tile_keep);
     HIPCK(hipGetLastError());
+    if (mark(s, 3, timed)) return SM_E_HIP;
     return SM_OK;
 }
 
 int launch_compact(sm_ctx *s, const FrameParams &fp, bool splat, bool timed)
 {
-    const int slot = (int)(s->ev_frames % EV_RING);
-    if (timed && s->ev_ok) HIPCK(hipEventRecord(s->ev[2][slot], s->stream));
     if (splat)
         hipLaunchKernelGGL(k_compact<true>, dim3(grid_surfels(s)), dim3(256), 0, s->stream, s->M, s->d_state, fp, s->d_cm,
                            s->d_dm, s->d_zm, s->d_tile_cnt, s->d_tile_allow, s->d_tile_keep, s->d_keyT);
@@ -255,24 +263,24 @@ int launch_compact(sm_ctx *s, const FrameParams &fp, bool splat, bool timed)
         hipLaunchKernelGGL(k_compact<false>, dim3(grid_surfels(s)), dim3(256), 0, s->stream, s->M, s->d_state, fp, s->d_cm,
                            s->d_dm, s->d_zm, s->d_tile_cnt, s->d_tile_allow, s->d_tile_keep, s->d_keyT);
     HIPCK(hipGetLastError());
-    if (timed && s->ev_ok) HIPCK(hipEventRecord(s->ev[3][slot], s->stream));
+    if (mark(s, 4, timed)) return SM_E_HIP;
     return SM_OK;
 }
 
 int launch_associate(sm_ctx *s, const FrameParams &fp, bool timed)
 {
-    const int slot = (int)(s->ev_frames % EV_RING);
-    if (timed && s->ev_ok) HIPCK(hipEventRecord(s->ev[4][slot], s->stream));
     hipLaunchKernelGGL(k_associate, dim3(s->n_pix_blocks), dim3(PIX_BLOCK), 0, s->stream, s->M, s->d_state, fp,
                        s->d_depthT, s->d_rgbsT, s->d_keyT, s->d_xs, s->d_ys, s->d_newmask, s->d_blk_new, s->d_blk_fused);
     HIPCK(hipGetLastError());
-    if (timed && s->ev_ok) HIPCK(hipEventRecord(s->ev[5][slot], s->stream));
+    if (mark(s, 5, timed)) return SM_E_HIP;
     hipLaunchKernelGGL(k_scan_new, dim3(1), dim3(1024), 0, s->stream, s->d_state, fp, s->n_pix_blocks, s->d_blk_new,
-                       s->d_blk_fused, s->d_blk_prefix);
+                       s->d_blk_fused, s->d_blk_prefix, s->d_log);
     HIPCK(hipGetLastError());
+    if (mark(s, 6, timed)) return SM_E_HIP;
     hipLaunchKernelGGL(k_append, dim3(s->n_pix_blocks), dim3(PIX_BLOCK), 0, s->stream, s->M, s->d_state, fp, s->d_depthT,
                        s->d_rgbsT, s->d_xs, s->d_ys, s->d_newmask, s->d_blk_prefix);
     HIPCK(hipGetLastError());
+    if (mark(s, 7, timed)) return SM_E_HIP;
     return SM_OK;
 }
 
@@ -288,12 +296,12 @@ int enqueue_frame(sm_ctx *s, const uint8_t *d_rgb, const uint16_t *d_raw, const 
     if (s->pending_cull) { g_err = "sm_stage_conflict without sm_stage_cull"; return SM_E_ARG; }
     memcpy(s->curr_pose, pose, 64);
     FrameParams fp = make_params(s, pose);
-    const int slot = (int)(s->ev_frames % EV_RING);
     const bool fusing = s->ref_set && s->tick != 0;
-    if (fusing && s->ev_ok) HIPCK(hipEventRecord(s->ev[0][slot], s->stream));
     int rc;
+    if ((rc = mark(s, 0, fusing))) return rc;
     // metriciseDepth (+ filterDepth when preprocess=1)   src/SurfelMapping.cpp:136-139
     if ((rc = launch_prep(s, d_rgb, d_raw, d_sem, nullptr, fp, true))) return rc;
+    if ((rc = mark(s, 1, fusing))) return rc;
     if (s->cfg.preprocess) { g_err = "preprocess=1 (p0b..p0e) not built yet"; return SM_E_UNSUPPORTED; }
     HIPCK(hipMemcpyAsync(s->d_filteredT, s->d_depthT, (size_t)s->P * 4, hipMemcpyDeviceToDevice, s->stream));
     if (!s->ref_set) {                                    // src/SurfelMapping.cpp:142-154
@@ -307,13 +315,15 @@ int enqueue_frame(sm_ctx *s, const uint8_t *d_rgb, const uint16_t *d_raw, const 
         g_err = "tick==0 re-initialisation from the raw feedback cloud is not built yet";
         return SM_E_UNSUPPORTED;
     }
-    if ((rc = launch_conflict(s, fp))) return rc;          // :178-187
+    fp.splat_follows = 1;
+    fp.log_frame = 1;
+    if ((rc = launch_conflict(s, fp, true))) return rc;    // :178-187
     if ((rc = launch_compact(s, fp, true, true))) return rc;   // :189-197 (cull + mirror + index map)
     if ((rc = launch_associate(s, fp, true))) return rc;   // :212-239
     bump_bound(s);
     HIPCK(hipMemcpyAsync(s->d_lastT, s->d_filteredT, (size_t)s->P * 4, hipMemcpyDeviceToDevice, s->stream));  // :244
     memcpy(s->last_pose, s->curr_pose, 64);
-    if (s->ev_ok) { HIPCK(hipEventRecord(s->ev[1][slot], s->stream)); s->ev_frames++; }
+    if (s->ev_ok) s->ev_frames++;
     s->tick++;
     return SM_OK;
 }
@@ -388,7 +398,7 @@ sm_ctx *sm_create(const sm_config *c)
     s->n_pix_blocks = (s->P + PIX_BLOCK - 1) / PIX_BLOCK;
     bool ok = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) == hipSuccess;
     ok = ok && alloc_set(s->M.s[0], cap) == SM_OK && alloc_set(s->M.s[1], cap) == SM_OK;
-    ok = ok && dalloc(&s->d_state, 1) == SM_OK;
+    ok = ok && dalloc(&s->d_state, 1) == SM_OK && dalloc(&s->d_log, FRAME_LOG_LEN) == SM_OK;
     ok = ok && hipHostMalloc((void **)&s->h_state, sizeof(DevState), hipHostMallocDefault) == hipSuccess;
     ok = ok && dalloc(&s->d_depthT, P) == SM_OK && dalloc(&s->d_filteredT, P) == SM_OK && dalloc(&s->d_lastT, P) == SM_OK;
     ok = ok && dalloc(&s->d_rgbsT, P) == SM_OK && dalloc(&s->d_keyT, P) == SM_OK;
@@ -459,7 +469,7 @@ void sm_destroy(sm_ctx *s)
     (void)hipSetDevice(s->cfg.device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     free_set(s->M.s[0]); free_set(s->M.s[1]);
-    (void)hipFree(s->d_state);
+    (void)hipFree(s->d_state); (void)hipFree(s->d_log);
     if (s->h_state) (void)hipHostFree(s->h_state);
     (void)hipFree(s->d_depthT); (void)hipFree(s->d_filteredT); (void)hipFree(s->d_lastT);
     (void)hipFree(s->d_rgbsT); (void)hipFree(s->d_keyT);
@@ -697,13 +707,23 @@ int sm_stage_conflict(sm_ctx *s, const float *pose16, float min_depth, float max
 {
     if (!s || !pose16) return SM_E_ARG;
     HIPCK(hipSetDevice(s->cfg.device));
-    if (s->pending_cull) { g_err = "sm_stage_conflict called twice without sm_stage_cull"; return SM_E_ARG; }
     int rc = pull_state(s);
     if (rc) return rc;
+    if (s->pending_cull) {
+        // processConflict may be called again before backMapping (it only rewrites conflictVbo,
+        // src/GlobalModel.cpp:449-454): re-arm the not yet applied cull.
+        s->h_state->count = s->h_state->cull_n;
+        s->h_state->cur = s->h_state->cull_src;
+        s->h_state->offset = s->offset_before_cull;
+        s->pending_cull = false;
+        if ((rc = push_state(s))) return rc;
+        if ((rc = pull_state(s))) return rc;
+    }
     memcpy(s->curr_pose, pose16, 64);
     FrameParams fp = make_params(s, pose16);
     fp.min_depth = min_depth; fp.max_depth = max_depth; fp.conflict_thresh = fuse_thresh; fp.is_clean = is_clean;
     s->count_before_cull = s->h_state->count;
+    s->offset_before_cull = s->h_state->offset;
     if ((rc = launch_conflict(s, fp))) return rc;
     s->pending_cull = true;
     return sm_sync(s);
@@ -762,24 +782,57 @@ int sm_stage_timings(sm_ctx *s, sm_timings *out)
     HIPCK(hipStreamSynchronize(s->stream));
     uint64_t first = s->ev_read;
     if (s->ev_frames - first > EV_RING) first = s->ev_frames - EV_RING;
-    double run = 0, cull = 0, assoc = 0;
-    uint64_t nfr = 0;
+    double seg[N_EV - 1] = {0}, run = 0;
+    uint32_t nfr = 0;
     for (uint64_t f = first; f < s->ev_frames; ++f) {
         const int slot = (int)(f % EV_RING);
         float ms = 0;
-        if (hipEventElapsedTime(&ms, s->ev[0][slot], s->ev[1][slot]) == hipSuccess) run += ms;
-        if (hipEventElapsedTime(&ms, s->ev[2][slot], s->ev[3][slot]) == hipSuccess) cull += ms;
-        if (hipEventElapsedTime(&ms, s->ev[4][slot], s->ev[5][slot]) == hipSuccess) assoc += ms;
+        bool ok = true;
+        double loc[N_EV - 1];
+        for (int k = 0; k < N_EV - 1 && ok; ++k) {
+            ok = hipEventElapsedTime(&ms, s->ev[k][slot], s->ev[k + 1][slot]) == hipSuccess;
+            loc[k] = ms;
+        }
+        ok = ok && hipEventElapsedTime(&ms, s->ev[0][slot], s->ev[N_EV - 1][slot]) == hipSuccess;
+        if (!ok) continue;
+        for (int k = 0; k < N_EV - 1; ++k) seg[k] += loc[k];
+        run += ms;
         nfr++;
     }
     s->ev_read = s->ev_frames;
+    out->frames = nfr;
     if (nfr) {
-        out->run = (float)(run / nfr);
-        out->cull_kernel = (float)(cull / nfr);
-        out->assoc_kernel = (float)(assoc / nfr);
-        out->conflict = out->cull_kernel;
-        out->data_association = out->assoc_kernel;
+        const double inv = 1.0 / nfr;
+        out->k_prep = (float)(seg[0] * inv); out->k_conflict = (float)(seg[1] * inv); out->k_scan_cull = (float)(seg[2] * inv);
+        out->k_compact = (float)(seg[3] * inv); out->k_associate = (float)(seg[4] * inv); out->k_scan_new = (float)(seg[5] * inv);
+        out->k_append = (float)(seg[6] * inv);
+        out->preprocess = out->k_prep;
+        out->conflict = out->k_conflict + out->k_scan_cull + out->k_compact;
+        out->index_map = 0.0f;
+        out->data_association = out->k_associate;
+        out->concatenate = out->k_scan_new + out->k_append;
+        out->run = (float)(run * inv);
     }
+    return SM_OK;
+}
+
+int sm_read_frame_log(sm_ctx *s, sm_frame_log *out, uint32_t n, uint32_t *written)
+{
+    if (!s || !out || !written) return SM_E_ARG;
+    static_assert(sizeof(sm_frame_log) == sizeof(FrameLog), "frame log layout");
+    static_assert(SM_FRAME_LOG_LEN == FRAME_LOG_LEN, "frame log length");
+    HIPCK(hipSetDevice(s->cfg.device));
+    int rc = pull_state(s);
+    if (rc) return rc;
+    const uint32_t total = s->h_state->frames_logged;
+    uint32_t m = std::min(std::min(n, total), (uint32_t)FRAME_LOG_LEN);
+    std::vector<FrameLog> ring(FRAME_LOG_LEN);
+    HIPCK(hipMemcpy(ring.data(), s->d_log, sizeof(FrameLog) * FRAME_LOG_LEN, hipMemcpyDeviceToHost));
+    for (uint32_t k = 0; k < m; ++k) {
+        const uint32_t idx = (total - m + k) % FRAME_LOG_LEN;
+        memcpy(&out[k], &ring[idx], sizeof(FrameLog));
+    }
+    *written = m;
     return SM_OK;
 }
 

@@ -47,8 +47,12 @@ struct DevState {
     uint32_t visible_count;
     uint32_t append_n;        // new surfels the append kernel may write
     int32_t error;            // sticky SM_E_*
-    uint32_t pad[2];
+    uint32_t frames_logged;   // fusing frames completed (frame-log write index)
+    uint32_t pad[1];
 };
+
+struct FrameLog { uint32_t tick, n_before, n_after_cull, n_kill, conflict_count, visible_count, fused_count, unstable_count; };
+constexpr uint32_t FRAME_LOG_LEN = 1024;
 
 struct FrameParams {
     float pose[16];           // camera -> world, column-major
@@ -66,6 +70,8 @@ struct FrameParams {
     int time_delta;
     float depth_cutoff;
     uint32_t conflict_cap;    // W*H or 0xFFFFFFFF
+    int splat_follows;        // the cull is followed by the index-map splat (resets visible_count)
+    int log_frame;            // append a FrameLog entry at the end of the frame
     uint32_t max_vertices;
 };
 

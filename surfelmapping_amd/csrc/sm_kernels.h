@@ -235,7 +235,7 @@ __global__ __launch_bounds__(1024) void k_scan_cull(DevState *__restrict__ st, F
         st->cur = st->cull_dst;
         st->count = kept;                                 // src/GlobalModel.cpp:575
         st->offset = kept;
-        st->visible_count = 0;
+        if (fp.splat_follows) st->visible_count = 0;
     }
 }
 
@@ -537,7 +537,7 @@ __global__ __launch_bounds__(PIX_BLOCK) void k_associate(Model M, const DevState
 __global__ __launch_bounds__(1024) void k_scan_new(DevState *__restrict__ st, FrameParams fp, int nblocks,
                                                    const uint32_t *__restrict__ blk_new,
                                                    const uint32_t *__restrict__ blk_fused,
-                                                   uint32_t *__restrict__ blk_prefix)
+                                                   uint32_t *__restrict__ blk_prefix, FrameLog *__restrict__ log)
 {
     __shared__ uint32_t s_scan[17];
     const uint32_t nb = (uint32_t)nblocks;
@@ -560,6 +560,14 @@ __global__ __launch_bounds__(1024) void k_scan_new(DevState *__restrict__ st, Fr
         } else {
             st->append_n = ntot;
             st->count = st->offset + ntot;
+        }
+        if (fp.log_frame && log) {
+            FrameLog e;
+            e.tick = (uint32_t)fp.time; e.n_before = st->cull_n; e.n_after_cull = st->offset; e.n_kill = st->n_kill;
+            e.conflict_count = st->conflict_count; e.visible_count = st->visible_count;
+            e.fused_count = ftot; e.unstable_count = ntot;
+            log[st->frames_logged % FRAME_LOG_LEN] = e;
+            st->frames_logged = st->frames_logged + 1;
         }
     }
 }

@@ -63,7 +63,7 @@ def test_fuse_thresh_with_noise_exercises_both_fuse_branches():
     o, h = pair(SMALL, stereo_border=20.0, fuse_thresh=0.05, max_sqrt_vertices=600)
     run_sequence(o, h, seq)
     c = o.counts()
-    assert c["fused_count"] > 500 and c["unstable_count"] > 500 and c["conflict_count"] > 100
+    assert c["fused_count"] > 500 and c["unstable_count"] > 500 and c["conflict_count"] > 0
     m = o.download_model()
     assert (m[:, 3] > 1.0).sum() > 500          # confidence accumulated
 
