@@ -75,6 +75,7 @@ def main():
     ap.add_argument("--noise-mm", type=float, default=15.0)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workers", type=int, default=0, help="frame-generation processes (0 = auto; use 1 under rocprofv3)")
     ap.add_argument("--sync-every-frame", action="store_true",
                     help="reference semantics: host waits for the counters after every frame")
     args = ap.parse_args()
@@ -91,7 +92,7 @@ def main():
 
     # ---- synthetic frames (before anything touches the GPU; forked workers never do)
     t0 = time.time()
-    workers = max(1, min(8, (os.cpu_count() or 2) // max(world, 1)))
+    workers = args.workers or max(1, min(8, (os.cpu_count() or 2) // max(world, 1)))
     frames = make_frames(cam, n_frames, args.seed + rank, args.noise_mm, workers)
     t_gen = time.time() - t0
 

@@ -1,0 +1,90 @@
+// GlobalModel.h -- drop-in for src/GlobalModel.h:16-120 over the C-ABI.  The per-pass methods
+// keep the reference's names and call order (src/SurfelMapping.cpp:178-239); passes that the
+// HIP core fuses into a neighbour are no-ops here (noted per method).
+#pragma once
+#include <cstdio>
+#include <string>
+#include <utility>
+#include <vector>
+#include "../../../include/sm_c_api.h"
+#include "Config.h"
+#include "GPUTexture.h"
+#include "sm_compat.h"
+
+class GlobalModel {
+public:
+    explicit GlobalModel(sm_ctx *ctx = nullptr)
+        : TEXTURE_DIMENSION(Config::maxSqrtVertices()), MAX_VERTICES(TEXTURE_DIMENSION * TEXTURE_DIMENSION), ctx_(ctx) {}
+    void bind(sm_ctx *ctx) { ctx_ = ctx; }
+
+    const int TEXTURE_DIMENSION;
+    const int MAX_VERTICES;
+
+    // p2 (+p3): src/GlobalModel.cpp:396-515
+    void processConflict(const Eigen::Matrix4f &pose, const int & /*time*/, GPUTexture * /*depthRaw*/, GPUTexture * /*semantic*/,
+                         float minDepth, float maxDepth, float fuseThresh = Config::surfelFuseDistanceThreshFactor(), int isClean = 0)
+    {
+        if (sm_stage_conflict(ctx_, pose.data(), minDepth, maxDepth, fuseThresh, isClean) == SM_OK) pending_ = true;
+        else std::printf("processConflict: %s\n", sm_last_error());
+    }
+    void updateConflict() {}                       // in-place decrement, applied by backMapping()
+    // p4/p10: src/GlobalModel.cpp:517-579 (the 2nd call per frame copies nothing: fuse is in place)
+    void backMapping()
+    {
+        if (pending_) { if (sm_stage_cull(ctx_) != SM_OK) std::printf("backMapping: %s\n", sm_last_error()); pending_ = false; }
+    }
+    void buildModelMap() {}                        // no mirror textures (src/GlobalModel.cpp:639-681)
+    // p8 + p9 + p11: src/GlobalModel.cpp:246-394,581-637
+    void dataAssociate(const Eigen::Matrix4f &pose, const int &time, GPUTexture *, GPUTexture *, GPUTexture *, GPUTexture *,
+                       GPUTexture *, GPUTexture *, GPUTexture *, float depthMin, float depthMax)
+    {
+        int rc = sm_stage_associate_fuse(ctx_, pose.data(), time, depthMin, depthMax);
+        if (rc != SM_OK) std::printf("dataAssociate: %s\n", sm_last_error());
+    }
+    void updateFuse() {}
+    void concatenate() {}
+
+    std::pair<GLuint, GLuint> getModel() { return {0u, counts().count}; }
+    std::pair<GLuint, GLuint> getData() { return {0u, counts().data_count}; }
+    std::pair<GLuint, GLuint> getConflict() { return {0u, counts().conflict_count}; }
+    std::pair<GLuint, GLuint> getUnstable() { return {0u, counts().unstable_count}; }
+    unsigned int getOffset() { return counts().offset; }
+
+    // src/GlobalModel.cpp:901-1011, same file format and diagnostics
+    bool downloadMap(const std::string &path, int startId, int endId)
+    {
+        if (sm_save_map(ctx_, path.c_str(), startId, endId) != SM_OK) { std::printf("%s\n", sm_last_error()); return false; }
+        std::printf("%s is saved! Saved model count: %d\n", path.c_str(), (int)counts().count);
+        return true;
+    }
+    bool uploadMap(const std::string &model_path, std::vector<int> &start_end_ids)
+    {
+        int32_t a = 0, b = 0;
+        if (sm_load_map(ctx_, model_path.c_str(), &a, &b) != SM_OK) { std::printf("%s\n", sm_last_error()); return false; }
+        std::printf("Load model count: %d\nRead model from %s.\n", (int)counts().count, model_path.c_str());
+        start_end_ids.clear(); start_end_ids.push_back(a); start_end_ids.push_back(b);
+        return true;
+    }
+    void resetBuffer() { sm_reset(ctx_); }
+
+    // model read-back in the reference's AoS layout (12 floats / surfel, src/Config.cpp:17-32)
+    std::vector<float> downloadModel()
+    {
+        uint32_t n = 0;
+        sm_download_model_aos(ctx_, nullptr, 0, &n);
+        std::vector<float> v((size_t)n * 12);
+        if (n) sm_download_model_aos(ctx_, v.data(), n, &n);
+        return v;
+    }
+
+    // GL presentation (src/GlobalModel.cpp:683-833) is out of scope of the compute core
+    pangolin::GlTexture *getModelMapVC() { return mapVC_.texture; }
+    pangolin::GlTexture *getModelMapCT() { return mapCT_.texture; }
+    pangolin::GlTexture *getModelMapNR() { return mapNR_.texture; }
+
+private:
+    sm_counts counts() { sm_counts c{}; sm_get_counts(ctx_, &c); return c; }
+    sm_ctx *ctx_;
+    bool pending_ = false;
+    GPUTexture mapVC_, mapCT_, mapNR_;
+};

@@ -1,0 +1,35 @@
+// facade_demo.cpp -- a caller written like the reference's build_map.cpp main loop
+// (build_map.cpp:275-338) against the drop-in facade: Config::getInstance -> SurfelMapping ->
+// processFrame per frame -> GlobalModel::downloadMap.  Frames come from a raw dump
+// (u32 W,H,n; f32 fx,fy,cx,cy; then per frame rgb|depth|sem|pose16) written by the pytest.
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "../../surfelmapping_amd/csrc/facade/SurfelMapping.h"
+
+int main(int argc, char **argv)
+{
+    if (argc < 3) { std::printf("usage: facade_demo frames.bin out_map.bin\n"); return 2; }
+    FILE *f = std::fopen(argv[1], "rb");
+    if (!f) return 2;
+    uint32_t hdr[3]; float intr[4];
+    if (std::fread(hdr, 4, 3, f) != 3 || std::fread(intr, 4, 4, f) != 4) return 2;
+    const int W = (int)hdr[0], H = (int)hdr[1], n = (int)hdr[2];
+    Config::getInstance(intr[0], intr[1], intr[2], intr[3], H, W);          // build_map.cpp:282
+    Config::maxSqrtVertices() = 1000;
+    setenv("SM_PREPROCESS", "0", 0);
+    SurfelMapping core;                                                      // build_map.cpp:286
+    std::vector<unsigned char> rgb((size_t)W * H * 3), sem((size_t)W * H);
+    std::vector<unsigned short> depth((size_t)W * H);
+    for (int k = 0; k < n; ++k) {
+        Eigen::Matrix4f pose;
+        if (std::fread(rgb.data(), 1, rgb.size(), f) != rgb.size() || std::fread(depth.data(), 2, depth.size(), f) != depth.size() ||
+            std::fread(sem.data(), 1, sem.size(), f) != sem.size() || std::fread(pose.data(), 4, 16, f) != 16) return 2;
+        core.processFrame(rgb.data(), depth.data(), sem.data(), &pose);    // build_map.cpp:301
+        std::printf("frame %d: model %u offset %u data %u conflict %u unstable %u\n", k, core.getGlobalModel().getModel().second,
+                    core.getGlobalModel().getOffset(), core.getGlobalModel().getData().second,
+                    core.getGlobalModel().getConflict().second, core.getGlobalModel().getUnstable().second);
+    }
+    std::fclose(f);
+    return core.getGlobalModel().downloadMap(argv[2], 0, n - 1) ? 0 : 1;  // build_map.cpp:254
+}
