@@ -35,6 +35,14 @@ from surfelmapping_amd import synth  # noqa: E402
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+def rig_trajectory(n, rank, world, step=0.8):
+    """Camera `rank` of a `world`-camera rig: same forward motion, yaw offset rank*360/world deg
+    (BASELINE configs[4] / SURVEY 8d config 5); world == 1 is the plain KITTI trajectory."""
+    import math
+    yaw0 = 360.0 / world * rank if world > 1 else 0.0
+    return [synth.pose_matrix(0.0, 0.0, step * k, yaw0 + 0.5 * math.sin(k / 20.0)) for k in range(n)]
+
+
 def _render(args):
     cam_kw, pose, seed, k, noise = args
     scene = synth.Scene(seed)
@@ -42,8 +50,8 @@ def _render(args):
     return rgb, depth, sem, synth.pose_to_colmajor(pose)
 
 
-def make_frames(cam_kw, n, seed, noise, workers):
-    poses = synth.kitti_trajectory(n)
+def make_frames(cam_kw, n, seed, noise, workers, rank=0, world=1):
+    poses = rig_trajectory(n, rank, world)
     jobs = [(cam_kw, poses[k], seed, k, noise) for k in range(n)]
     if workers > 1:
         with mp.get_context("fork").Pool(workers) as pool:
@@ -93,14 +101,18 @@ def main():
     # ---- synthetic frames (before anything touches the GPU; forked workers never do)
     t0 = time.time()
     workers = args.workers or max(1, min(8, (os.cpu_count() or 2) // max(world, 1)))
-    frames = make_frames(cam, n_frames, args.seed + rank, args.noise_mm, workers)
+    frames = make_frames(cam, n_frames, args.seed, args.noise_mm, workers, rank, world)
     t_gen = time.time() - t0
 
     dist = None
     if world > 1:
-        import torch.distributed as dist_mod      # gloo only: barrier + max over ranks
+        # torch first: its HIP runtime must be the one the core binds to (one runtime per process)
+        import torch
+        import torch.distributed as dist_mod
         dist = dist_mod
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from surfelmapping_amd import capi
     cfg = capi.make_config(**cam, preprocess=0, device=local_rank, enable_timing=1)
@@ -119,29 +131,45 @@ def main():
             if args.sync_every_frame:
                 sm.sync()
 
+    sm_global = None
+    if dist:
+        from surfelmapping_amd import dist as smd
+        sm_global = capi.SurfelMap(capi.make_config(**cam, preprocess=0, device=local_rank))
+        # warm the collective path (RCCL communicator setup is not part of a frame)
+        g0, c0 = smd.gather_model_device(sm, local_rank)
+        del g0
+
+    def barrier():
+        if dist:
+            dist.barrier()
+            torch.cuda.synchronize()
+
     run(0, Wm)
     sm.sync()
     sm.timings()                                  # drop warm-up samples
-    if dist:
-        dist.barrier()
+    barrier()
     t0 = time.perf_counter()
     run(Wm, Wm + K)
     sm.sync()
-    if dist:
-        dist.barrier()
+    global_count = None
+    if dist:                                      # the exchange step: all-gather into a single GlobalModel
+        gathered, gcounts = smd.gather_model_device(sm, local_rank)
+        global_count = smd.build_global_model(sm_global, gathered, gcounts)
+    barrier()
     elapsed = time.perf_counter() - t0
     tim = sm.timings()
     log = sm.read_frame_log(K)
     counts = sm.counts()
 
     if dist:
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64)
+        dev = torch.device("cuda", local_rank)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t[0])
-        fu = torch.tensor([float(log["fused_count"].sum() + log["unstable_count"].sum())], dtype=torch.float64)
+        fu = torch.tensor([float(log["fused_count"].sum() + log["unstable_count"].sum())], dtype=torch.float64, device=dev)
         dist.all_reduce(fu, op=dist.ReduceOp.SUM)
         fused_total = float(fu[0])
+        dist.destroy_process_group()
     else:
         fused_total = float(log["fused_count"].sum() + log["unstable_count"].sum())
 
@@ -197,7 +225,8 @@ def main():
         "data": "synthetic",
         "config": {"workload": "BASELINE configs[1]: KITTI 1242x375 synthetic street sequence, 0.8 m/frame, "
                                f"depth noise {args.noise_mm} mm, metricise+conflict+cull+splat+associate+fuse+append per frame",
-                   "frames": f"{Wm}..{Wm + K - 1}", "multi_gpu": "independent camera stream per GPU (replicas)" if world > 1 else "single stream",
+                   "frames": f"{Wm}..{Wm + K - 1}", "multi_gpu": (f"{world}-camera rig, one stream per GPU, RCCL all-gather into a single GlobalModel of "
+                                 f"{global_count} surfels inside the timed region") if world > 1 else "single stream",
                    "host_sync": "per frame" if args.sync_every_frame else "none inside the timed region",
                    "surfels_start": int(log["n_before"][0]) if len(log) else 0, "surfels_end": int(counts["count"])},
         "surfels_fused_per_sec": fused_total / elapsed,

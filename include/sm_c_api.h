@@ -169,6 +169,13 @@ int sm_read_frame_log(sm_ctx *s, sm_frame_log *out, uint32_t n, uint32_t *writte
 void *sm_device_alloc(sm_ctx *s, size_t bytes);
 int sm_device_free(sm_ctx *s, void *p);
 int sm_device_upload(sm_ctx *s, void *dst_device, const void *src_host, size_t bytes);
+/* Multi-GPU "all-gather into a single GlobalModel" (BASELINE configs[4]): export the model as
+ * AoS (12 f32 / surfel) into a device staging buffer owned by the ctx (valid until the next
+ * export/download on this ctx) so that RCCL can gather it without a host round trip ... */
+int sm_export_model_device(sm_ctx *s, void **d_aos, uint32_t *n);
+/* ... and append `n` AoS surfels that already live in this GPU's memory to the model
+ * (GlobalModel::concatenate's glCopyBufferSubData, src/GlobalModel.cpp:624-629). */
+int sm_append_model_aos_device(sm_ctx *s, const float *d_src12, uint32_t n);
 /* raw device pointer of the 64-bit depth|id key map (W*H, column-major) for the multi-GPU
  * min-reduction, and the entry points that bracket it */
 void *sm_key_map_device_ptr(sm_ctx *s);

@@ -24,7 +24,7 @@ SYMBOLS = (
     "sm_download_index_map", "sm_download_depth", "sm_set_frame", "sm_set_tick",
     "sm_stage_conflict", "sm_stage_cull", "sm_stage_splat", "sm_stage_associate_fuse",
     "sm_stage_timings", "sm_read_frame_log", "sm_device_alloc", "sm_device_free", "sm_device_upload",
-    "sm_key_map_device_ptr",
+    "sm_export_model_device", "sm_append_model_aos_device", "sm_key_map_device_ptr",
 )
 
 
@@ -117,6 +117,8 @@ def load():
     L.sm_device_alloc.argtypes = [vp, C.c_size_t]
     L.sm_device_free.argtypes = [vp, vp]
     L.sm_device_upload.argtypes = [vp, vp, vp, C.c_size_t]
+    L.sm_export_model_device.argtypes = [vp, C.POINTER(vp), u32p]
+    L.sm_append_model_aos_device.argtypes = [vp, vp, C.c_uint32]
     L.sm_key_map_device_ptr.restype = vp
     L.sm_key_map_device_ptr.argtypes = [vp]
     for name in SYMBOLS:
@@ -288,6 +290,15 @@ class SurfelMap:
     def device_upload(self, dst: int, arr: np.ndarray):
         arr = np.ascontiguousarray(arr)
         self._chk(self._L.sm_device_upload(self._h, dst, _ptr(arr), arr.nbytes), "sm_device_upload")
+
+    def export_model_device(self):
+        """(device pointer of an AoS float32[n][12] staging copy of the model, n)."""
+        p, n = C.c_void_p(), C.c_uint32()
+        self._chk(self._L.sm_export_model_device(self._h, C.byref(p), C.byref(n)), "sm_export_model_device")
+        return p.value, n.value
+
+    def append_model_device(self, d_ptr: int, n: int):
+        self._chk(self._L.sm_append_model_aos_device(self._h, d_ptr, n), "sm_append_model_aos_device")
 
     def key_map_device_ptr(self) -> int:
         return self._L.sm_key_map_device_ptr(self._h)

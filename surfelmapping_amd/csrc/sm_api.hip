@@ -867,6 +867,45 @@ int sm_device_upload(sm_ctx *s, void *dst_device, const void *src_host, size_t b
     return SM_OK;
 }
 
+int sm_export_model_device(sm_ctx *s, void **d_aos, uint32_t *n)
+{
+    if (!s || !d_aos || !n) return SM_E_ARG;
+    HIPCK(hipSetDevice(s->cfg.device));
+    if (s->pending_cull) { g_err = "sm_export_model_device between sm_stage_conflict and sm_stage_cull"; return SM_E_ARG; }
+    int rc = pull_state(s);
+    if (rc) return rc;
+    const uint32_t cnt = s->h_state->count;
+    if ((rc = ensure_export(s, (size_t)std::max(cnt, 1u) * 48))) return rc;
+    if (cnt) {
+        hipLaunchKernelGGL(k_export_aos, dim3((cnt + 255) / 256), dim3(256), 0, s->stream, s->M, s->d_state, (float *)s->d_export, 0u, cnt);
+        HIPCK(hipGetLastError());
+        HIPCK(hipStreamSynchronize(s->stream));
+    }
+    *d_aos = s->d_export;
+    *n = cnt;
+    return SM_OK;
+}
+
+int sm_append_model_aos_device(sm_ctx *s, const float *d_src12, uint32_t n)
+{
+    if (!s || (!d_src12 && n)) return SM_E_ARG;
+    HIPCK(hipSetDevice(s->cfg.device));
+    if (s->pending_cull) { g_err = "sm_append_model_aos_device between sm_stage_conflict and sm_stage_cull"; return SM_E_ARG; }
+    int rc = pull_state(s);
+    if (rc) return rc;
+    const uint32_t cnt = s->h_state->count;
+    if ((uint64_t)cnt + n > s->cap) { g_err = "sm_append_model_aos_device: exceeds MAX_VERTICES"; return SM_E_CAPACITY; }
+    if (n) {
+        hipLaunchKernelGGL(k_import_aos, dim3((n + 255) / 256), dim3(256), 0, s->stream, s->M, s->d_state, d_src12, cnt, n);
+        HIPCK(hipGetLastError());
+        HIPCK(hipStreamSynchronize(s->stream));
+    }
+    s->h_state->count = cnt + n;
+    s->h_state->offset = cnt;
+    if ((rc = push_state(s))) return rc;
+    return pull_state(s);
+}
+
 void *sm_key_map_device_ptr(sm_ctx *s) { return s ? (void *)s->d_keyT : nullptr; }
 
 }  // extern "C"

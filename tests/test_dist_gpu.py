@@ -1,0 +1,53 @@
+"""GPU check of the RCCL plumbing used by bench.py --gpus N (N>1 needs an 8-GPU node and is run
+by the driver): with world_size 1 on one GPU, torch.distributed('nccl') all-gathers the model
+through device buffers owned by the HIP core, and the gathered slices are appended into a second
+context = the single GlobalModel.  Run in a subprocess so that the import order (torch first,
+as bench.py does) is controlled."""
+import os
+import subprocess
+import sys
+import textwrap
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SCRIPT = textwrap.dedent("""
+    import os, sys
+    sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+    ORDER = sys.argv[1]
+    if ORDER == "torch_first":
+        import torch, torch.distributed as dist
+    from surfelmapping_amd import capi, synth, dist as smd
+    capi.load()
+    if ORDER != "torch_first":
+        import torch, torch.distributed as dist
+    import numpy as np
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % (20000 + os.getpid() % 20000), rank=0, world_size=1)
+    torch.cuda.set_device(0)
+    cam = dict(width=320, height=120, fx=180.0, fy=180.0, cx=159.5, cy=59.5)
+    seq = synth.make_sequence(cam, synth.kitti_trajectory(4), seed=3)
+    over = dict(preprocess=0, stereo_border=20.0, max_sqrt_vertices=600)
+    sm = capi.SurfelMap(capi.make_config(**cam, **over))
+    for fr in seq:
+        sm.process_frame(*fr)
+    local = sm.download_model()
+    gathered, counts = smd.gather_model_device(sm, 0)
+    glob = capi.SurfelMap(capi.make_config(**cam, **over))
+    total = smd.build_global_model(glob, gathered, counts)
+    g = glob.download_model()
+    assert total == local.shape[0] == counts[0] > 0, (total, local.shape, counts)
+    assert np.array_equal(g.view(np.uint32), local.view(np.uint32))
+    dist.destroy_process_group()
+    print("DIST_GPU_OK", ORDER, total)
+""") % (ROOT, ROOT)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("order", ["torch_first"])   # torch must be imported before the HIP core (one HIP runtime per process)
+def test_rccl_gather_world1(order, tmp_path):
+    f = tmp_path / "w1.py"
+    f.write_text(SCRIPT)
+    r = subprocess.run([sys.executable, str(f), order], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "DIST_GPU_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
