@@ -63,9 +63,11 @@ def kernel_bytes(log):
     """Algorithmic HBM bytes per launch of each kernel from the per-frame counters
     (DESIGN.md "Measurement"; SoA surfel = 44 B, key = 8 B)."""
     P = log["P"]
-    N, Np, V, F, U, kill = (log[k].astype(np.float64) for k in
-                            ("n_before", "n_after_cull", "visible_count", "fused_count", "unstable_count", "n_kill"))
-    compact = np.where(kill > 0, 88.0 * Np + 8.0 * V, 20.0 * N + 8.0 * V)
+    N, Np, V, F, U, Ns = (log[k].astype(np.float64) for k in
+                          ("n_before", "n_after_cull", "visible_count", "fused_count", "unstable_count", "n_static"))
+    # in-place cull: static tiles are only read for the splat (pos_conf 16 + time 4), the rest is
+    # read and rewritten in full (44 + 44); every drawn surfel costs one 8-byte key atomic
+    compact = 20.0 * Ns + 88.0 * np.maximum(Np - Ns, 0.0) + 8.0 * V
     return {
         "k_prep": np.full_like(N, 6.0 * P + 16.0 * P),          # u8x3+u16+u8 in, f32+u32+u64 out
         "k_conflict": 16.0 * N,
@@ -84,6 +86,7 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workers", type=int, default=0, help="frame-generation processes (0 = auto; use 1 under rocprofv3)")
+    ap.add_argument("--force-dist", action="store_true", help="rehearse the multi-GPU code path with WORLD_SIZE=1")
     ap.add_argument("--sync-every-frame", action="store_true",
                     help="reference semantics: host waits for the counters after every frame")
     args = ap.parse_args()
@@ -105,7 +108,7 @@ def main():
     t_gen = time.time() - t0
 
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         # torch first: its HIP runtime must be the one the core binds to (one runtime per process)
         import torch
         import torch.distributed as dist_mod
@@ -195,7 +198,7 @@ def main():
 
     # ---- CPU baseline: the oracle over the very same frames (rank 0, N=1 only)
     cpu = None
-    if not args.no_cpu_baseline and world == 1:
+    if not args.no_cpu_baseline and dist is None:
         import oracle_lib as ol                  # checker / baseline only
         o = ol.Oracle(ol.make_config(**cam, preprocess=0))
         for k in range(Wm):
@@ -226,7 +229,7 @@ def main():
         "config": {"workload": "BASELINE configs[1]: KITTI 1242x375 synthetic street sequence, 0.8 m/frame, "
                                f"depth noise {args.noise_mm} mm, metricise+conflict+cull+splat+associate+fuse+append per frame",
                    "frames": f"{Wm}..{Wm + K - 1}", "multi_gpu": (f"{world}-camera rig, one stream per GPU, RCCL all-gather into a single GlobalModel of "
-                                 f"{global_count} surfels inside the timed region") if world > 1 else "single stream",
+                                 f"{global_count} surfels inside the timed region") if dist else "single stream",
                    "host_sync": "per frame" if args.sync_every_frame else "none inside the timed region",
                    "surfels_start": int(log["n_before"][0]) if len(log) else 0, "surfels_end": int(counts["count"])},
         "surfels_fused_per_sec": fused_total / elapsed,

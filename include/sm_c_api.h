@@ -30,7 +30,8 @@ enum {
     SM_E_CAPACITY = -2,     /* model would exceed MAX_VERTICES (unchecked in src/GlobalModel.cpp:627-629) */
     SM_E_UNSUPPORTED = -3,
     SM_E_HIP = -4,          /* a HIP runtime call failed; see sm_last_error() */
-    SM_E_NO_DEVICE = -5     /* no gfx950 device visible: the product has NO CPU fallback */
+    SM_E_NO_DEVICE = -5,    /* no gfx950 device visible: the product has NO CPU fallback */
+    SM_E_STALL = -6         /* an in-kernel hand-off wait hit its spin bound (GPU shared with another job?) */
 };
 
 /* Config singleton values (src/Config.cpp:32-37) + the magic numbers of the hot path
@@ -89,6 +90,8 @@ typedef struct sm_frame_log {
     uint32_t visible_count;   /* V */
     uint32_t fused_count;     /* F */
     uint32_t unstable_count;  /* U */
+    uint32_t n_static;        /* surfels the in-place cull did not have to move */
+    uint32_t reserved;
 } sm_frame_log;
 
 enum { SM_TEX_DEPTH_METRIC = 0, SM_TEX_DEPTH_FILTERED = 1, SM_TEX_LAST = 2 };

@@ -63,7 +63,7 @@ class SmTimings(C.Structure):
 FRAME_LOG_LEN = 1024
 FRAME_LOG_DTYPE = np.dtype([(n, np.uint32) for n in (
     "tick", "n_before", "n_after_cull", "n_kill", "conflict_count", "visible_count",
-    "fused_count", "unstable_count")])
+    "fused_count", "unstable_count", "n_static", "reserved")])
 
 
 class SurfelMapError(RuntimeError):

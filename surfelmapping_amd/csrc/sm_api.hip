@@ -40,6 +40,7 @@ void set_err(const char *what, hipError_t e, const char *file, int line)
 constexpr int EV_RING = 256;
 constexpr int N_EV = 8;           // start, prep, conflict, scan_cull, compact, associate, scan_new, append
 constexpr int MAX_GRID = 2048;   // 256 CUs x 8 workgroups
+constexpr int COMPACT_GRID = 1024;  // k_compact: 256 CUs x 4 workgroups, must be fully co-resident (in-place hand-off)
 
 // general 4x4 inverse, column-major, cofactor expansion, inv = adj * (1/det), fp32
 // (the role of Eigen::Matrix4f::inverse() at src/GlobalModel.cpp:419, src/IndexMap.cpp:157)
@@ -104,7 +105,9 @@ struct sm_ctx {
     float *d_xs = nullptr, *d_ys = nullptr;
     // cull scratch
     uint64_t *d_cm = nullptr, *d_dm = nullptr, *d_zm = nullptr;
-    uint32_t *d_tile_cnt = nullptr, *d_tile_allow = nullptr, *d_tile_keep = nullptr;
+    uint32_t *d_tile_cnt = nullptr, *d_tile_allow = nullptr, *d_tile_keep = nullptr, *d_tile_flag = nullptr;
+    uint32_t cull_epoch = 0;
+    int compact_grid = COMPACT_GRID;
     // association scratch
     uint64_t *d_newmask = nullptr;
     uint32_t *d_blk_new = nullptr, *d_blk_fused = nullptr, *d_blk_prefix = nullptr;
@@ -229,7 +232,7 @@ int launch_prep(sm_ctx *s, const uint8_t *rgb, const uint16_t *raw, const uint8_
                 const FrameParams &fp, bool clear_keys)
 {
     const int tiles = ((s->W + 63) / 64) * ((s->H + 63) / 64);
-    hipLaunchKernelGGL(k_prep, dim3(tiles), dim3(256), 0, s->stream, rgb, raw, sem, dm, s->d_depthT, s->d_rgbsT,
+    hipLaunchKernelGGL(k_prep, dim3(tiles), dim3(1024), 0, s->stream, rgb, raw, sem, dm, s->d_depthT, s->d_rgbsT,
                        clear_keys ? s->d_keyT : nullptr, fp);
     HIPCK(hipGetLastError());
     return SM_OK;
@@ -256,12 +259,14 @@ int launch_conflict(sm_ctx *s, const FrameParams &fp, bool timed = false)
 
 int launch_compact(sm_ctx *s, const FrameParams &fp, bool splat, bool timed)
 {
+    const int grid = std::min(grid_surfels(s), s->compact_grid);
+    const uint32_t epoch = ++s->cull_epoch;
     if (splat)
-        hipLaunchKernelGGL(k_compact<true>, dim3(grid_surfels(s)), dim3(256), 0, s->stream, s->M, s->d_state, fp, s->d_cm,
-                           s->d_dm, s->d_zm, s->d_tile_cnt, s->d_tile_allow, s->d_tile_keep, s->d_keyT);
+        hipLaunchKernelGGL(k_compact<true>, dim3(grid), dim3(256), 0, s->stream, s->M, s->d_state, fp, s->d_cm,
+                           s->d_dm, s->d_zm, s->d_tile_cnt, s->d_tile_allow, s->d_tile_keep, s->d_keyT, s->d_tile_flag, epoch);
     else
-        hipLaunchKernelGGL(k_compact<false>, dim3(grid_surfels(s)), dim3(256), 0, s->stream, s->M, s->d_state, fp, s->d_cm,
-                           s->d_dm, s->d_zm, s->d_tile_cnt, s->d_tile_allow, s->d_tile_keep, s->d_keyT);
+        hipLaunchKernelGGL(k_compact<false>, dim3(grid), dim3(256), 0, s->stream, s->M, s->d_state, fp, s->d_cm,
+                           s->d_dm, s->d_zm, s->d_tile_cnt, s->d_tile_allow, s->d_tile_keep, s->d_keyT, s->d_tile_flag, epoch);
     HIPCK(hipGetLastError());
     if (mark(s, 4, timed)) return SM_E_HIP;
     return SM_OK;
@@ -303,9 +308,9 @@ int enqueue_frame(sm_ctx *s, const uint8_t *d_rgb, const uint16_t *d_raw, const 
     if ((rc = launch_prep(s, d_rgb, d_raw, d_sem, nullptr, fp, true))) return rc;
     if ((rc = mark(s, 1, fusing))) return rc;
     if (s->cfg.preprocess) { g_err = "preprocess=1 (p0b..p0e) not built yet"; return SM_E_UNSUPPORTED; }
-    HIPCK(hipMemcpyAsync(s->d_filteredT, s->d_depthT, (size_t)s->P * 4, hipMemcpyDeviceToDevice, s->stream));
+    // preprocess == 0: DEPTH_FILTERED and LAST are the metric depth itself (nothing reads them on the
+    // hot path); they alias d_depthT in sm_download_depth instead of being copied every frame.
     if (!s->ref_set) {                                    // src/SurfelMapping.cpp:142-154
-        HIPCK(hipMemcpyAsync(s->d_lastT, s->d_filteredT, (size_t)s->P * 4, hipMemcpyDeviceToDevice, s->stream));
         memcpy(s->last_pose, s->curr_pose, 64);
         s->ref_set = true;
         s->tick++;
@@ -321,8 +326,7 @@ int enqueue_frame(sm_ctx *s, const uint8_t *d_rgb, const uint16_t *d_raw, const 
     if ((rc = launch_compact(s, fp, true, true))) return rc;   // :189-197 (cull + mirror + index map)
     if ((rc = launch_associate(s, fp, true))) return rc;   // :212-239
     bump_bound(s);
-    HIPCK(hipMemcpyAsync(s->d_lastT, s->d_filteredT, (size_t)s->P * 4, hipMemcpyDeviceToDevice, s->stream));  // :244
-    memcpy(s->last_pose, s->curr_pose, 64);
+    memcpy(s->last_pose, s->curr_pose, 64);               // :244-245 (LAST aliases the metric depth when preprocess == 0)
     if (s->ev_ok) s->ev_frames++;
     s->tick++;
     return SM_OK;
@@ -397,7 +401,7 @@ sm_ctx *sm_create(const sm_config *c)
     const size_t nwords = (cap + 63) / 64 + TILE_WORDS, ntiles = (cap + TILE - 1) / TILE + 1;
     s->n_pix_blocks = (s->P + PIX_BLOCK - 1) / PIX_BLOCK;
     bool ok = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) == hipSuccess;
-    ok = ok && alloc_set(s->M.s[0], cap) == SM_OK && alloc_set(s->M.s[1], cap) == SM_OK;
+    ok = ok && alloc_set(s->M.s[0], cap) == SM_OK;      // one SoA set: the compaction is in place
     ok = ok && dalloc(&s->d_state, 1) == SM_OK && dalloc(&s->d_log, FRAME_LOG_LEN) == SM_OK;
     ok = ok && hipHostMalloc((void **)&s->h_state, sizeof(DevState), hipHostMallocDefault) == hipSuccess;
     ok = ok && dalloc(&s->d_depthT, P) == SM_OK && dalloc(&s->d_filteredT, P) == SM_OK && dalloc(&s->d_lastT, P) == SM_OK;
@@ -407,7 +411,8 @@ sm_ctx *sm_create(const sm_config *c)
     ok = ok && dalloc(&s->d_xs, (size_t)s->W) == SM_OK && dalloc(&s->d_ys, (size_t)s->H) == SM_OK;
     ok = ok && dalloc(&s->d_cm, nwords) == SM_OK && dalloc(&s->d_dm, nwords) == SM_OK && dalloc(&s->d_zm, nwords) == SM_OK;
     ok = ok && dalloc(&s->d_tile_cnt, ntiles * 3) == SM_OK && dalloc(&s->d_tile_allow, ntiles) == SM_OK &&
-         dalloc(&s->d_tile_keep, ntiles) == SM_OK;
+         dalloc(&s->d_tile_keep, ntiles) == SM_OK && dalloc(&s->d_tile_flag, ntiles) == SM_OK &&
+         hipMemset(s->d_tile_flag, 0, ntiles * 4) == hipSuccess;
     ok = ok && dalloc(&s->d_newmask, (P + 63) / 64 + 4) == SM_OK;
     ok = ok && dalloc(&s->d_blk_new, (size_t)s->n_pix_blocks) == SM_OK && dalloc(&s->d_blk_fused, (size_t)s->n_pix_blocks) == SM_OK &&
          dalloc(&s->d_blk_prefix, (size_t)s->n_pix_blocks) == SM_OK;
@@ -454,6 +459,15 @@ sm_ctx *sm_create(const sm_config *c)
         ok = hipStreamSynchronize(s->stream) == hipSuccess;
     }
     if (!ok) { g_err = "sm_create: device initialisation failed"; sm_destroy(s); return nullptr; }
+    {
+        // the in-place compaction needs every workgroup of k_compact resident at once
+        int cus = 0, per_cu = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess && cus > 0 &&
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_compact<true>, 256, 0) == hipSuccess && per_cu > 0) {
+            // the occupancy API can over-report by one block per CU (MI355X_MICROARCH.md): stay at <= 4 and below it
+            s->compact_grid = std::max(1, cus * std::min(4, std::max(1, per_cu - 1)));
+        }
+    }
     if (c->enable_timing) {
         s->ev_ok = true;
         for (auto &row : s->ev)
@@ -476,7 +490,7 @@ void sm_destroy(sm_ctx *s)
     (void)hipFree(s->d_rgb); (void)hipFree(s->d_sem); (void)hipFree(s->d_depth_raw); (void)hipFree(s->d_depth_f32);
     (void)hipFree(s->d_xs); (void)hipFree(s->d_ys);
     (void)hipFree(s->d_cm); (void)hipFree(s->d_dm); (void)hipFree(s->d_zm);
-    (void)hipFree(s->d_tile_cnt); (void)hipFree(s->d_tile_allow); (void)hipFree(s->d_tile_keep);
+    (void)hipFree(s->d_tile_cnt); (void)hipFree(s->d_tile_allow); (void)hipFree(s->d_tile_keep); (void)hipFree(s->d_tile_flag);
     (void)hipFree(s->d_newmask); (void)hipFree(s->d_blk_new); (void)hipFree(s->d_blk_fused); (void)hipFree(s->d_blk_prefix);
     if (s->d_export) (void)hipFree(s->d_export);
     for (void *p : s->user_allocs) (void)hipFree(p);
@@ -663,8 +677,9 @@ int sm_download_depth(sm_ctx *s, int which, float *dst)
 {
     if (!s || !dst) return SM_E_ARG;
     HIPCK(hipSetDevice(s->cfg.device));
-    const float *src = which == SM_TEX_DEPTH_METRIC ? s->d_depthT : which == SM_TEX_DEPTH_FILTERED ? s->d_filteredT
-                     : which == SM_TEX_LAST ? s->d_lastT : nullptr;
+    const bool alias = s->cfg.preprocess == 0;
+    const float *src = which == SM_TEX_DEPTH_METRIC ? s->d_depthT : which == SM_TEX_DEPTH_FILTERED ? (alias ? s->d_depthT : s->d_filteredT)
+                     : which == SM_TEX_LAST ? (alias ? s->d_depthT : s->d_lastT) : nullptr;
     if (!src) return SM_E_ARG;
     int rc = ensure_export(s, (size_t)s->P * 4);
     if (rc) return rc;
@@ -687,7 +702,7 @@ int sm_set_frame(sm_ctx *s, const uint8_t *rgb, const float *depth_metric, const
     FrameParams fp = make_params(s, s->curr_pose);
     // re-pack every plane from the staged inputs; depth only when given (else keep depthT)
     const int tiles = ((s->W + 63) / 64) * ((s->H + 63) / 64);
-    hipLaunchKernelGGL(k_prep, dim3(tiles), dim3(256), 0, s->stream, s->d_rgb, (const uint16_t *)nullptr, s->d_sem,
+    hipLaunchKernelGGL(k_prep, dim3(tiles), dim3(1024), 0, s->stream, s->d_rgb, (const uint16_t *)nullptr, s->d_sem,
                        depth_metric ? s->d_depth_f32 : nullptr, depth_metric ? s->d_depthT : nullptr, s->d_rgbsT,
                        (uint64_t *)nullptr, fp);
     HIPCK(hipGetLastError());

@@ -48,10 +48,10 @@ struct DevState {
     uint32_t append_n;        // new surfels the append kernel may write
     int32_t error;            // sticky SM_E_*
     uint32_t frames_logged;   // fusing frames completed (frame-log write index)
-    uint32_t pad[1];
+    uint32_t n_static;        // surfels in tiles the last cull left in place
 };
 
-struct FrameLog { uint32_t tick, n_before, n_after_cull, n_kill, conflict_count, visible_count, fused_count, unstable_count; };
+struct FrameLog { uint32_t tick, n_before, n_after_cull, n_kill, conflict_count, visible_count, fused_count, unstable_count, n_static, pad; };
 constexpr uint32_t FRAME_LOG_LEN = 1024;
 
 struct FrameParams {

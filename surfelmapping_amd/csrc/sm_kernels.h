@@ -15,24 +15,24 @@ namespace sm {
 // p0a metricise (depth_metric.frag:15-35) + u8 RGB/semantic pack + LDS-tiled transpose to the
 // column-major frame layout + key-map clear.  64x64 pixel tile per 256-thread block.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_prep(const uint8_t *__restrict__ rgb,
-                                              const uint16_t *__restrict__ depth_raw,
-                                              const uint8_t *__restrict__ sem,
-                                              const float *__restrict__ depth_f32,  // optional: metric depth given directly
-                                              float *__restrict__ depthT, uint32_t *__restrict__ rgbsT,
-                                              uint64_t *__restrict__ keyT, FrameParams fp)
+__global__ __launch_bounds__(1024) void k_prep(const uint8_t *__restrict__ rgb,
+                                               const uint16_t *__restrict__ depth_raw,
+                                               const uint8_t *__restrict__ sem,
+                                               const float *__restrict__ depth_f32,  // optional: metric depth given directly
+                                               float *__restrict__ depthT, uint32_t *__restrict__ rgbsT,
+                                               uint64_t *__restrict__ keyT, FrameParams fp)
 {
     __shared__ float s_d[64][65];
     __shared__ uint32_t s_c[64][65];
     const int W = fp.W, H = fp.H;
     const int tiles_x = (W + 63) >> 6;
     const int i0 = (blockIdx.x % tiles_x) << 6, j0 = (blockIdx.x / tiles_x) << 6;
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;      // 16 waves: one image row each per round
     const uint32_t lo = (uint32_t)(fp.min_depth * 1000.0f);
     const uint32_t hi = (uint32_t)((fp.max_depth - 0.001f) * 1000.0f);
-#pragma unroll 4
-    for (int r = 0; r < 16; ++r) {
-        const int jl = ty + 4 * r;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int jl = ty + 16 * r;
         const int i = i0 + tx, j = j0 + jl;
         float d = 0.0f;
         uint32_t c = 0;
@@ -55,9 +55,9 @@ __global__ __launch_bounds__(256) void k_prep(const uint8_t *__restrict__ rgb,
         s_c[jl][tx] = c;
     }
     __syncthreads();
-#pragma unroll 4
-    for (int r = 0; r < 16; ++r) {
-        const int il = ty + 4 * r;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int il = ty + 16 * r;
         const int i = i0 + il, j = j0 + tx;
         if (i < W && j < H) {
             const size_t q = (size_t)i * H + j;
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(1024) void k_scan_cull(DevState *__restrict__ st, F
         ksum += nvalid - kills;
         cpre += nconf;
     }
-    uint32_t ktotal;
+    uint32_t ktotal, nstatic = 0;
     uint32_t kpre = block_scan_1024(ksum, &ktotal, s_scan);
     for (uint32_t t = t0; t < t1; ++t) {
         const uint32_t nconf = tile_cnt[t * 3];
@@ -222,16 +222,21 @@ __global__ __launch_bounds__(1024) void k_scan_cull(DevState *__restrict__ st, F
             }
         }
         tile_keep_prefix[t] = kpre;
-        kpre += min((uint32_t)TILE, N - t * TILE) - kills;
+        const uint32_t nv = min((uint32_t)TILE, N - t * TILE);
+        if (kpre == t * TILE && kills == 0) nstatic += nv;
+        kpre += nv - kills;
     }
+    uint32_t stotal;
+    block_scan_1024(nstatic, &stotal, s_scan);
     if (threadIdx.x == 0) {
+        st->n_static = stotal;
         const uint32_t kept = ktotal;
         const uint32_t nk = N - kept;
         st->cull_n = N;
         st->n_kill = nk;
         st->conflict_count = min(ctotal, cap);
         st->cull_src = st->cur;
-        st->cull_dst = nk ? (st->cur ^ 1u) : st->cur;   // no cull -> stay in place
+        st->cull_dst = st->cur;                           // compaction is in place
         st->cur = st->cull_dst;
         st->count = kept;                                 // src/GlobalModel.cpp:575
         st->offset = kept;
@@ -265,8 +270,20 @@ __device__ __forceinline__ bool splat_one(const FrameParams &fp, float x, float 
 }
 
 // ---------------------------------------------------------------------------------------------
-// p3+p4+p5(+p6): apply the confidence decrement, stable-compact the survivors into the other
-// SoA set (or stay in place when nothing dies) and, fused, splat each survivor under its NEW id.
+// p3+p4+p5(+p6): apply the confidence decrement, stable-compact the survivors IN PLACE and, fused,
+// splat each survivor under its NEW id.
+//
+// In-place stable compaction across workgroups: a survivor never moves to a higher index, so the
+// destination range [prefix, prefix+kept) of tile t lies inside the source regions of tiles <= t.
+// Every tile that moves or loses surfels first loads all its survivors into registers, then
+// publishes tile_flag[t] = epoch ("my source is consumed"), then waits for the flags of the (at
+// most two) lower tiles its destination overlaps, then writes.  Tiles with nothing killed in or
+// before them are "static": they copy nothing (only the decremented confidences are written), so
+// the part of the model the camera has left behind costs 20 B/surfel instead of 88.
+// Deadlock-freedom: a tile only waits for lower-numbered tiles, a tile publishes before it waits,
+// tiles are assigned round-robin to a grid that is fully co-resident (<= 4 workgroups per CU).
+// Flag protocol: agent-scope atomic exchange to publish, sc1 (agent-scope relaxed) load to poll
+// (MI355X_MICROARCH.md "hand-offs measured", row 3); nothing but the flag itself is handed over.
 // ---------------------------------------------------------------------------------------------
 template <bool SPLAT>
 __global__ __launch_bounds__(256) void k_compact(Model M, DevState *__restrict__ st, FrameParams fp,
@@ -276,14 +293,14 @@ __global__ __launch_bounds__(256) void k_compact(Model M, DevState *__restrict__
                                                  const uint32_t *__restrict__ tile_cnt,
                                                  const uint32_t *__restrict__ tile_allow,
                                                  const uint32_t *__restrict__ tile_keep_prefix,
-                                                 uint64_t *__restrict__ keyT)
+                                                 uint64_t *__restrict__ keyT,
+                                                 uint32_t *__restrict__ tile_flag, uint32_t epoch)
 {
     __shared__ uint64_t s_keep[TILE_WORDS], s_ceff[TILE_WORDS];
-    __shared__ uint32_t s_cpop[TILE_WORDS], s_kpre[TILE_WORDS];
+    __shared__ uint32_t s_cpop[TILE_WORDS], s_kpre[TILE_WORDS + 1];
     __shared__ uint32_t s_vis[4];
     const uint32_t N = st->cull_n;
-    const SurfelSet src = M.s[st->cull_src], dst = M.s[st->cull_dst];
-    const bool inplace = st->cull_src == st->cull_dst;
+    const SurfelSet set = M.s[st->cull_src];
     const uint32_t ntiles = (N + TILE - 1) / TILE;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t vis = 0;
@@ -313,38 +330,77 @@ __global__ __launch_bounds__(256) void k_compact(Model M, DevState *__restrict__
             s_keep[threadIdx.x] = keep;
         }
         __syncthreads();
-        if (threadIdx.x < TILE_WORDS) {
+        if (threadIdx.x <= TILE_WORDS) {
             uint32_t before = 0;
             for (int w = 0; w < (int)threadIdx.x; ++w) before += (uint32_t)__popcll(s_keep[w]);
-            s_kpre[threadIdx.x] = before;
+            s_kpre[threadIdx.x] = before;                 // s_kpre[TILE_WORDS] = survivors of the tile
         }
         __syncthreads();
         const uint32_t base_id = tile_keep_prefix[tile];
+        const uint32_t kcount = s_kpre[TILE_WORDS];
+        const uint32_t nvalid = min((uint32_t)TILE, N - tile * TILE);
+        const bool moving = (base_id != tile * TILE) || (kcount != nvalid);   // block-uniform
+
+        // ---- load phase: every survivor of the tile into registers
+        float4 v[4], nr[4];
+        uint32_t col[4], nid[4];
+        float it[4], tl[4];
+        bool kept[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int w = r * 4 + wave;
             const uint64_t keepw = s_keep[w];
             const uint32_t k = (tile * TILE_WORDS + w) * 64u + lane;
-            const bool kept = (keepw >> lane) & 1ull;
-            bool drew = false;
-            if (kept) {
-                const uint32_t nid = base_id + s_kpre[w] + (uint32_t)__popcll(keepw & ((1ull << lane) - 1ull));
-                float4 v = src.pos_conf[k];
-                const bool dec = (s_ceff[w] >> lane) & 1ull;
-                if (dec) v.w -= 1.0f;                    // conflict.vert:72
-                const float tl = src.time[k];
-                if (!inplace) {
-                    dst.pos_conf[nid] = v;
-                    dst.norm_rad[nid] = src.norm_rad[k];
-                    dst.color[nid] = src.color[k];
-                    dst.init_time[nid] = src.init_time[k];
-                    dst.time[nid] = tl;
-                } else if (dec) {
-                    src.pos_conf[k].w = v.w;
+            kept[r] = (keepw >> lane) & 1ull;
+            nid[r] = base_id + s_kpre[w] + (uint32_t)__popcll(keepw & ((1ull << lane) - 1ull));
+            v[r] = make_float4(0.f, 0.f, 0.f, 0.f); nr[r] = v[r]; col[r] = 0; it[r] = 0.f; tl[r] = 0.f;
+            if (kept[r]) {
+                v[r] = set.pos_conf[k];
+                tl[r] = set.time[k];
+                if (moving) { nr[r] = set.norm_rad[k]; col[r] = set.color[k]; it[r] = set.init_time[k]; }
+                if ((s_ceff[w] >> lane) & 1ull) {
+                    v[r].w -= 1.0f;                       // conflict.vert:72
+                    if (!moving) set.pos_conf[k].w = v[r].w;
                 }
-                if (SPLAT) drew = splat_one(fp, v.x, v.y, v.z, tl, nid, keyT);
             }
-            if (SPLAT) vis += (uint32_t)__popcll(__ballot(drew));
+        }
+        if (moving) {
+            // all loads of this workgroup have returned before the flag goes out
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                __hip_atomic_exchange(&tile_flag[tile], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (kcount && base_id != tile * TILE) {
+                    const uint32_t first = base_id / TILE;
+                    const uint32_t last = min(tile - 1u, (base_id + kcount - 1u) / TILE);
+                    for (uint32_t t = first; t <= last; ++t) {
+                        uint32_t spins = 0;
+                        while (__hip_atomic_load(&tile_flag[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
+                            __builtin_amdgcn_s_sleep(2);
+                            if (++spins > (1u << 24)) { st->error = -6; break; }   // SM_E_STALL: never hang the GPU
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (kept[r]) {
+                    set.pos_conf[nid[r]] = v[r];
+                    set.norm_rad[nid[r]] = nr[r];
+                    set.color[nid[r]] = col[r];
+                    set.init_time[nid[r]] = it[r];
+                    set.time[nid[r]] = tl[r];
+                }
+            }
+        }
+        if (SPLAT) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                bool drew = false;
+                if (kept[r]) drew = splat_one(fp, v[r].x, v[r].y, v[r].z, tl[r], nid[r], keyT);
+                vis += (uint32_t)__popcll(__ballot(drew));
+            }
         }
         __syncthreads();
     }
@@ -565,7 +621,7 @@ __global__ __launch_bounds__(1024) void k_scan_new(DevState *__restrict__ st, Fr
             FrameLog e;
             e.tick = (uint32_t)fp.time; e.n_before = st->cull_n; e.n_after_cull = st->offset; e.n_kill = st->n_kill;
             e.conflict_count = st->conflict_count; e.visible_count = st->visible_count;
-            e.fused_count = ftot; e.unstable_count = ntot;
+            e.fused_count = ftot; e.unstable_count = ntot; e.n_static = st->n_static; e.pad = 0;
             log[st->frames_logged % FRAME_LOG_LEN] = e;
             st->frames_logged = st->frames_logged + 1;
         }
