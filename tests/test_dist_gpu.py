@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 SCRIPT = textwrap.dedent("""
     import os, sys
-    sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+    sys.path.insert(0, "__ROOT__"); sys.path.insert(0, os.path.join("__ROOT__", "tests"))
     ORDER = sys.argv[1]
     if ORDER == "torch_first":
         import torch, torch.distributed as dist
@@ -41,7 +41,7 @@ SCRIPT = textwrap.dedent("""
     assert np.array_equal(g.view(np.uint32), local.view(np.uint32))
     dist.destroy_process_group()
     print("DIST_GPU_OK", ORDER, total)
-""") % (ROOT, ROOT)
+""").replace("__ROOT__", ROOT)
 
 
 @pytest.mark.gpu
