@@ -84,6 +84,34 @@ void invert4(const float *m, float *out)
     for (int i = 0; i < 16; ++i) out[i] = a[i] * rdet;
 }
 
+
+// column-major 4x4 product, c_ij = ((a_i0 b_0j + a_i1 b_1j) + a_i2 b_2j) + a_i3 b_3j
+void mul4(const float *a, const float *b, float *out)
+{
+    float r[16];
+    for (int j = 0; j < 4; ++j)
+        for (int i = 0; i < 4; ++i)
+            r[j * 4 + i] = ((a[i] * b[j * 4] + a[4 + i] * b[j * 4 + 1]) + a[8 + i] * b[j * 4 + 2]) + a[12 + i] * b[j * 4 + 3];
+    memcpy(out, r, sizeof r);
+}
+
+// exp of DESIGN.md "Arithmetic": k = rint(x*log2e); r = (x - k*ln2hi) - k*ln2lo; degree-6 Horner; ldexp
+float exp_spec(float x)
+{
+    const float LOG2E = 1.44269502162933349609375f;
+    const float LN2HI = 0.693145751953125f, LN2LO = 1.428606765330187045037746429443359375e-06f;
+    const float k = rintf(x * LOG2E);
+    const float r = (x - k * LN2HI) - k * LN2LO;
+    float p = 1.0f / 720.0f;
+    p = 1.0f / 120.0f + r * p;
+    p = 1.0f / 24.0f + r * p;
+    p = 1.0f / 6.0f + r * p;
+    p = 0.5f + r * p;
+    p = 1.0f + r * p;
+    p = 1.0f + r * p;
+    return ldexpf(p, (int)k);
+}
+
 }  // namespace
 
 struct sm_ctx {
@@ -102,7 +130,7 @@ struct sm_ctx {
     uint8_t *d_rgb = nullptr, *d_sem = nullptr;
     uint16_t *d_depth_raw = nullptr;
     float *d_depth_f32 = nullptr;
-    float *d_xs = nullptr, *d_ys = nullptr;
+    float *d_xs = nullptr, *d_ys = nullptr, *d_wtab = nullptr;
     // cull scratch
     uint64_t *d_cm = nullptr, *d_dm = nullptr, *d_zm = nullptr;
     uint32_t *d_tile_cnt = nullptr, *d_tile_allow = nullptr, *d_tile_keep = nullptr, *d_tile_flag = nullptr;
@@ -306,16 +334,34 @@ int enqueue_frame(sm_ctx *s, const uint8_t *d_rgb, const uint16_t *d_raw, const 
     if ((rc = mark(s, 0, fusing))) return rc;
     // metriciseDepth (+ filterDepth when preprocess=1)   src/SurfelMapping.cpp:136-139
     if ((rc = launch_prep(s, d_rgb, d_raw, d_sem, nullptr, fp, true))) return rc;
-    if ((rc = mark(s, 1, fusing))) return rc;
-    if (s->cfg.preprocess) { g_err = "preprocess=1 (p0b..p0e) not built yet"; return SM_E_UNSUPPORTED; }
+    const int pblocks = (s->P + 255) / 256;
+    if (s->cfg.preprocess) {                              // filterDepth src/SurfelMapping.cpp:269-334
+        const int stiles = ((s->W + 31) / 32) * ((s->H + 31) / 32);
+        const int border = (int)std::ceil(s->cfg.stereo_border - 0.5f);
+        hipLaunchKernelGGL(k_filter_depth, dim3(pblocks), dim3(256), 0, s->stream, s->d_depthT, s->d_rgbsT, s->d_filteredT, fp, 0.15f);
+        hipLaunchKernelGGL(k_smooth_depth, dim3(stiles), dim3(1024), 0, s->stream, s->d_filteredT, s->d_rgbsT, s->d_depthT, fp, s->d_wtab, border);
+        hipLaunchKernelGGL(k_filter_depth, dim3(pblocks), dim3(256), 0, s->stream, s->d_depthT, s->d_rgbsT, s->d_filteredT, fp, 0.1f);
+        HIPCK(hipGetLastError());
+    }
     // preprocess == 0: DEPTH_FILTERED and LAST are the metric depth itself (nothing reads them on the
     // hot path); they alias d_depthT in sm_download_depth instead of being copied every frame.
     if (!s->ref_set) {                                    // src/SurfelMapping.cpp:142-154
+        if (s->cfg.preprocess) std::swap(s->d_lastT, s->d_filteredT);   // LAST <- DEPTH_FILTERED without a copy
         memcpy(s->last_pose, s->curr_pose, 64);
         s->ref_set = true;
         s->tick++;
         return SM_OK;
     }
+    if (s->cfg.preprocess) {                              // removeMovings src/SurfelMapping.cpp:156,336-365
+        Mat4 t_c2l;
+        float linv[16];
+        invert4(s->last_pose, linv);
+        mul4(linv, s->curr_pose, t_c2l.m);
+        hipLaunchKernelGGL(k_remove_movings, dim3(pblocks), dim3(256), 0, s->stream, s->d_filteredT, s->d_rgbsT, s->d_lastT,
+                           s->d_depthT, fp, t_c2l);
+        HIPCK(hipGetLastError());
+    }
+    if ((rc = mark(s, 1, fusing))) return rc;
     if (s->tick == 0) {                                   // src/SurfelMapping.cpp:161-169 (after reset())
         g_err = "tick==0 re-initialisation from the raw feedback cloud is not built yet";
         return SM_E_UNSUPPORTED;
@@ -326,7 +372,8 @@ int enqueue_frame(sm_ctx *s, const uint8_t *d_rgb, const uint16_t *d_raw, const 
     if ((rc = launch_compact(s, fp, true, true))) return rc;   // :189-197 (cull + mirror + index map)
     if ((rc = launch_associate(s, fp, true))) return rc;   // :212-239
     bump_bound(s);
-    memcpy(s->last_pose, s->curr_pose, 64);               // :244-245 (LAST aliases the metric depth when preprocess == 0)
+    if (s->cfg.preprocess) std::swap(s->d_lastT, s->d_filteredT);   // :244 LAST <- DEPTH_FILTERED without a copy
+    memcpy(s->last_pose, s->curr_pose, 64);               // :245 (LAST aliases the metric depth when preprocess == 0)
     if (s->ev_ok) s->ev_frames++;
     s->tick++;
     return SM_OK;
@@ -408,7 +455,7 @@ sm_ctx *sm_create(const sm_config *c)
     ok = ok && dalloc(&s->d_rgbsT, P) == SM_OK && dalloc(&s->d_keyT, P) == SM_OK;
     ok = ok && dalloc(&s->d_rgb, P * 3) == SM_OK && dalloc(&s->d_sem, P) == SM_OK && dalloc(&s->d_depth_raw, P) == SM_OK;
     ok = ok && dalloc(&s->d_depth_f32, P) == SM_OK;
-    ok = ok && dalloc(&s->d_xs, (size_t)s->W) == SM_OK && dalloc(&s->d_ys, (size_t)s->H) == SM_OK;
+    ok = ok && dalloc(&s->d_xs, (size_t)s->W) == SM_OK && dalloc(&s->d_ys, (size_t)s->H) == SM_OK && dalloc(&s->d_wtab, (size_t)169) == SM_OK;
     ok = ok && dalloc(&s->d_cm, nwords) == SM_OK && dalloc(&s->d_dm, nwords) == SM_OK && dalloc(&s->d_zm, nwords) == SM_OK;
     ok = ok && dalloc(&s->d_tile_cnt, ntiles * 3) == SM_OK && dalloc(&s->d_tile_allow, ntiles) == SM_OK &&
          dalloc(&s->d_tile_keep, ntiles) == SM_OK && dalloc(&s->d_tile_flag, ntiles) == SM_OK &&
@@ -445,8 +492,18 @@ sm_ctx *sm_create(const sm_config *c)
     }
     for (int i = 0; i < s->W; ++i) odd += (uint32_t)((s->H + ((i & 1) ? 1 : 0)) / 2);
     s->n_odd_pixels = odd;
+    // depth_smooth.frag weights: the host passes 0.5/30^2 as "sigPix" (src/SurfelMapping.cpp:292-309)
+    float wtab[169];
+    {
+        const float sigma_intensity = 30.0f;
+        const float sigPix = 0.5f / (sigma_intensity * sigma_intensity);
+        for (int iy = -6; iy <= 6; ++iy)
+            for (int ix = -6; ix <= 6; ++ix)
+                wtab[(iy + 6) * 13 + (ix + 6)] = exp_spec(-((float)(ix * ix + iy * iy) * sigPix));
+    }
     memset(s->h_state, 0, sizeof(DevState));
-    ok = hipMemcpy(s->d_xs, xs.data(), xs.size() * 4, hipMemcpyHostToDevice) == hipSuccess &&
+    ok = hipMemcpy(s->d_wtab, wtab, sizeof wtab, hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(s->d_xs, xs.data(), xs.size() * 4, hipMemcpyHostToDevice) == hipSuccess &&
          hipMemcpy(s->d_ys, ys.data(), ys.size() * 4, hipMemcpyHostToDevice) == hipSuccess &&
          hipMemcpy(s->d_state, s->h_state, sizeof(DevState), hipMemcpyHostToDevice) == hipSuccess &&
          hipMemset(s->d_depthT, 0, P * 4) == hipSuccess && hipMemset(s->d_filteredT, 0, P * 4) == hipSuccess &&
@@ -488,7 +545,7 @@ void sm_destroy(sm_ctx *s)
     (void)hipFree(s->d_depthT); (void)hipFree(s->d_filteredT); (void)hipFree(s->d_lastT);
     (void)hipFree(s->d_rgbsT); (void)hipFree(s->d_keyT);
     (void)hipFree(s->d_rgb); (void)hipFree(s->d_sem); (void)hipFree(s->d_depth_raw); (void)hipFree(s->d_depth_f32);
-    (void)hipFree(s->d_xs); (void)hipFree(s->d_ys);
+    (void)hipFree(s->d_xs); (void)hipFree(s->d_ys); (void)hipFree(s->d_wtab);
     (void)hipFree(s->d_cm); (void)hipFree(s->d_dm); (void)hipFree(s->d_zm);
     (void)hipFree(s->d_tile_cnt); (void)hipFree(s->d_tile_allow); (void)hipFree(s->d_tile_keep); (void)hipFree(s->d_tile_flag);
     (void)hipFree(s->d_newmask); (void)hipFree(s->d_blk_new); (void)hipFree(s->d_blk_fused); (void)hipFree(s->d_blk_prefix);
@@ -678,7 +735,9 @@ int sm_download_depth(sm_ctx *s, int which, float *dst)
     if (!s || !dst) return SM_E_ARG;
     HIPCK(hipSetDevice(s->cfg.device));
     const bool alias = s->cfg.preprocess == 0;
-    const float *src = which == SM_TEX_DEPTH_METRIC ? s->d_depthT : which == SM_TEX_DEPTH_FILTERED ? (alias ? s->d_depthT : s->d_filteredT)
+    // preprocess == 1: after every processFrame LAST == DEPTH_FILTERED (src/SurfelMapping.cpp:244); the two
+    // buffers are swapped instead of copied, so both names read d_lastT.
+    const float *src = which == SM_TEX_DEPTH_METRIC ? s->d_depthT : which == SM_TEX_DEPTH_FILTERED ? (alias ? s->d_depthT : s->d_lastT)
                      : which == SM_TEX_LAST ? (alias ? s->d_depthT : s->d_lastT) : nullptr;
     if (!src) return SM_E_ARG;
     int rc = ensure_export(s, (size_t)s->P * 4);

@@ -68,6 +68,132 @@ __global__ __launch_bounds__(1024) void k_prep(const uint8_t *__restrict__ rgb,
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// p0b / p0d  depth_filter.frag:16-80 (host src/SurfelMapping.cpp:271-288,316-332): drop classes
+// 10/11/12, keep a pixel iff >= 7 of its in-image 8-neighbours have the same class and
+// |dz| < diffThresh.  Column-major images, one pixel per thread.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_filter_depth(const float *__restrict__ inT, const uint32_t *__restrict__ rgbsT,
+                                                      float *__restrict__ outT, FrameParams fp, float diff_thresh)
+{
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= fp.P) return;
+    const int H = fp.H, W = fp.W;
+    const int i = q / H, j = q - i * H;
+    const float depth = inT[q];
+    const uint32_t cl = rgbsT[q] >> 24;
+    float r = 0.0f;
+    if (!(depth <= fp.min_depth || depth >= 100.0f || cl == 10u || cl == 11u || cl == 12u)) {
+        int support = 0;
+#pragma unroll
+        for (int iy = -1; iy <= 1; ++iy)
+#pragma unroll
+            for (int ix = -1; ix <= 1; ++ix) {
+                if (iy == 0 && ix == 0) continue;
+                const int qi = i + ix, qj = j + iy;
+                if (qi < 0 || qi >= W || qj < 0 || qj >= H) continue;   // texX<0||texX>1 (depth_filter.frag:52)
+                const int qq = qi * H + qj;
+                if (fabsf(inT[qq] - depth) < diff_thresh && cl == (rgbsT[qq] >> 24)) support++;
+            }
+        if (support >= 7) r = depth;
+    }
+    outT[q] = r;
+}
+
+// ---------------------------------------------------------------------------------------------
+// p0c  depth_smooth.frag:17-82 (host src/SurfelMapping.cpp:291-313): 13x13 class-aware weighted
+// mean.  The weights exp(-(ix^2+iy^2)*sigPix) come precomputed from the host (169 floats, the
+// fixed exp of DESIGN.md "Arithmetic"); the accumulation order is the shader's: iy outer, ix inner.
+// 32x32-pixel tile per 1024-thread workgroup, (depth, class) staged with a 6-pixel halo in LDS.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_smooth_depth(const float *__restrict__ inT, const uint32_t *__restrict__ rgbsT,
+                                                       float *__restrict__ outT, FrameParams fp,
+                                                       const float *__restrict__ wtab, int border)
+{
+    constexpr int R = 6, TS = 32, HS = TS + 2 * R;       // 44
+    __shared__ float s_d[HS][HS + 1];
+    __shared__ uint8_t s_c[HS][HS + 4];
+    __shared__ float s_w[13 * 13];
+    const int H = fp.H, W = fp.W;
+    const int tiles_j = (H + TS - 1) / TS;
+    const int j0 = (blockIdx.x % tiles_j) * TS, i0 = (blockIdx.x / tiles_j) * TS;
+    const int tj = threadIdx.x & 31, ti = threadIdx.x >> 5;
+    if (threadIdx.x < 169) s_w[threadIdx.x] = wtab[threadIdx.x];
+    for (int e = threadIdx.x; e < HS * HS; e += 1024) {
+        const int li = e / HS, lj = e - li * HS;
+        const int gi = i0 + li - R, gj = j0 + lj - R;
+        float d = 0.0f;
+        uint32_t c = 255u;
+        if (gi >= 0 && gi < W && gj >= 0 && gj < H) {
+            const int qq = gi * H + gj;
+            d = inT[qq];
+            c = rgbsT[qq] >> 24;
+        }
+        s_d[li][lj] = d;
+        s_c[li][lj] = (uint8_t)c;
+    }
+    __syncthreads();
+    const int i = i0 + ti, j = j0 + tj;
+    if (i >= W || j >= H) return;
+    const float depth = s_d[ti + R][tj + R];
+    const uint32_t cl = s_c[ti + R][tj + R];
+    float r = 0.0f;
+    if (!(depth <= fp.min_depth || depth >= 100.0f || cl == 10u)) {
+        float sum1 = 0.0f, sum2 = 0.0f;
+        int valid = 0;
+        for (int iy = -R; iy <= R; ++iy) {
+            const int qj = j + iy;
+            if (qj < 0 || qj >= H) continue;
+#pragma unroll
+            for (int ix = -R; ix <= R; ++ix) {
+                const int qi = i + ix;
+                if (qi < border || qi >= W) continue;            // texX < stereoBorder/cols || texX > 1
+                const float dk = s_d[ti + R + ix][tj + R + iy];
+                if (dk <= fp.min_depth || dk >= 100.0f || cl != (uint32_t)s_c[ti + R + ix][tj + R + iy]) continue;
+                const float w = s_w[(iy + R) * 13 + (ix + R)];
+                sum1 += dk * w;
+                sum2 += w;
+                valid++;
+            }
+        }
+        if (valid > 0) r = sum1 / sum2;
+    }
+    outT[i * H + j] = r;
+}
+
+// ---------------------------------------------------------------------------------------------
+// p0e  depth_movings.frag:20-82 (host src/SurfelMapping.cpp:336-365): pixels of movable classes
+// (13..18) are reprojected into the previous frame and zeroed if |z_hat - z_last| > 0.5 m.
+// ---------------------------------------------------------------------------------------------
+struct Mat4 { float m[16]; };
+
+__global__ __launch_bounds__(256) void k_remove_movings(const float *__restrict__ inT, const uint32_t *__restrict__ rgbsT,
+                                                        const float *__restrict__ lastT, float *__restrict__ outT,
+                                                        FrameParams fp, Mat4 t_c2l)
+{
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= fp.P) return;
+    const int H = fp.H;
+    const int i = q / H, j = q - i * H;
+    const float depth = inT[q];
+    const uint32_t cl = rgbsT[q] >> 24;
+    float r = depth;
+    const float px = (float)i + 0.5f, py = (float)j + 0.5f;
+    if (!(px < fp.stereo_border || depth <= fp.min_depth) && (cl >= 13u && cl <= 18u)) {
+        const float vx = (px - fp.cx) * depth / fp.fx, vy = (py - fp.cy) * depth / fp.fy;
+        const float3 t = xform3(t_c2l.m, vx, vy, depth);
+        const float ux = fp.fx * t.x / t.z + fp.cx;
+        const float uy = fp.fy * t.y / t.z + fp.cy;
+        const float uz = t.z;
+        if (!(uz <= fp.min_depth || uz >= 100.0f || ux < fp.stereo_border || ux > fp.cols || uy < 0.0f || uy > fp.rows)) {
+            const int qi = tex_idx(ux / fp.cols, fp.W), qj = tex_idx(uy / fp.rows, fp.H);
+            const float depth_last = lastT[qi * H + qj];
+            if (fabsf(uz - depth_last) > 0.5f) r = 0.0f;
+        }
+    }
+    outT[q] = r;
+}
+
 // column-major -> row-major read-back helper (tests / GUI textures)
 __global__ void k_untranspose_f32(const float *__restrict__ srcT, float *__restrict__ dst, int W, int H)
 {

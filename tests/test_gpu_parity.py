@@ -209,3 +209,48 @@ def test_seeded_two_million_surfels_hd():
         check(o, h, f"hd frame {k}", model=(k == 1))
     c = h.counts()
     assert c["conflict_count"] > 1000 and c["visible_count"] > 10000
+
+
+# ---------------------------------------------------------------- pre-processing chain p0a..p0e
+def moving_boxes_sequence(cam, n, seed, noise_mm=3.0, box_speed=1.5):
+    """Frames in which the car-sized boxes drive away from the camera (exercises removeMovings)."""
+    out = []
+    poses = synth.kitti_trajectory(n)
+    for k, p in enumerate(poses):
+        sc = synth.Scene(seed, n_boxes=10, length=40.0)
+        sc.boxes[:, [2, 5]] += box_speed * k
+        rgb, d, s = sc.render(synth.Camera(**cam), p, noise_mm=noise_mm, noise_seed=seed * 1000 + k)
+        out.append((rgb, d, s, synth.pose_to_colmajor(p)))
+    return out
+
+
+def check_depth_textures(o, h, what):
+    for which, name in ((0, "DEPTH_METRIC"), (1, "DEPTH_FILTERED"), (2, "LAST")):
+        a, b = o.download_depth(which), h.download_depth(which)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"{what}: {name} differs in {(a != b).sum()} pixels"
+
+
+def test_preprocess_chain_small():
+    cam = dict(width=320, height=120, fx=180.0, fy=180.0, cx=159.5, cy=59.5)
+    seq = moving_boxes_sequence(cam, 6, seed=31)
+    o, h = pair(cam, preprocess=1, stereo_border=20.0, max_sqrt_vertices=600)
+    removed = 0
+    for k, fr in enumerate(seq):
+        o.process_frame(*fr); h.process_frame(*fr)
+        check_depth_textures(o, h, f"frame {k}")
+        check(o, h, f"frame {k}")
+        if k:
+            removed += int(((o.download_depth(1) > 0) & (o.download_depth(0) == 0)).sum())
+    assert removed > 0, "removeMovings never fired: the test does not exercise p0e"
+    assert o.counts()["count"] > 5000
+
+
+def test_preprocess_chain_kitti_size():
+    cam = synth.KITTI
+    seq = moving_boxes_sequence(cam, 4, seed=32, noise_mm=8.0)
+    o, h = pair(cam, preprocess=1, max_sqrt_vertices=2000)
+    for k, fr in enumerate(seq):
+        o.process_frame(*fr); h.process_frame(*fr)
+        check_depth_textures(o, h, f"frame {k}")
+    check(o, h, "kitti preprocess")
+    assert o.counts()["count"] > 100000

@@ -354,3 +354,57 @@ def test_frame_invariants_moving_camera(backend):
         np.testing.assert_allclose(nn, 1.0, atol=1e-6)
         prev = c["count"]
     assert prev > 0
+
+
+# ---------------------------------------------------------------- pre-processing known answers (oracle)
+def test_filter_depth_support_rule():
+    """depth_filter.frag:16-80: keep iff >= 7 of the 8 neighbours agree (class and |dz| < thr)."""
+    cfg = cfg_small(W=8, H=8)
+    d = np.full((8, 8), 5.0, np.float32)
+    sem = np.zeros((8, 8), np.uint8)
+    out = ol.filter_depth(cfg, d, sem, 0.15)
+    assert np.all(out[1:-1, 1:-1] == 5.0) and np.all(out[0, :] == 0) and np.all(out[:, 0] == 0)   # borders: < 7 in-image
+    d2 = d.copy(); d2[3, 3] = 5.2                     # outlier: kills itself, neighbours keep 7 of 8
+    out = ol.filter_depth(cfg, d2, sem, 0.15)
+    assert out[3, 3] == 0 and out[3, 4] == 5.0
+    d3 = d.copy(); d3[3, 3] = 5.2; d3[3, 5] = 5.2     # (3,4) now has 2 disagreeing neighbours
+    out = ol.filter_depth(cfg, d3, sem, 0.15)
+    assert out[3, 4] == 0
+    sem2 = sem.copy(); sem2[4, 4] = 11                 # person class is dropped
+    assert ol.filter_depth(cfg, d, sem2, 0.15)[4, 4] == 0
+
+
+def test_smooth_depth_constant_plane_and_weights():
+    """depth_smooth.frag:17-82: a constant plane stays constant; a step within one class is averaged
+    with weights exp(-(dx^2+dy^2) * 0.5/30^2) (the sigPix quirk, src/SurfelMapping.cpp:309)."""
+    cfg = cfg_small(W=40, H=40)
+    d = np.full((40, 40), 7.0, np.float32)
+    sem = np.zeros((40, 40), np.uint8)
+    out = ol.smooth_depth(cfg, d, sem)
+    np.testing.assert_allclose(out, 7.0, rtol=2e-6)
+    d[:, 20:] = 8.0
+    out = ol.smooth_depth(cfg, d, sem)
+    ix = np.arange(-6, 7)
+    w = np.exp(-(ix[None, :] ** 2 + ix[:, None] ** 2) * (0.5 / 900.0))
+    vals = np.where((20 + ix)[None, :] >= 20, 8.0, 7.0) * np.ones((13, 1))
+    want = (w * vals).sum() / w.sum()
+    assert abs(out[20, 20] - want) < 1e-5
+    sem[:, 20:] = 2                                    # different classes do not mix
+    out = ol.smooth_depth(cfg, d, sem)
+    np.testing.assert_allclose(out[20, 19], 7.0, rtol=2e-6)
+    np.testing.assert_allclose(out[20, 20], 8.0, rtol=2e-6)
+
+
+def test_remove_movings_rule():
+    """depth_movings.frag:30-82: class 13..18 pixels whose reprojected depth disagrees with LAST by > 0.5 m -> 0."""
+    cfg = cfg_small(W=32, H=24)
+    d = np.full((24, 32), 6.0, np.float32)
+    last = np.full((24, 32), 6.0, np.float32)
+    sem = np.zeros((24, 32), np.uint8); sem[8:16, 8:16] = 13
+    out = ol.remove_movings(cfg, d, sem, last, IDENT)
+    assert np.array_equal(out, d)
+    last2 = last.copy(); last2[8:16, 8:16] = 7.0
+    out = ol.remove_movings(cfg, d, sem, last2, IDENT)
+    assert np.all(out[8:16, 8:16] == 0) and out[0, 0] == 6.0
+    sem[:] = 0                                         # static classes are never removed
+    assert np.array_equal(ol.remove_movings(cfg, d, sem, last2, IDENT), d)
