@@ -86,6 +86,8 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workers", type=int, default=0, help="frame-generation processes (0 = auto; use 1 under rocprofv3)")
+    ap.add_argument("--no-events", action="store_true", help="no HIP events inside frames (no per-kernel timings / roofline)")
+    ap.add_argument("--preprocess", type=int, default=0, help="1: run the full depth pre-processing chain p0a..p0e per frame")
     ap.add_argument("--force-dist", action="store_true", help="rehearse the multi-GPU code path with WORLD_SIZE=1")
     ap.add_argument("--sync-every-frame", action="store_true",
                     help="reference semantics: host waits for the counters after every frame")
@@ -118,8 +120,12 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from surfelmapping_amd import capi
-    cfg = capi.make_config(**cam, preprocess=0, device=local_rank, enable_timing=1)
-    sm = capi.SurfelMap(cfg)                      # raises without a GPU: no CPU fallback
+    mk = lambda timing: capi.SurfelMap(capi.make_config(**cam, preprocess=args.preprocess, device=local_rank,
+                                                        enable_timing=timing))
+    sm = mk(0)                                    # raises without a GPU: no CPU fallback
+    # second context: the same frames again with HIP events between the kernels (the events cost
+    # ~25 us per frame, so they stay out of the run that produces `value`)
+    sm_ev = None if args.no_events else mk(1)
 
     # ---- stage every frame in HBM
     dptr = []
@@ -128,11 +134,11 @@ def main():
         sm.device_upload(dr, rgb); sm.device_upload(dd, depth); sm.device_upload(ds, sem)
         dptr.append((dr, dd, ds, pose))
 
-    def run(lo, hi):
+    def run(ctx, lo, hi):
         for k in range(lo, hi):
-            sm.process_frame_device(*dptr[k])
+            ctx.process_frame_device(*dptr[k])
             if args.sync_every_frame:
-                sm.sync()
+                ctx.sync()
 
     sm_global = None
     if dist:
@@ -147,12 +153,11 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    run(0, Wm)
+    run(sm, 0, Wm)
     sm.sync()
-    sm.timings()                                  # drop warm-up samples
     barrier()
     t0 = time.perf_counter()
-    run(Wm, Wm + K)
+    run(sm, Wm, Wm + K)
     sm.sync()
     global_count = None
     if dist:                                      # the exchange step: all-gather into a single GlobalModel
@@ -160,9 +165,19 @@ def main():
         global_count = smd.build_global_model(sm_global, gathered, gcounts)
     barrier()
     elapsed = time.perf_counter() - t0
-    tim = sm.timings()
     log = sm.read_frame_log(K)
     counts = sm.counts()
+
+    # ---- the same K frames on the instrumented context: per-kernel durations for the roofline
+    tim = {k: 0.0 for k in ("k_prep", "k_conflict", "k_scan_cull", "k_compact", "k_associate", "k_scan_new", "k_append", "run")}
+    if sm_ev is not None:
+        run(sm_ev, 0, Wm)
+        sm_ev.sync()
+        sm_ev.timings()                           # drop warm-up samples
+        run(sm_ev, Wm, Wm + K)
+        sm_ev.sync()
+        tim = sm_ev.timings()
+        assert sm_ev.counts()["count"] == counts["count"], "instrumented pass diverged from the timed pass"
 
     if dist:
         dev = torch.device("cuda", local_rank)
@@ -200,7 +215,7 @@ def main():
     cpu = None
     if not args.no_cpu_baseline and dist is None:
         import oracle_lib as ol                  # checker / baseline only
-        o = ol.Oracle(ol.make_config(**cam, preprocess=0))
+        o = ol.Oracle(ol.make_config(**cam, preprocess=args.preprocess))
         for k in range(Wm):
             o.process_frame(*frames[k])
         c0 = time.perf_counter()
@@ -227,7 +242,8 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": "BASELINE configs[1]: KITTI 1242x375 synthetic street sequence, 0.8 m/frame, "
-                               f"depth noise {args.noise_mm} mm, metricise+conflict+cull+splat+associate+fuse+append per frame",
+                               f"depth noise {args.noise_mm} mm, metricise+conflict+cull+splat+associate+fuse+append per frame"
+                               + (" + depth pre-processing p0b..p0e" if args.preprocess else ""),
                    "frames": f"{Wm}..{Wm + K - 1}", "multi_gpu": (f"{world}-camera rig, one stream per GPU, RCCL all-gather into a single GlobalModel of "
                                  f"{global_count} surfels inside the timed region") if dist else "single stream",
                    "host_sync": "per frame" if args.sync_every_frame else "none inside the timed region",

@@ -259,7 +259,7 @@ int take_error(sm_ctx *s)
 int launch_prep(sm_ctx *s, const uint8_t *rgb, const uint16_t *raw, const uint8_t *sem, const float *dm,
                 const FrameParams &fp, bool clear_keys)
 {
-    const int tiles = ((s->W + 63) / 64) * ((s->H + 63) / 64);
+    const int tiles = ((s->W + 31) / 32) * ((s->H + 31) / 32);
     hipLaunchKernelGGL(k_prep, dim3(tiles), dim3(1024), 0, s->stream, rgb, raw, sem, dm, s->d_depthT, s->d_rgbsT,
                        clear_keys ? s->d_keyT : nullptr, fp);
     HIPCK(hipGetLastError());
@@ -760,7 +760,7 @@ int sm_set_frame(sm_ctx *s, const uint8_t *rgb, const float *depth_metric, const
     if (depth_metric) HIPCK(hipMemcpyAsync(s->d_depth_f32, depth_metric, (size_t)s->P * 4, hipMemcpyHostToDevice, s->stream));
     FrameParams fp = make_params(s, s->curr_pose);
     // re-pack every plane from the staged inputs; depth only when given (else keep depthT)
-    const int tiles = ((s->W + 63) / 64) * ((s->H + 63) / 64);
+    const int tiles = ((s->W + 31) / 32) * ((s->H + 31) / 32);
     hipLaunchKernelGGL(k_prep, dim3(tiles), dim3(1024), 0, s->stream, s->d_rgb, (const uint16_t *)nullptr, s->d_sem,
                        depth_metric ? s->d_depth_f32 : nullptr, depth_metric ? s->d_depthT : nullptr, s->d_rgbsT,
                        (uint64_t *)nullptr, fp);

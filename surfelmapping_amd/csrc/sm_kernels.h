@@ -13,7 +13,7 @@ namespace sm {
 
 // ---------------------------------------------------------------------------------------------
 // p0a metricise (depth_metric.frag:15-35) + u8 RGB/semantic pack + LDS-tiled transpose to the
-// column-major frame layout + key-map clear.  64x64 pixel tile per 256-thread block.
+// column-major frame layout + key-map clear.  32x32 pixel tile per 1024-thread workgroup.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void k_prep(const uint8_t *__restrict__ rgb,
                                                const uint16_t *__restrict__ depth_raw,
@@ -22,18 +22,14 @@ __global__ __launch_bounds__(1024) void k_prep(const uint8_t *__restrict__ rgb,
                                                float *__restrict__ depthT, uint32_t *__restrict__ rgbsT,
                                                uint64_t *__restrict__ keyT, FrameParams fp)
 {
-    __shared__ float s_d[64][65];
-    __shared__ uint32_t s_c[64][65];
+    __shared__ float s_d[32][33];
+    __shared__ uint32_t s_c[32][33];
     const int W = fp.W, H = fp.H;
-    const int tiles_x = (W + 63) >> 6;
-    const int i0 = (blockIdx.x % tiles_x) << 6, j0 = (blockIdx.x / tiles_x) << 6;
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;      // 16 waves: one image row each per round
-    const uint32_t lo = (uint32_t)(fp.min_depth * 1000.0f);
-    const uint32_t hi = (uint32_t)((fp.max_depth - 0.001f) * 1000.0f);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int jl = ty + 16 * r;
-        const int i = i0 + tx, j = j0 + jl;
+    const int tiles_x = (W + 31) >> 5;
+    const int i0 = (blockIdx.x % tiles_x) << 5, j0 = (blockIdx.x / tiles_x) << 5;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    {
+        const int i = i0 + tx, j = j0 + ty;          // read: lanes along the image row
         float d = 0.0f;
         uint32_t c = 0;
         if (i < W && j < H) {
@@ -41,6 +37,8 @@ __global__ __launch_bounds__(1024) void k_prep(const uint8_t *__restrict__ rgb,
             if (depth_f32) {
                 d = depth_f32[p];
             } else if (depth_raw) {
+                const uint32_t lo = (uint32_t)(fp.min_depth * 1000.0f);
+                const uint32_t hi = (uint32_t)((fp.max_depth - 0.001f) * 1000.0f);
                 const uint32_t v = depth_raw[p];
                 if (!((float)i + 0.5f < fp.stereo_border)) {
                     if (v > lo && v < hi) d = (float)v / 1000.0f;
@@ -51,18 +49,16 @@ __global__ __launch_bounds__(1024) void k_prep(const uint8_t *__restrict__ rgb,
             if (rgb) { cr = rgb[p * 3]; cg = rgb[p * 3 + 1]; cb = rgb[p * 3 + 2]; }
             c = (s << 24) | (cr << 16) | (cg << 8) | cb;
         }
-        s_d[jl][tx] = d;
-        s_c[jl][tx] = c;
+        s_d[ty][tx] = d;
+        s_c[ty][tx] = c;
     }
     __syncthreads();
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int il = ty + 16 * r;
-        const int i = i0 + il, j = j0 + tx;
+    {
+        const int i = i0 + ty, j = j0 + tx;          // write: lanes along the image column
         if (i < W && j < H) {
             const size_t q = (size_t)i * H + j;
-            if (depthT) depthT[q] = s_d[tx][il];
-            if (rgbsT) rgbsT[q] = s_c[tx][il];
+            if (depthT) depthT[q] = s_d[tx][ty];
+            if (rgbsT) rgbsT[q] = s_c[tx][ty];
             if (keyT) keyT[q] = KEY_EMPTY;
         }
     }
@@ -296,12 +292,14 @@ __global__ __launch_bounds__(1024) void k_scan_cull(DevState *__restrict__ st, F
     const uint32_t t0 = min(threadIdx.x * per, ntiles), t1 = min(t0 + per, ntiles);
     // pass 1: conflicts
     uint32_t csum = 0;
+#pragma unroll 8
     for (uint32_t t = t0; t < t1; ++t) csum += tile_cnt[t * 3];
     uint32_t ctotal;
     uint32_t cpre = block_scan_1024(csum, &ctotal, s_scan);
     // pass 2: allowed conflicts + effective kills per tile
     const uint32_t cap = fp.conflict_cap;
     uint32_t ksum = 0;
+#pragma unroll 4
     for (uint32_t t = t0; t < t1; ++t) {
         const uint32_t nconf = tile_cnt[t * 3];
         uint32_t allow = nconf;
@@ -329,6 +327,7 @@ __global__ __launch_bounds__(1024) void k_scan_cull(DevState *__restrict__ st, F
     }
     uint32_t ktotal, nstatic = 0;
     uint32_t kpre = block_scan_1024(ksum, &ktotal, s_scan);
+#pragma unroll 4
     for (uint32_t t = t0; t < t1; ++t) {
         const uint32_t nconf = tile_cnt[t * 3];
         const uint32_t allow = tile_allow[t];
@@ -726,6 +725,7 @@ __global__ __launch_bounds__(1024) void k_scan_new(DevState *__restrict__ st, Fr
     const uint32_t per = (nb + 1023u) / 1024u;
     const uint32_t b0 = min(threadIdx.x * per, nb), b1 = min(b0 + per, nb);
     uint32_t ns = 0, fs = 0;
+#pragma unroll 4
     for (uint32_t b = b0; b < b1; ++b) { ns += blk_new[b]; fs += blk_fused[b]; }
     uint32_t ntot, ftot;
     uint32_t npre = block_scan_1024(ns, &ntot, s_scan);
