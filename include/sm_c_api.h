@@ -182,6 +182,30 @@ int sm_append_model_aos_device(sm_ctx *s, const float *d_src12, uint32_t n);
 /* raw device pointer of the 64-bit depth|id key map (W*H, column-major) for the multi-GPU
  * min-reduction, and the entry points that bracket it */
 void *sm_key_map_device_ptr(sm_ctx *s);
+/* per-pixel "fused by this rank" ballot words (ceil(W*H/64) x u64): sum-reduced over the ranks */
+void *sm_fused_mask_device_ptr(sm_ctx *s, uint32_t *nwords);
+int sm_device_download(sm_ctx *s, void *dst_host, const void *src_device, size_t bytes);
+
+/* ---- ONE camera stream sharded over `world` GPUs (BASELINE configs[3]; DESIGN.md "Multi-GPU").
+ * Surfels created by fusing frame f live on rank f % world as "segment" f; the concatenation of
+ * all segments in frame order is exactly the single-GPU model order.  Per frame every rank calls
+ * the five stages below in lock-step; between them the caller (surfelmapping_amd/sharded.py)
+ * reduces over the ranks: segment survivor counts (sum), the key map (min), the fused mask (sum).
+ * The W*H conflict cap cannot be evaluated per shard and is off in this mode. */
+int sm_shard_configure(sm_ctx *s, int rank, int world);
+/* upload + pre-process (src/SurfelMapping.cpp:115-158); returns 1 if the fusing stages follow, 0 if not */
+int sm_shard_begin_frame(sm_ctx *s, const uint8_t *rgb, const uint16_t *depth_mm,
+                         const uint8_t *semantic, const float *pose16);
+/* p2/p3 on the local slice.  exempt_local: local index of the surfel with global id 0 (or 0xFFFFFFFF);
+ * seg_lstart_old[nseg+1]: local start of every local segment; out: survivors per segment, conflicts */
+int sm_shard_conflict(sm_ctx *s, uint32_t exempt_local, const uint32_t *seg_lstart_old, int nseg,
+                      uint32_t *seg_keep_out, uint32_t *conflict_out);
+/* p4..p6: compaction + splat under GLOBAL ids (seg_gbase[nseg]: global id of each local segment's first surfel) */
+int sm_shard_cull_splat(sm_ctx *s, const uint32_t *seg_lstart_new, const uint32_t *seg_gbase, int nseg);
+/* p8..p10 for the pixels whose (min-reduced) winner this rank owns; gseg_base[n_gseg+1] */
+int sm_shard_associate(sm_ctx *s, const uint32_t *gseg_base, int n_gseg);
+/* p11 on the rank that owns this frame's segment (append_here), counters everywhere; ends the frame */
+int sm_shard_append(sm_ctx *s, int append_here);
 
 #ifdef __cplusplus
 }

@@ -45,6 +45,8 @@ struct smo_ctx {
     int32_t tick;
     int ref_set;
     float curr_pose[16], last_pose[16];
+    int32_t exempt_id;        /* surfel that never fuses / conflicts: id 0 (A5); shard tests move it */
+    int32_t *data_pix;        /* column-major pixel index of every dataVbo record */
 };
 
 /* ------------------------------------------------------------------ scalar helpers */
@@ -280,6 +282,8 @@ smo_ctx *smo_create(const smo_config *c)
     s->conflict = xcalloc(P * 5, 4);
     s->conflict_cap = (uint32_t)P;
     s->idx = xcalloc(P, 4); s->zbuf = xcalloc(P, 4);
+    s->data_pix = xcalloc(P, 4);
+    for (size_t q = 0; q < P; ++q) s->zbuf[q] = 16777215u;
     s->ivc = xcalloc(P * 4, 4); s->ict = xcalloc(P * 4, 4); s->inr = xcalloc(P * 4, 4);
     for (int i = 0; i < 16; ++i) s->curr_pose[i] = s->last_pose[i] = (i % 5 == 0) ? 1.0f : 0.0f;
     return s;
@@ -294,7 +298,7 @@ void smo_destroy(smo_ctx *s)
     free(s->last); free(s->sem);
     free(s->model); free(s->mvc); free(s->mct); free(s->mnr);
     free(s->data); free(s->unstable); free(s->conflict);
-    free(s->idx); free(s->zbuf); free(s->ivc); free(s->ict); free(s->inr);
+    free(s->idx); free(s->zbuf); free(s->data_pix); free(s->ivc); free(s->ict); free(s->inr);
     free(s);
 }
 
@@ -502,7 +506,7 @@ int smo_stage_process_conflict(smo_ctx *s, const float *pose, float min_depth, f
         if (sem == 10u) depth = max_depth + 1.0f;
         if (is_clean == 0 && depth == 0.0f) depth = max_depth + 20.0f;
         if (depth * lambda - ph[2] * lambda > fuse_thresh * ph[2]) {
-            if ((int32_t)k > 0) {                /* conflict.geom:15 */
+            if ((int32_t)k != s->exempt_id) {    /* conflict.geom:15: conf_id > 0, i.e. every id but 0 */
                 if (n < cap) {
                     float *r = s->conflict + (size_t)n * 5;
                     r[0] = u2f(k);
@@ -693,7 +697,10 @@ int smo_stage_data_associate(smo_ctx *s, const float *pose, int time_i, float de
 
             /* window loop data.vert:126-172 with scale == IndexMap::FACTOR == 1: one lookup */
             int currentID = s->idx[p];
-            if (currentID > 0) {
+            /* data.vert:142 `currentID > 0`: a projection exists and it is not surfel 0 (the index
+             * texture is cleared to 0, A5); written via the depth buffer so that shard tests can
+             * move the exempt id */
+            if (s->zbuf[p] != 16777215u && currentID != s->exempt_id) {
                 const float *vertConf = s->ivc + p * 4;
                 const float *colorTime = s->ict + p * 4;
                 uint32_t sc = f2u(colorTime[0]);
@@ -723,6 +730,7 @@ int smo_stage_data_associate(smo_ctx *s, const float *pose, int time_i, float de
             }
 
             float *o = s->data + (size_t)n * SURFEL_F;
+            s->data_pix[n] = i * H + j;
             float t4[4], n3[3];
             if (updateCounter > 0) {
                 nf++;
@@ -834,9 +842,11 @@ static void run_preprocess_pre(smo_ctx *s)
     }
 }
 
-/* SurfelMapping::processFrame src/SurfelMapping.cpp:115-251 */
-int smo_process_frame(smo_ctx *s, const uint8_t *rgb, const uint16_t *depth_mm,
-                      const uint8_t *sem, const float *pose)
+/* First half of SurfelMapping::processFrame (src/SurfelMapping.cpp:115-158): upload, pre-process,
+ * reference-frame early-out.  Returns 1 when the fusing passes must follow, 0 when the call ends
+ * here (first call), negative on error. */
+int smo_begin_frame(smo_ctx *s, const uint8_t *rgb, const uint16_t *depth_mm, const uint8_t *sem,
+                    const float *pose)
 {
     if (!s || !rgb || !pose) return SMO_E_ARG;
     upload_rgb(s, rgb);
@@ -851,7 +861,7 @@ int smo_process_frame(smo_ctx *s, const uint8_t *rgb, const uint16_t *depth_mm,
         memcpy(s->last_pose, s->curr_pose, 64);
         s->ref_set = 1;
         s->tick++;
-        return SMO_OK;
+        return 0;
     }
 
     if (s->c.preprocess) {                               /* removeMovings :156, :336-365 */
@@ -860,29 +870,42 @@ int smo_process_frame(smo_ctx *s, const uint8_t *rgb, const uint16_t *depth_mm,
         smo_mul4(linv, s->curr_pose, t_c2l);
         smo_remove_movings(&s->c, s->depth_filtered, s->sem, s->last, t_c2l, s->depth_metric);
     }
-
-    int rc = SMO_OK;
     if (s->tick == 0) {
         /* reachable only after reset(): GlobalModel::initialize from the raw feedback cloud
          *  -- not restated yet */
         return SMO_E_UNSUPPORTED;
-    } else {
-        float nearc = s->c.near_clip, farc = s->c.far_clip;
-        smo_stage_process_conflict(s, s->curr_pose, nearc, farc, s->c.fuse_thresh, 0); /* :178 */
-        smo_stage_update_conflict(s);                                                   /* :187 */
-        smo_stage_back_mapping(s);                                                      /* :189 */
-        smo_stage_build_model_map(s);                                                   /* :193 */
-        smo_stage_predict_indices(s, s->curr_pose, s->tick, farc, s->c.time_delta);     /* :197 */
-        smo_stage_data_associate(s, s->curr_pose, s->tick, nearc, farc);                /* :212 */
-        smo_stage_update_fuse(s);                                                       /* :227 */
-        smo_stage_back_mapping(s);                                                      /* :229 */
-        rc = smo_stage_concatenate(s);                                                  /* :234 */
-        smo_stage_build_model_map(s);                                                   /* :239 */
     }
+    return 1;
+}
 
+/* Tail of SurfelMapping::processFrame (src/SurfelMapping.cpp:244-248) */
+int smo_end_frame(smo_ctx *s)
+{
+    if (!s) return SMO_E_ARG;
     memcpy(s->last, s->depth_filtered, (size_t)s->P * 4);  /* :244 */
     memcpy(s->last_pose, s->curr_pose, 64);
     s->tick++;
+    return SMO_OK;
+}
+
+/* SurfelMapping::processFrame src/SurfelMapping.cpp:115-251 */
+int smo_process_frame(smo_ctx *s, const uint8_t *rgb, const uint16_t *depth_mm,
+                      const uint8_t *sem, const float *pose)
+{
+    int go = smo_begin_frame(s, rgb, depth_mm, sem, pose);
+    if (go <= 0) return go;
+    float nearc = s->c.near_clip, farc = s->c.far_clip;
+    smo_stage_process_conflict(s, s->curr_pose, nearc, farc, s->c.fuse_thresh, 0); /* :178 */
+    smo_stage_update_conflict(s);                                                   /* :187 */
+    smo_stage_back_mapping(s);                                                      /* :189 */
+    smo_stage_build_model_map(s);                                                   /* :193 */
+    smo_stage_predict_indices(s, s->curr_pose, s->tick, farc, s->c.time_delta);     /* :197 */
+    smo_stage_data_associate(s, s->curr_pose, s->tick, nearc, farc);                /* :212 */
+    smo_stage_update_fuse(s);                                                       /* :227 */
+    smo_stage_back_mapping(s);                                                      /* :229 */
+    int rc = smo_stage_concatenate(s);                                              /* :234 */
+    smo_stage_build_model_map(s);                                                   /* :239 */
+    smo_end_frame(s);
     return rc;
 }
 
@@ -987,5 +1010,61 @@ int smo_set_tick(smo_ctx *s, int32_t tick)
     if (!s) return SMO_E_ARG;
     s->tick = tick;
     s->ref_set = 1;
+    return SMO_OK;
+}
+
+/* ---- helpers for the multi-GPU shard tests (tests/test_sharded.py): one oracle instance plays
+ * one rank; the test moves the exempt id, exchanges the index map and filters dataVbo ---- */
+int smo_set_exempt_id(smo_ctx *s, int32_t id)
+{
+    if (!s) return SMO_E_ARG;
+    s->exempt_id = id;
+    return SMO_OK;
+}
+
+int smo_download_zbuf(const smo_ctx *s, uint32_t *dst)
+{
+    if (!s || !dst) return SMO_E_ARG;
+    memcpy(dst, s->zbuf, (size_t)s->P * 4);
+    return SMO_OK;
+}
+
+/* replace the ids / "has a projection" state of the index map (attributes stay as splatted) */
+int smo_upload_index_ids(smo_ctx *s, const int32_t *idx, const uint8_t *has)
+{
+    if (!s || !idx || !has) return SMO_E_ARG;
+    for (int p = 0; p < s->P; ++p) {
+        s->idx[p] = idx[p];
+        s->zbuf[p] = has[p] ? 0u : 16777215u;
+    }
+    return SMO_OK;
+}
+
+int smo_download_data_pixels(const smo_ctx *s, int32_t *dst, uint32_t cap, uint32_t *n)
+{
+    if (!s || !n) return SMO_E_ARG;
+    *n = s->data_count;
+    if (!dst) return SMO_OK;
+    if (cap < s->data_count) return SMO_E_CAPACITY;
+    memcpy(dst, s->data_pix, (size_t)s->data_count * 4);
+    return SMO_OK;
+}
+
+/* keep only the dataVbo records whose flag is non-zero (order preserved) */
+int smo_filter_data(smo_ctx *s, const uint8_t *keep)
+{
+    if (!s || (!keep && s->data_count)) return SMO_E_ARG;
+    uint32_t n = 0, nf = 0;
+    for (uint32_t q = 0; q < s->data_count; ++q) {
+        if (!keep[q]) continue;
+        if (n != q) {
+            memmove(s->data + (size_t)n * SURFEL_F, s->data + (size_t)q * SURFEL_F, SURFEL_F * 4);
+            s->data_pix[n] = s->data_pix[q];
+        }
+        if ((int32_t)f2u(s->data[(size_t)n * SURFEL_F + 5]) >= 0) nf++;
+        n++;
+    }
+    s->data_count = n;
+    s->fused_count = nf;
     return SMO_OK;
 }

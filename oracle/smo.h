@@ -63,6 +63,10 @@ void smo_destroy(smo_ctx *s);
 /* SurfelMapping::processFrame (src/SurfelMapping.cpp:115-251). pose: column-major 4x4 camera->world. */
 int smo_process_frame(smo_ctx *s, const uint8_t *rgb, const uint16_t *depth_mm,
                       const uint8_t *sem, const float *pose);
+/* the two halves of processFrame around the fusing passes (src/SurfelMapping.cpp:115-158,244-248) */
+int smo_begin_frame(smo_ctx *s, const uint8_t *rgb, const uint16_t *depth_mm, const uint8_t *sem,
+                    const float *pose);
+int smo_end_frame(smo_ctx *s);
 /* SurfelMapping::cleanPoints (src/SurfelMapping.cpp:496-532) */
 int smo_clean_points(smo_ctx *s, const uint16_t *depth_mm, const uint8_t *sem, const float *pose);
 /* SurfelMapping::reset (src/SurfelMapping.cpp:436-441) */
@@ -93,6 +97,13 @@ int smo_stage_data_associate(smo_ctx *s, const float *pose, int time, float dept
                              float depth_max);                       /* p8 */
 int smo_stage_update_fuse(smo_ctx *s);                               /* p9 */
 int smo_stage_concatenate(smo_ctx *s);                               /* p11 */
+
+/* ---- helpers for the multi-GPU shard tests: one oracle instance plays one rank ---- */
+int smo_set_exempt_id(smo_ctx *s, int32_t id);
+int smo_download_zbuf(const smo_ctx *s, uint32_t *dst);
+int smo_upload_index_ids(smo_ctx *s, const int32_t *idx, const uint8_t *has);
+int smo_download_data_pixels(const smo_ctx *s, int32_t *dst, uint32_t cap, uint32_t *n);
+int smo_filter_data(smo_ctx *s, const uint8_t *keep);
 
 /* ---- pre-processing passes on explicit buffers (p0a..p0e) ---- */
 void smo_metricise(const smo_config *c, const uint16_t *raw, float *out);

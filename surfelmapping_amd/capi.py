@@ -25,6 +25,8 @@ SYMBOLS = (
     "sm_stage_conflict", "sm_stage_cull", "sm_stage_splat", "sm_stage_associate_fuse",
     "sm_stage_timings", "sm_read_frame_log", "sm_device_alloc", "sm_device_free", "sm_device_upload",
     "sm_export_model_device", "sm_append_model_aos_device", "sm_key_map_device_ptr",
+    "sm_fused_mask_device_ptr", "sm_device_download", "sm_shard_configure", "sm_shard_begin_frame",
+    "sm_shard_conflict", "sm_shard_cull_splat", "sm_shard_associate", "sm_shard_append",
 )
 
 
@@ -119,6 +121,15 @@ def load():
     L.sm_device_upload.argtypes = [vp, vp, vp, C.c_size_t]
     L.sm_export_model_device.argtypes = [vp, C.POINTER(vp), u32p]
     L.sm_append_model_aos_device.argtypes = [vp, vp, C.c_uint32]
+    L.sm_fused_mask_device_ptr.restype = vp
+    L.sm_fused_mask_device_ptr.argtypes = [vp, u32p]
+    L.sm_device_download.argtypes = [vp, vp, vp, C.c_size_t]
+    L.sm_shard_configure.argtypes = [vp, C.c_int, C.c_int]
+    L.sm_shard_begin_frame.argtypes = [vp, vp, vp, vp, vp]
+    L.sm_shard_conflict.argtypes = [vp, C.c_uint32, vp, C.c_int, vp, u32p]
+    L.sm_shard_cull_splat.argtypes = [vp, vp, vp, C.c_int]
+    L.sm_shard_associate.argtypes = [vp, vp, C.c_int]
+    L.sm_shard_append.argtypes = [vp, C.c_int]
     L.sm_key_map_device_ptr.restype = vp
     L.sm_key_map_device_ptr.argtypes = [vp]
     for name in SYMBOLS:
@@ -299,6 +310,51 @@ class SurfelMap:
 
     def append_model_device(self, d_ptr: int, n: int):
         self._chk(self._L.sm_append_model_aos_device(self._h, d_ptr, n), "sm_append_model_aos_device")
+
+    def device_download(self, src: int, nbytes: int, dtype=np.uint8) -> np.ndarray:
+        out = np.zeros(nbytes // np.dtype(dtype).itemsize, dtype)
+        self._chk(self._L.sm_device_download(self._h, _ptr(out), src, nbytes), "sm_device_download")
+        return out
+
+    def fused_mask_device_ptr(self):
+        n = C.c_uint32()
+        p = self._L.sm_fused_mask_device_ptr(self._h, C.byref(n))
+        return p, n.value
+
+    # -- sharded mode (see surfelmapping_amd/sharded.py)
+    def shard_configure(self, rank, world):
+        self._chk(self._L.sm_shard_configure(self._h, rank, world), "sm_shard_configure")
+
+    def shard_begin_frame(self, rgb, depth, sem, pose) -> int:
+        rgb = np.ascontiguousarray(rgb, np.uint8)
+        depth = np.ascontiguousarray(depth, np.uint16)
+        sem = np.ascontiguousarray(sem, np.uint8)
+        pose = np.ascontiguousarray(pose, np.float32)
+        return self._chk(self._L.sm_shard_begin_frame(self._h, _ptr(rgb), _ptr(depth), _ptr(sem), _ptr(pose)),
+                         "sm_shard_begin_frame", allow=(0, 1))
+
+    def shard_conflict(self, exempt_local, seg_lstart_old):
+        ls = np.ascontiguousarray(seg_lstart_old, np.uint32)
+        nseg = ls.shape[0] - 1
+        keep = np.zeros(max(nseg, 1), np.uint32)
+        c = C.c_uint32()
+        self._chk(self._L.sm_shard_conflict(self._h, int(exempt_local) & 0xFFFFFFFF, _ptr(ls), nseg, _ptr(keep), C.byref(c)),
+                  "sm_shard_conflict")
+        return keep[:nseg], c.value
+
+    def shard_cull_splat(self, seg_lstart_new, seg_gbase):
+        ls = np.ascontiguousarray(seg_lstart_new, np.uint32)
+        gb = np.ascontiguousarray(seg_gbase, np.uint32)
+        if gb.shape[0] == 0:
+            gb = np.zeros(1, np.uint32)
+        self._chk(self._L.sm_shard_cull_splat(self._h, _ptr(ls), _ptr(gb), ls.shape[0] - 1), "sm_shard_cull_splat")
+
+    def shard_associate(self, gseg_base):
+        gb = np.ascontiguousarray(gseg_base, np.uint32)
+        self._chk(self._L.sm_shard_associate(self._h, _ptr(gb), gb.shape[0] - 1), "sm_shard_associate")
+
+    def shard_append(self, append_here: bool, allow=(0,)):
+        return self._chk(self._L.sm_shard_append(self._h, 1 if append_here else 0), "sm_shard_append", allow)
 
     def key_map_device_ptr(self) -> int:
         return self._L.sm_key_map_device_ptr(self._h)

@@ -137,8 +137,14 @@ struct sm_ctx {
     uint32_t cull_epoch = 0;
     int compact_grid = COMPACT_GRID;
     // association scratch
-    uint64_t *d_newmask = nullptr;
-    uint32_t *d_blk_new = nullptr, *d_blk_fused = nullptr, *d_blk_prefix = nullptr;
+    uint64_t *d_validmask = nullptr, *d_fusedmask = nullptr;
+    uint32_t *d_blk_prefix = nullptr;
+    // multi-GPU segment tables (device copies; nseg == 0 on a single GPU)
+    uint32_t *d_seg_lstart = nullptr, *d_seg_gbase = nullptr, *d_gseg_base = nullptr, *d_seg_keep = nullptr;
+    uint32_t seg_cap = 0;
+    int sh_rank = 0, sh_world = 1, sh_nseg = 0, sh_ngseg = 0;
+    uint32_t sh_exempt = 0;
+    bool sh_in_frame = false;
     int n_pix_blocks = 0;
     uint32_t n_odd_pixels = 0;
     // export staging
@@ -208,6 +214,12 @@ FrameParams make_params(const sm_ctx *s, const float *pose)
     fp.depth_cutoff = c.far_clip;
     fp.conflict_cap = c.conflict_cap ? (uint32_t)s->P : 0xFFFFFFFFu;
     fp.max_vertices = s->cap;
+    fp.exempt_local = s->sh_world > 1 ? s->sh_exempt : 0u;
+    fp.nseg = s->sh_world > 1 ? s->sh_nseg : 0;
+    fp.n_gseg = s->sh_world > 1 ? s->sh_ngseg : 0;
+    fp.rank = s->sh_rank;
+    fp.world = s->sh_world;
+    fp.append_here = 1;
     return fp;
 }
 
@@ -291,30 +303,45 @@ int launch_compact(sm_ctx *s, const FrameParams &fp, bool splat, bool timed)
     const uint32_t epoch = ++s->cull_epoch;
     if (splat)
         hipLaunchKernelGGL(k_compact<true>, dim3(grid), dim3(256), 0, s->stream, s->M, s->d_state, fp, s->d_cm,
-                           s->d_dm, s->d_zm, s->d_tile_cnt, s->d_tile_allow, s->d_tile_keep, s->d_keyT, s->d_tile_flag, epoch);
+                           s->d_dm, s->d_zm, s->d_tile_cnt, s->d_tile_allow, s->d_tile_keep, s->d_keyT, s->d_tile_flag, epoch,
+                           s->d_seg_lstart, s->d_seg_gbase);
     else
         hipLaunchKernelGGL(k_compact<false>, dim3(grid), dim3(256), 0, s->stream, s->M, s->d_state, fp, s->d_cm,
-                           s->d_dm, s->d_zm, s->d_tile_cnt, s->d_tile_allow, s->d_tile_keep, s->d_keyT, s->d_tile_flag, epoch);
+                           s->d_dm, s->d_zm, s->d_tile_cnt, s->d_tile_allow, s->d_tile_keep, s->d_keyT, s->d_tile_flag, epoch,
+                           s->d_seg_lstart, s->d_seg_gbase);
     HIPCK(hipGetLastError());
     if (mark(s, 4, timed)) return SM_E_HIP;
     return SM_OK;
 }
 
-int launch_associate(sm_ctx *s, const FrameParams &fp, bool timed)
+int launch_associate_only(sm_ctx *s, const FrameParams &fp)
 {
     hipLaunchKernelGGL(k_associate, dim3(s->n_pix_blocks), dim3(PIX_BLOCK), 0, s->stream, s->M, s->d_state, fp,
-                       s->d_depthT, s->d_rgbsT, s->d_keyT, s->d_xs, s->d_ys, s->d_newmask, s->d_blk_new, s->d_blk_fused);
+                       s->d_depthT, s->d_rgbsT, s->d_keyT, s->d_xs, s->d_ys, s->d_validmask, s->d_fusedmask,
+                       s->d_gseg_base, s->d_seg_lstart);
     HIPCK(hipGetLastError());
-    if (mark(s, 5, timed)) return SM_E_HIP;
-    hipLaunchKernelGGL(k_scan_new, dim3(1), dim3(1024), 0, s->stream, s->d_state, fp, s->n_pix_blocks, s->d_blk_new,
-                       s->d_blk_fused, s->d_blk_prefix, s->d_log);
+    return SM_OK;
+}
+
+int launch_append(sm_ctx *s, const FrameParams &fp, bool timed)
+{
+    hipLaunchKernelGGL(k_scan_new, dim3(1), dim3(1024), 0, s->stream, s->d_state, fp, s->n_pix_blocks, s->d_validmask,
+                       s->d_fusedmask, s->d_blk_prefix, s->d_log);
     HIPCK(hipGetLastError());
     if (mark(s, 6, timed)) return SM_E_HIP;
     hipLaunchKernelGGL(k_append, dim3(s->n_pix_blocks), dim3(PIX_BLOCK), 0, s->stream, s->M, s->d_state, fp, s->d_depthT,
-                       s->d_rgbsT, s->d_xs, s->d_ys, s->d_newmask, s->d_blk_prefix);
+                       s->d_rgbsT, s->d_xs, s->d_ys, s->d_validmask, s->d_fusedmask, s->d_blk_prefix);
     HIPCK(hipGetLastError());
     if (mark(s, 7, timed)) return SM_E_HIP;
     return SM_OK;
+}
+
+int launch_associate(sm_ctx *s, const FrameParams &fp, bool timed)
+{
+    int rc = launch_associate_only(s, fp);
+    if (rc) return rc;
+    if (mark(s, 5, timed)) return SM_E_HIP;
+    return launch_append(s, fp, timed);
 }
 
 void bump_bound(sm_ctx *s)
@@ -322,9 +349,11 @@ void bump_bound(sm_ctx *s)
     s->count_bound = (uint32_t)std::min<uint64_t>((uint64_t)s->count_bound + s->n_odd_pixels, s->cap);
 }
 
-// SurfelMapping::processFrame body after the textures are on the device
-// (src/SurfelMapping.cpp:130-251); enqueue only.
-int enqueue_frame(sm_ctx *s, const uint8_t *d_rgb, const uint16_t *d_raw, const uint8_t *d_sem, const float *pose)
+// First half of SurfelMapping::processFrame once the textures are on the device
+// (src/SurfelMapping.cpp:130-169): pre-processing and the reference-frame early-out.
+// Returns 1 when the fusing passes must follow, 0 when the call ends here, <0 on error.
+int begin_frame(sm_ctx *s, const uint8_t *d_rgb, const uint16_t *d_raw, const uint8_t *d_sem, const float *pose,
+                FrameParams *fp_out)
 {
     if (s->pending_cull) { g_err = "sm_stage_conflict without sm_stage_cull"; return SM_E_ARG; }
     memcpy(s->curr_pose, pose, 64);
@@ -350,7 +379,7 @@ int enqueue_frame(sm_ctx *s, const uint8_t *d_rgb, const uint16_t *d_raw, const 
         memcpy(s->last_pose, s->curr_pose, 64);
         s->ref_set = true;
         s->tick++;
-        return SM_OK;
+        return 0;
     }
     if (s->cfg.preprocess) {                              // removeMovings src/SurfelMapping.cpp:156,336-365
         Mat4 t_c2l;
@@ -368,14 +397,53 @@ int enqueue_frame(sm_ctx *s, const uint8_t *d_rgb, const uint16_t *d_raw, const 
     }
     fp.splat_follows = 1;
     fp.log_frame = 1;
-    if ((rc = launch_conflict(s, fp, true))) return rc;    // :178-187
-    if ((rc = launch_compact(s, fp, true, true))) return rc;   // :189-197 (cull + mirror + index map)
-    if ((rc = launch_associate(s, fp, true))) return rc;   // :212-239
-    bump_bound(s);
+    *fp_out = fp;
+    return 1;
+}
+
+// tail of processFrame (src/SurfelMapping.cpp:244-248)
+void end_frame(sm_ctx *s)
+{
     if (s->cfg.preprocess) std::swap(s->d_lastT, s->d_filteredT);   // :244 LAST <- DEPTH_FILTERED without a copy
     memcpy(s->last_pose, s->curr_pose, 64);               // :245 (LAST aliases the metric depth when preprocess == 0)
     if (s->ev_ok) s->ev_frames++;
     s->tick++;
+}
+
+// SurfelMapping::processFrame body (src/SurfelMapping.cpp:130-251); enqueue only.
+int enqueue_frame(sm_ctx *s, const uint8_t *d_rgb, const uint16_t *d_raw, const uint8_t *d_sem, const float *pose)
+{
+    if (s->sh_world > 1) { g_err = "context is configured for sharding: use the sm_shard_* entry points"; return SM_E_ARG; }
+    FrameParams fp;
+    int rc = begin_frame(s, d_rgb, d_raw, d_sem, pose, &fp);
+    if (rc <= 0) return rc;
+    if ((rc = launch_conflict(s, fp, true))) return rc;    // :178-187
+    if ((rc = launch_compact(s, fp, true, true))) return rc;   // :189-197 (cull + mirror + index map)
+    if ((rc = launch_associate(s, fp, true))) return rc;   // :212-239
+    bump_bound(s);
+    end_frame(s);
+    return SM_OK;
+}
+
+int upload_u32(sm_ctx *s, uint32_t **dbuf, uint32_t *cap_field, const uint32_t *src, size_t n)
+{
+    (void)cap_field;
+    if (n == 0) return SM_OK;
+    HIPCK(hipMemcpyAsync(*dbuf, src, n * 4, hipMemcpyHostToDevice, s->stream));
+    return SM_OK;
+}
+
+int ensure_seg(sm_ctx *s, size_t n)
+{
+    if (n + 2 <= s->seg_cap) return SM_OK;
+    size_t cap = std::max<size_t>(1024, (n + 2) * 2);
+    HIPCK(hipStreamSynchronize(s->stream));
+    for (uint32_t **p : {&s->d_seg_lstart, &s->d_seg_gbase, &s->d_gseg_base, &s->d_seg_keep}) {
+        if (*p) (void)hipFree(*p);
+        *p = nullptr;
+        HIPCK(hipMalloc((void **)p, cap * 4));
+    }
+    s->seg_cap = (uint32_t)cap;
     return SM_OK;
 }
 
@@ -460,9 +528,8 @@ sm_ctx *sm_create(const sm_config *c)
     ok = ok && dalloc(&s->d_tile_cnt, ntiles * 3) == SM_OK && dalloc(&s->d_tile_allow, ntiles) == SM_OK &&
          dalloc(&s->d_tile_keep, ntiles) == SM_OK && dalloc(&s->d_tile_flag, ntiles) == SM_OK &&
          hipMemset(s->d_tile_flag, 0, ntiles * 4) == hipSuccess;
-    ok = ok && dalloc(&s->d_newmask, (P + 63) / 64 + 4) == SM_OK;
-    ok = ok && dalloc(&s->d_blk_new, (size_t)s->n_pix_blocks) == SM_OK && dalloc(&s->d_blk_fused, (size_t)s->n_pix_blocks) == SM_OK &&
-         dalloc(&s->d_blk_prefix, (size_t)s->n_pix_blocks) == SM_OK;
+    ok = ok && dalloc(&s->d_validmask, (P + 63) / 64 + 4) == SM_OK && dalloc(&s->d_fusedmask, (P + 63) / 64 + 4) == SM_OK;
+    ok = ok && dalloc(&s->d_blk_prefix, (size_t)s->n_pix_blocks) == SM_OK;
     if (!ok) { if (g_err.empty()) g_err = "sm_create: allocation failed"; sm_destroy(s); return nullptr; }
 
     // pixel-centre coordinates exactly as data.vert sees them:
@@ -548,7 +615,8 @@ void sm_destroy(sm_ctx *s)
     (void)hipFree(s->d_xs); (void)hipFree(s->d_ys); (void)hipFree(s->d_wtab);
     (void)hipFree(s->d_cm); (void)hipFree(s->d_dm); (void)hipFree(s->d_zm);
     (void)hipFree(s->d_tile_cnt); (void)hipFree(s->d_tile_allow); (void)hipFree(s->d_tile_keep); (void)hipFree(s->d_tile_flag);
-    (void)hipFree(s->d_newmask); (void)hipFree(s->d_blk_new); (void)hipFree(s->d_blk_fused); (void)hipFree(s->d_blk_prefix);
+    (void)hipFree(s->d_validmask); (void)hipFree(s->d_fusedmask); (void)hipFree(s->d_blk_prefix);
+    (void)hipFree(s->d_seg_lstart); (void)hipFree(s->d_seg_gbase); (void)hipFree(s->d_gseg_base); (void)hipFree(s->d_seg_keep);
     if (s->d_export) (void)hipFree(s->d_export);
     for (void *p : s->user_allocs) (void)hipFree(p);
     if (s->ev_ok)
@@ -829,7 +897,7 @@ int sm_stage_splat(sm_ctx *s, const float *pose16, int32_t time, float depth_cut
     hipLaunchKernelGGL(k_fill_keys, dim3((s->P + 255) / 256), dim3(256), 0, s->stream, s->d_keyT, s->P);
     HIPCK(hipGetLastError());
     const int grid = (int)std::min<uint64_t>(std::max<uint64_t>(((uint64_t)s->h_state->count + 255) / 256, 1), MAX_GRID);
-    hipLaunchKernelGGL(k_splat, dim3(grid), dim3(256), 0, s->stream, s->M, s->d_state, fp, s->d_keyT);
+    hipLaunchKernelGGL(k_splat, dim3(grid), dim3(256), 0, s->stream, s->M, s->d_state, fp, s->d_keyT, s->d_seg_lstart, s->d_seg_gbase);
     HIPCK(hipGetLastError());
     return sm_sync(s);
 }
@@ -981,5 +1049,120 @@ int sm_append_model_aos_device(sm_ctx *s, const float *d_src12, uint32_t n)
 }
 
 void *sm_key_map_device_ptr(sm_ctx *s) { return s ? (void *)s->d_keyT : nullptr; }
+
+void *sm_fused_mask_device_ptr(sm_ctx *s, uint32_t *nwords)
+{
+    if (!s) return nullptr;
+    if (nwords) *nwords = (uint32_t)((s->P + 63) / 64);
+    return (void *)s->d_fusedmask;
+}
+
+int sm_device_download(sm_ctx *s, void *dst_host, const void *src_device, size_t bytes)
+{
+    if (!s || !dst_host || !src_device) return SM_E_ARG;
+    HIPCK(hipSetDevice(s->cfg.device));
+    HIPCK(hipMemcpyAsync(dst_host, src_device, bytes, hipMemcpyDeviceToHost, s->stream));
+    HIPCK(hipStreamSynchronize(s->stream));
+    return SM_OK;
+}
+
+// ---- one camera stream sharded over `world` GPUs (DESIGN.md "Multi-GPU", sharded mode) ----
+
+int sm_shard_configure(sm_ctx *s, int rank, int world)
+{
+    if (!s || world < 1 || rank < 0 || rank >= world) return SM_E_ARG;
+    s->sh_rank = rank; s->sh_world = world;
+    s->sh_nseg = 0; s->sh_ngseg = 0; s->sh_exempt = 0; s->sh_in_frame = false;
+    return ensure_seg(s, 64);
+}
+
+int sm_shard_begin_frame(sm_ctx *s, const uint8_t *rgb, const uint16_t *depth_mm, const uint8_t *semantic, const float *pose16)
+{
+    if (!s || !rgb || !pose16) return SM_E_ARG;
+    HIPCK(hipSetDevice(s->cfg.device));
+    if (s->sh_in_frame) { g_err = "sm_shard_begin_frame: previous frame not finished (sm_shard_append)"; return SM_E_ARG; }
+    int rc = upload_inputs(s, rgb, depth_mm, semantic);
+    if (rc) return rc;
+    FrameParams fp;
+    rc = begin_frame(s, s->d_rgb, s->d_depth_raw, s->d_sem, pose16, &fp);
+    if (rc == 1) s->sh_in_frame = true;
+    if (rc < 0) return rc;
+    int rs = sm_sync(s);
+    return rs ? rs : rc;
+}
+
+int sm_shard_conflict(sm_ctx *s, uint32_t exempt_local, const uint32_t *seg_lstart_old, int nseg, uint32_t *seg_keep_out,
+                      uint32_t *conflict_out)
+{
+    if (!s || nseg < 0 || (nseg && (!seg_lstart_old || !seg_keep_out)) || !conflict_out) return SM_E_ARG;
+    HIPCK(hipSetDevice(s->cfg.device));
+    if (!s->sh_in_frame) { g_err = "sm_shard_conflict outside a frame"; return SM_E_ARG; }
+    int rc = ensure_seg(s, (size_t)nseg);
+    if (rc) return rc;
+    s->sh_exempt = exempt_local;
+    s->sh_nseg = nseg;
+    FrameParams fp = make_params(s, s->curr_pose);
+    fp.conflict_cap = 0xFFFFFFFFu;           // the W*H conflict cap needs the global conflict order: off when sharded
+    fp.splat_follows = 1;
+    if ((rc = upload_u32(s, &s->d_seg_lstart, nullptr, seg_lstart_old, (size_t)nseg + 1))) return rc;
+    if ((rc = launch_conflict(s, fp, false))) return rc;
+    if (nseg) {
+        hipLaunchKernelGGL(k_seg_counts, dim3((nseg + 255) / 256), dim3(256), 0, s->stream, s->d_state, s->d_cm, s->d_dm, s->d_zm,
+                           s->d_tile_keep, s->d_seg_lstart, nseg, s->d_seg_keep);
+        HIPCK(hipGetLastError());
+        HIPCK(hipMemcpyAsync(seg_keep_out, s->d_seg_keep, (size_t)nseg * 4, hipMemcpyDeviceToHost, s->stream));
+    }
+    HIPCK(hipMemcpyAsync(s->h_state, s->d_state, sizeof(DevState), hipMemcpyDeviceToHost, s->stream));
+    HIPCK(hipStreamSynchronize(s->stream));
+    *conflict_out = s->h_state->conflict_count;
+    return SM_OK;
+}
+
+int sm_shard_cull_splat(sm_ctx *s, const uint32_t *seg_lstart_new, const uint32_t *seg_gbase, int nseg)
+{
+    if (!s || nseg < 0 || (nseg && (!seg_lstart_new || !seg_gbase))) return SM_E_ARG;
+    HIPCK(hipSetDevice(s->cfg.device));
+    if (!s->sh_in_frame) { g_err = "sm_shard_cull_splat outside a frame"; return SM_E_ARG; }
+    int rc = ensure_seg(s, (size_t)nseg);
+    if (rc) return rc;
+    s->sh_nseg = nseg;
+    FrameParams fp = make_params(s, s->curr_pose);
+    fp.conflict_cap = 0xFFFFFFFFu;
+    if ((rc = upload_u32(s, &s->d_seg_lstart, nullptr, seg_lstart_new, (size_t)nseg + 1))) return rc;
+    if ((rc = upload_u32(s, &s->d_seg_gbase, nullptr, seg_gbase, (size_t)nseg))) return rc;
+    s->count_bound = std::max(s->count_bound, s->h_state->cull_n);
+    if ((rc = launch_compact(s, fp, true, false))) return rc;
+    return sm_sync(s);
+}
+
+int sm_shard_associate(sm_ctx *s, const uint32_t *gseg_base, int n_gseg)
+{
+    if (!s || n_gseg < 0 || (n_gseg && !gseg_base)) return SM_E_ARG;
+    HIPCK(hipSetDevice(s->cfg.device));
+    if (!s->sh_in_frame) { g_err = "sm_shard_associate outside a frame"; return SM_E_ARG; }
+    int rc = ensure_seg(s, (size_t)n_gseg);
+    if (rc) return rc;
+    s->sh_ngseg = n_gseg;
+    FrameParams fp = make_params(s, s->curr_pose);
+    if ((rc = upload_u32(s, &s->d_gseg_base, nullptr, gseg_base, (size_t)n_gseg + 1))) return rc;
+    if ((rc = launch_associate_only(s, fp))) return rc;
+    return sm_sync(s);
+}
+
+int sm_shard_append(sm_ctx *s, int append_here)
+{
+    if (!s) return SM_E_ARG;
+    HIPCK(hipSetDevice(s->cfg.device));
+    if (!s->sh_in_frame) { g_err = "sm_shard_append outside a frame"; return SM_E_ARG; }
+    FrameParams fp = make_params(s, s->curr_pose);
+    fp.append_here = append_here ? 1 : 0;
+    fp.log_frame = 1;
+    int rc = launch_append(s, fp, false);
+    if (rc) return rc;
+    if (append_here) bump_bound(s);
+    end_frame(s);
+    s->sh_in_frame = false;
+    return sm_sync(s);
+}
 
 }  // extern "C"

@@ -248,7 +248,7 @@ __global__ __launch_bounds__(256) void k_conflict(Model M, const DevState *__res
                     const uint32_t sem = rgbsT[q] >> 24;
                     if (sem == 10u) depth = fp.max_depth + 1.0f;
                     if (fp.is_clean == 0 && depth == 0.0f) depth = fp.max_depth + 20.0f;
-                    conflict = (depth * lambda - ph.z * lambda > fp.conflict_thresh * ph.z) && (k > 0u);
+                    conflict = (depth * lambda - ph.z * lambda > fp.conflict_thresh * ph.z) && (k != fp.exempt_local);
                 }
             }
             const bool dies = valid && !(v.w - 1.0f > 0.0f);
@@ -419,7 +419,9 @@ __global__ __launch_bounds__(256) void k_compact(Model M, DevState *__restrict__
                                                  const uint32_t *__restrict__ tile_allow,
                                                  const uint32_t *__restrict__ tile_keep_prefix,
                                                  uint64_t *__restrict__ keyT,
-                                                 uint32_t *__restrict__ tile_flag, uint32_t epoch)
+                                                 uint32_t *__restrict__ tile_flag, uint32_t epoch,
+                                                 const uint32_t *__restrict__ seg_lstart,
+                                                 const uint32_t *__restrict__ seg_gbase)
 {
     __shared__ uint64_t s_keep[TILE_WORDS], s_ceff[TILE_WORDS];
     __shared__ uint32_t s_cpop[TILE_WORDS], s_kpre[TILE_WORDS + 1];
@@ -523,7 +525,8 @@ __global__ __launch_bounds__(256) void k_compact(Model M, DevState *__restrict__
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 bool drew = false;
-                if (kept[r]) drew = splat_one(fp, v[r].x, v[r].y, v[r].z, tl[r], nid[r], keyT);
+                if (kept[r])
+                    drew = splat_one(fp, v[r].x, v[r].y, v[r].z, tl[r], local_to_global(nid[r], seg_lstart, seg_gbase, fp.nseg), keyT);
                 vis += (uint32_t)__popcll(__ballot(drew));
             }
         }
@@ -541,7 +544,8 @@ __global__ __launch_bounds__(256) void k_compact(Model M, DevState *__restrict__
 
 // standalone p6 (IndexMap::predictIndices) over the current model
 __global__ __launch_bounds__(256) void k_splat(Model M, DevState *__restrict__ st, FrameParams fp,
-                                               uint64_t *__restrict__ keyT)
+                                               uint64_t *__restrict__ keyT, const uint32_t *__restrict__ seg_lstart,
+                                               const uint32_t *__restrict__ seg_gbase)
 {
     __shared__ uint32_t s_vis[4];
     const uint32_t N = st->count;
@@ -554,7 +558,7 @@ __global__ __launch_bounds__(256) void k_splat(Model M, DevState *__restrict__ s
         bool drew = false;
         if (k < N) {
             const float4 v = cur.pos_conf[k];
-            drew = splat_one(fp, v.x, v.y, v.z, cur.time[k], k, keyT);
+            drew = splat_one(fp, v.x, v.y, v.z, cur.time[k], local_to_global(k, seg_lstart, seg_gbase, fp.nseg), keyT);
         }
         vis += (uint32_t)__popcll(__ballot(drew));
     }
@@ -634,20 +638,23 @@ __global__ __launch_bounds__(PIX_BLOCK) void k_associate(Model M, const DevState
                                                          const uint32_t *__restrict__ rgbsT,
                                                          const uint64_t *__restrict__ keyT,
                                                          const float *__restrict__ xs, const float *__restrict__ ys,
-                                                         uint64_t *__restrict__ newmask,
-                                                         uint32_t *__restrict__ blk_new, uint32_t *__restrict__ blk_fused)
+                                                         uint64_t *__restrict__ validmask, uint64_t *__restrict__ fusedmask,
+                                                         const uint32_t *__restrict__ gseg_base,
+                                                         const uint32_t *__restrict__ seg_lstart)
 {
-    __shared__ uint32_t s_n[4], s_f[4];
     const SurfelSet cur = M.s[st->cur];
     const int q = blockIdx.x * PIX_BLOCK + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    bool is_new = false, is_fused = false;
+    bool is_valid = false, is_fused = false;
     LocalSurfel L;
     if (q < fp.P && local_surfel(q, fp, depthT, rgbsT, xs, ys, L)) {
-        is_new = true;
+        is_valid = true;
         const uint64_t key = keyT[q];
-        const int32_t id = (int32_t)(uint32_t)(key & 0xFFFFFFFFull);
-        if (key != KEY_EMPTY && id > 0) {                                   // data.vert:142
+        const int32_t gid = (int32_t)(uint32_t)(key & 0xFFFFFFFFull);
+        uint32_t id = 0;
+        // data.vert:142 on the GLOBAL id; only the rank that owns the winner tries to fuse it
+        if (key != KEY_EMPTY && gid > 0 &&
+            global_to_local((uint32_t)gid, gseg_base, fp.n_gseg, seg_lstart, fp.rank, fp.world, &id)) {
             const float4 pc = cur.pos_conf[id];
             const uint32_t col = cur.color[id];
             const uint32_t sem_o = col >> 24;
@@ -661,7 +668,6 @@ __global__ __launch_bounds__(PIX_BLOCK) void k_associate(Model M, const DevState
                 const float3 no = normalize3(rot3(fp.t_inv, nr.x, nr.y, nr.z));                       // index_map.vert:63
                 const float ang = acos_spec(dot3(no, L.nrm) / (sqrtf(dot3(no, no)) * sqrtf(dot3(L.nrm, L.nrm))));
                 if (dist < 1000.0f && fabsf(ang) < 0.5f) {                                           // data.vert:158
-                    is_new = false;
                     is_fused = true;
                     const float c_n = 0.9f, c_o = pc.w;
                     const float w = c_n + c_o;
@@ -698,17 +704,12 @@ __global__ __launch_bounds__(PIX_BLOCK) void k_associate(Model M, const DevState
             }
         }
     }
-    const uint64_t nw = __ballot(is_new), fw = __ballot(is_fused);
+    // two ballot words per wave: candidate pixels, and pixels fused by THIS rank (disjoint across ranks,
+    // so a sum-reduction of the words over the ranks is their union)
+    const uint64_t vw = __ballot(is_valid), fw = __ballot(is_fused);
     if (lane == 0) {
         const int word = blockIdx.x * (PIX_BLOCK / 64) + wave;
-        if (word * 64 < fp.P) newmask[word] = nw;
-        s_n[wave] = (uint32_t)__popcll(nw);
-        s_f[wave] = (uint32_t)__popcll(fw);
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        blk_new[blockIdx.x] = s_n[0] + s_n[1] + s_n[2] + s_n[3];
-        blk_fused[blockIdx.x] = s_f[0] + s_f[1] + s_f[2] + s_f[3];
+        if (word * 64 < fp.P) { validmask[word] = vw; fusedmask[word] = fw; }
     }
 }
 
@@ -716,26 +717,46 @@ __global__ __launch_bounds__(PIX_BLOCK) void k_associate(Model M, const DevState
 // model count (GlobalModel::concatenate src/GlobalModel.cpp:629) with the capacity check the
 // reference lacks.
 __global__ __launch_bounds__(1024) void k_scan_new(DevState *__restrict__ st, FrameParams fp, int nblocks,
-                                                   const uint32_t *__restrict__ blk_new,
-                                                   const uint32_t *__restrict__ blk_fused,
+                                                   const uint64_t *__restrict__ validmask,
+                                                   const uint64_t *__restrict__ fusedmask,
                                                    uint32_t *__restrict__ blk_prefix, FrameLog *__restrict__ log)
 {
     __shared__ uint32_t s_scan[17];
     const uint32_t nb = (uint32_t)nblocks;
+    const uint32_t nwords = ((uint32_t)fp.P + 63u) >> 6;
     const uint32_t per = (nb + 1023u) / 1024u;
     const uint32_t b0 = min(threadIdx.x * per, nb), b1 = min(b0 + per, nb);
     uint32_t ns = 0, fs = 0;
-#pragma unroll 4
-    for (uint32_t b = b0; b < b1; ++b) { ns += blk_new[b]; fs += blk_fused[b]; }
+    for (uint32_t b = b0; b < b1; ++b) {
+#pragma unroll
+        for (uint32_t w = 0; w < PIX_BLOCK / 64; ++w) {
+            const uint32_t word = b * (PIX_BLOCK / 64) + w;
+            if (word < nwords) {
+                const uint64_t v = validmask[word], f = fusedmask[word];
+                ns += (uint32_t)__popcll(v & ~f);
+                fs += (uint32_t)__popcll(f);
+            }
+        }
+    }
     uint32_t ntot, ftot;
     uint32_t npre = block_scan_1024(ns, &ntot, s_scan);
     block_scan_1024(fs, &ftot, s_scan);
-    for (uint32_t b = b0; b < b1; ++b) { blk_prefix[b] = npre; npre += blk_new[b]; }
+    for (uint32_t b = b0; b < b1; ++b) {
+        blk_prefix[b] = npre;
+#pragma unroll
+        for (uint32_t w = 0; w < PIX_BLOCK / 64; ++w) {
+            const uint32_t word = b * (PIX_BLOCK / 64) + w;
+            if (word < nwords) npre += (uint32_t)__popcll(validmask[word] & ~fusedmask[word]);
+        }
+    }
     if (threadIdx.x == 0) {
         st->unstable_count = ntot;
         st->fused_count = ftot;
         st->data_count = ntot + ftot;
-        if ((uint64_t)st->offset + ntot > (uint64_t)fp.max_vertices) {
+        if (!fp.append_here) {                   // another rank owns this frame's new surfels
+            st->append_n = 0;
+            st->count = st->offset;
+        } else if ((uint64_t)st->offset + ntot > (uint64_t)fp.max_vertices) {
             st->error = -2;          // SM_E_CAPACITY: append nothing instead of corrupting state
             st->append_n = 0;
             st->count = st->offset;
@@ -760,7 +781,8 @@ __global__ __launch_bounds__(PIX_BLOCK) void k_append(Model M, const DevState *_
                                                       const float *__restrict__ depthT,
                                                       const uint32_t *__restrict__ rgbsT,
                                                       const float *__restrict__ xs, const float *__restrict__ ys,
-                                                      const uint64_t *__restrict__ newmask,
+                                                      const uint64_t *__restrict__ validmask,
+                                                      const uint64_t *__restrict__ fusedmask,
                                                       const uint32_t *__restrict__ blk_prefix)
 {
     if (st->append_n == 0) return;
@@ -770,10 +792,10 @@ __global__ __launch_bounds__(PIX_BLOCK) void k_append(Model M, const DevState *_
     const int word0 = blockIdx.x * (PIX_BLOCK / 64);
     const int nwords = (fp.P + 63) >> 6;
     if (word0 + wave >= nwords) return;
-    const uint64_t mw = newmask[word0 + wave];
+    const uint64_t mw = validmask[word0 + wave] & ~fusedmask[word0 + wave];
     if (!((mw >> lane) & 1ull)) return;
     uint32_t before = 0;
-    for (int w = 0; w < wave; ++w) before += (uint32_t)__popcll(newmask[word0 + w]);
+    for (int w = 0; w < wave; ++w) before += (uint32_t)__popcll(validmask[word0 + w] & ~fusedmask[word0 + w]);
     const uint32_t slot = st->offset + blk_prefix[blockIdx.x] + before + (uint32_t)__popcll(mw & ((1ull << lane) - 1ull));
     LocalSurfel L;
     if (!local_surfel(q, fp, depthT, rgbsT, xs, ys, L)) return;   // cannot happen: flagged pixels are valid
@@ -785,6 +807,36 @@ __global__ __launch_bounds__(PIX_BLOCK) void k_append(Model M, const DevState *_
     cur.color[slot] = encode_color(L.cr, L.cg, L.cb, L.sem);
     cur.init_time[slot] = (float)fp.time;
     cur.time[slot] = (float)fp.time;
+}
+
+// survivors per creation-frame segment after the pending cull (multi-GPU bookkeeping; the conflict cap
+// is off in sharded runs, so keep = ~(zm | cm & dm))
+__global__ void k_seg_counts(const DevState *__restrict__ st, const uint64_t *__restrict__ cm,
+                             const uint64_t *__restrict__ dm, const uint64_t *__restrict__ zm,
+                             const uint32_t *__restrict__ tile_keep_prefix, const uint32_t *__restrict__ seg_lstart,
+                             int nseg, uint32_t *__restrict__ out)
+{
+    const int sidx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (sidx >= nseg) return;
+    const uint32_t N = st->cull_n;
+    auto kept_before = [&](uint32_t x) -> uint32_t {
+        if (x >= N) return st->count;                       // k_scan_cull already published the survivor total
+        const uint32_t tile = x / TILE, within = x % TILE;
+        uint32_t sum = tile_keep_prefix[tile];
+        const uint32_t w0 = tile * TILE_WORDS;
+        for (uint32_t w = 0; w <= within / 64; ++w) {
+            const uint32_t word = w0 + w;
+            const uint64_t base = (uint64_t)word * 64u;
+            if (base >= N) break;
+            const uint64_t rem = (uint64_t)N - base;
+            const uint64_t valid = rem >= 64 ? ~0ull : ((1ull << rem) - 1ull);
+            uint64_t keep = ~(zm[word] | (cm[word] & dm[word])) & valid;
+            if (w == within / 64) keep &= ((1ull << (within % 64)) - 1ull);
+            sum += (uint32_t)__popcll(keep);
+        }
+        return sum;
+    };
+    out[sidx] = kept_before(seg_lstart[sidx + 1]) - kept_before(seg_lstart[sidx]);
 }
 
 // ---------------------------------------------------------------------------------------------
