@@ -77,6 +77,43 @@ def kernel_bytes(log):
     }
 
 
+def bench_sharded(args, dist, torch, capi, cam, frames, rank, world, local_rank, K, Wm, t_gen):
+    """ONE camera stream split over the GPUs (surfelmapping_amd/sharded.py); every rank holds the
+    replicated frame sequence, so all ranks generated the same frames (seed, no rank offset)."""
+    from surfelmapping_amd import sharded
+    P = cam["width"] * cam["height"]
+    sm = capi.SurfelMap(capi.make_config(**cam, preprocess=args.preprocess, device=local_rank, conflict_cap=1))
+    mp = sharded.ShardedMapper(sharded.HipShardBackend(sm, rank, world), sharded.TorchComm(device_index=local_rank), P,
+                               collect_stats=False)
+    for k in range(Wm):
+        mp.process_frame(*frames[k])
+    dist.barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    fused = 0
+    for k in range(Wm, Wm + K):
+        c = mp.process_frame(*frames[k])
+        fused += c["fused_count"] + c["unstable_count"]
+    dist.barrier(); torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device=torch.device("cuda", local_rank))
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t[0])
+    total = mp.counts()["count"]
+    dist.destroy_process_group()
+    if rank != 0:
+        return
+    print(json.dumps({
+        "metric": "frames/sec, 1242x375 KITTI-shaped RGB-D+semantic, full associate+fuse+merge",
+        "value": K / elapsed, "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm,
+        "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[3]: ONE KITTI 1242x375 stream sharded by creation-frame segments over "
+                               f"{world} GPUs; per frame: all-reduce(sum) segment counts, all-reduce(min) 3.7 MB key map, "
+                               "all-reduce(sum) fused mask (RCCL); host-buffer frames (PCIe-inclusive), result bit-identical to 1 GPU",
+                   "frames": f"{Wm}..{Wm + K - 1}", "surfels_end": int(total)},
+        "surfels_fused_per_sec": fused / elapsed, "roofline": None, "cpu_baseline": None, "gen_seconds": t_gen}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -88,6 +125,9 @@ def main():
     ap.add_argument("--workers", type=int, default=0, help="frame-generation processes (0 = auto; use 1 under rocprofv3)")
     ap.add_argument("--no-events", action="store_true", help="no HIP events inside frames (no per-kernel timings / roofline)")
     ap.add_argument("--preprocess", type=int, default=0, help="1: run the full depth pre-processing chain p0a..p0e per frame")
+    ap.add_argument("--mode", choices=["rig", "sharded"], default="rig",
+                    help="N>1: 'rig' = one camera stream per GPU + all-gather into one GlobalModel (weak scaling); "
+                         "'sharded' = ONE stream split over the GPUs, bit-identical to 1 GPU (strong scaling)")
     ap.add_argument("--force-dist", action="store_true", help="rehearse the multi-GPU code path with WORLD_SIZE=1")
     ap.add_argument("--sync-every-frame", action="store_true",
                     help="reference semantics: host waits for the counters after every frame")
@@ -106,7 +146,8 @@ def main():
     # ---- synthetic frames (before anything touches the GPU; forked workers never do)
     t0 = time.time()
     workers = args.workers or max(1, min(8, (os.cpu_count() or 2) // max(world, 1)))
-    frames = make_frames(cam, n_frames, args.seed, args.noise_mm, workers, rank, world)
+    shard = args.mode == "sharded" and (world > 1 or args.force_dist)
+    frames = make_frames(cam, n_frames, args.seed, args.noise_mm, workers, 0 if shard else rank, 1 if shard else world)
     t_gen = time.time() - t0
 
     dist = None
@@ -120,6 +161,8 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from surfelmapping_amd import capi
+    if dist and args.mode == "sharded":
+        return bench_sharded(args, dist, torch, capi, cam, frames, rank, world, local_rank, K, Wm, t_gen)
     mk = lambda timing: capi.SurfelMap(capi.make_config(**cam, preprocess=args.preprocess, device=local_rank,
                                                         enable_timing=timing))
     sm = mk(0)                                    # raises without a GPU: no CPU fallback

@@ -39,6 +39,16 @@ SCRIPT = textwrap.dedent("""
     g = glob.download_model()
     assert total == local.shape[0] == counts[0] > 0, (total, local.shape, counts)
     assert np.array_equal(g.view(np.uint32), local.view(np.uint32))
+    # sharded mode through the RCCL device path (world 1): key map / fused mask all-reduced in place
+    from surfelmapping_amd import sharded
+    import oracle_lib as ol
+    sm2 = capi.SurfelMap(capi.make_config(**cam, **over))
+    mp = sharded.ShardedMapper(sharded.HipShardBackend(sm2, 0, 1), sharded.TorchComm(device_index=0), cam["width"] * cam["height"])
+    o = ol.Oracle(ol.make_config(**cam, **over))
+    for fr in seq:
+        mp.process_frame(*fr); o.process_frame(*fr)
+    gm, om = mp.gather_global_model(), o.download_model()
+    assert gm.shape == om.shape and np.array_equal(gm.view(np.uint32), om.view(np.uint32))
     dist.destroy_process_group()
     print("DIST_GPU_OK", ORDER, total)
 """).replace("__ROOT__", ROOT)
