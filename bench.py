@@ -125,6 +125,10 @@ def main():
     ap.add_argument("--workers", type=int, default=0, help="frame-generation processes (0 = auto; use 1 under rocprofv3)")
     ap.add_argument("--no-events", action="store_true", help="no HIP events inside frames (no per-kernel timings / roofline)")
     ap.add_argument("--preprocess", type=int, default=0, help="1: run the full depth pre-processing chain p0a..p0e per frame")
+    ap.add_argument("--workload", choices=["kitti", "hd20m"], default="kitti",
+                    help="kitti = BASELINE configs[1] (default, the metric's config); hd20m = configs[2]: 1920x1080 "
+                         "dense depth, model pre-seeded with 20 M surfels (HBM-bandwidth stress)")
+    ap.add_argument("--seed-surfels", type=int, default=20_000_000)
     ap.add_argument("--mode", choices=["rig", "sharded"], default="rig",
                     help="N>1: 'rig' = one camera stream per GPU + all-gather into one GlobalModel (weak scaling); "
                          "'sharded' = ONE stream split over the GPUs, bit-identical to 1 GPU (strong scaling)")
@@ -139,7 +143,8 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit(f"WORLD_SIZE={world} but --gpus {args.gpus}")
     K, Wm = args.steps, max(args.warmup, 2)     # call 1 only sets the reference frame
-    cam = synth.KITTI
+    hd = args.workload == "hd20m"
+    cam = synth.HD if hd else synth.KITTI
     P = cam["width"] * cam["height"]
     n_frames = Wm + K
 
@@ -163,8 +168,9 @@ def main():
     from surfelmapping_amd import capi
     if dist and args.mode == "sharded":
         return bench_sharded(args, dist, torch, capi, cam, frames, rank, world, local_rank, K, Wm, t_gen)
+    # hd20m: the conflict cap is off for the stress benchmark (SURVEY.md A13 says to state which)
     mk = lambda timing: capi.SurfelMap(capi.make_config(**cam, preprocess=args.preprocess, device=local_rank,
-                                                        enable_timing=timing))
+                                                        enable_timing=timing, conflict_cap=0 if hd else 1))
     sm = mk(0)                                    # raises without a GPU: no CPU fallback
     # second context: the same frames again with HIP events between the kernels (the events cost
     # ~25 us per frame, so they stay out of the run that produces `value`)
@@ -176,6 +182,14 @@ def main():
         dr, dd, ds = sm.device_alloc(P * 3), sm.device_alloc(P * 2), sm.device_alloc(P)
         sm.device_upload(dr, rgb); sm.device_upload(dd, depth); sm.device_upload(ds, sem)
         dptr.append((dr, dd, ds, pose))
+
+    seed_model = None
+    if hd:
+        seed_model = synth.seeded_model(args.seed_surfels, tick=300, seed=args.seed)
+        for ctx in (sm, sm_ev):
+            if ctx is not None:
+                ctx.upload_model(seed_model)
+                ctx.set_tick(300)
 
     def run(ctx, lo, hi):
         for k in range(lo, hi):
@@ -258,21 +272,26 @@ def main():
     cpu = None
     if not args.no_cpu_baseline and dist is None:
         import oracle_lib as ol                  # checker / baseline only
-        o = ol.Oracle(ol.make_config(**cam, preprocess=args.preprocess))
+        o = ol.Oracle(ol.make_config(**cam, preprocess=args.preprocess, conflict_cap=0 if hd else 1))
+        Kc = K
+        if hd:                                   # bounded sample: a 20 M-surfel frame takes seconds on one core
+            o.upload_model(seed_model); o.set_tick(300)
+            Kc = min(K, 3)
         for k in range(Wm):
             o.process_frame(*frames[k])
         c0 = time.perf_counter()
-        for k in range(Wm, Wm + K):
+        for k in range(Wm, Wm + Kc):
             o.process_frame(*frames[k])
         c_el = time.perf_counter() - c0
         oc = o.counts()
-        same = all(oc[k] == counts[k] for k in ("count", "offset", "unstable_count", "fused_count", "conflict_count"))
-        cpu = {"value": K / c_el, "unit": "frames/s", "cores": 1, "kind": "port",
-               "sample": f"the same {K} frames (after the same {Wm} warm-up frames), oracle/libsmo.so, 1 thread, "
-                         f"host {os.cpu_count()} logical CPUs", "final_counts_match_gpu": bool(same)}
+        same = (Kc == K) and all(oc[k] == counts[k] for k in ("count", "offset", "unstable_count", "fused_count", "conflict_count"))
+        cpu = {"value": Kc / c_el, "unit": "frames/s", "cores": 1, "kind": "port",
+               "sample": f"the first {Kc} of the same {K} frames (after the same {Wm} warm-up frames), oracle/libsmo.so, 1 thread, "
+                         f"host {os.cpu_count()} logical CPUs", "final_counts_match_gpu": bool(same) if Kc == K else None}
 
     out = {
-        "metric": "frames/sec per GPU, 1242x375 KITTI-shaped RGB-D+semantic, full associate+fuse+merge",
+        "metric": ("frames/sec per GPU, 1920x1080 dense depth, >=20 M live surfels" if hd else
+                   "frames/sec per GPU, 1242x375 KITTI-shaped RGB-D+semantic, full associate+fuse+merge"),
         "value": world * K / elapsed,
         "unit": "frames/s",
         "n_gpus": world,
@@ -284,8 +303,9 @@ def main():
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": "BASELINE configs[1]: KITTI 1242x375 synthetic street sequence, 0.8 m/frame, "
-                               f"depth noise {args.noise_mm} mm, metricise+conflict+cull+splat+associate+fuse+append per frame"
+        "config": {"workload": (f"BASELINE configs[2]: 1920x1080 dense depth, model pre-seeded with {args.seed_surfels} surfels, conflict cap off, "
+                                if hd else "BASELINE configs[1]: KITTI 1242x375 synthetic street sequence, 0.8 m/frame, ")
+                               + f"depth noise {args.noise_mm} mm, metricise+conflict+cull+splat+associate+fuse+append per frame"
                                + (" + depth pre-processing p0b..p0e" if args.preprocess else ""),
                    "frames": f"{Wm}..{Wm + K - 1}", "multi_gpu": (f"{world}-camera rig, one stream per GPU, RCCL all-gather into a single GlobalModel of "
                                  f"{global_count} surfels inside the timed region") if dist else "single stream",
