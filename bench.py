@@ -170,7 +170,8 @@ def main():
         return bench_sharded(args, dist, torch, capi, cam, frames, rank, world, local_rank, K, Wm, t_gen)
     # hd20m: the conflict cap is off for the stress benchmark (SURVEY.md A13 says to state which)
     mk = lambda timing: capi.SurfelMap(capi.make_config(**cam, preprocess=args.preprocess, device=local_rank,
-                                                        enable_timing=timing, conflict_cap=0 if hd else 1))
+                                                        enable_timing=timing, conflict_cap=0 if hd else 1,
+                                                        max_sqrt_vertices=10000 if hd else 5000))
     sm = mk(0)                                    # raises without a GPU: no CPU fallback
     # second context: the same frames again with HIP events between the kernels (the events cost
     # ~25 us per frame, so they stay out of the run that produces `value`)
@@ -272,7 +273,8 @@ def main():
     cpu = None
     if not args.no_cpu_baseline and dist is None:
         import oracle_lib as ol                  # checker / baseline only
-        o = ol.Oracle(ol.make_config(**cam, preprocess=args.preprocess, conflict_cap=0 if hd else 1))
+        o = ol.Oracle(ol.make_config(**cam, preprocess=args.preprocess, conflict_cap=0 if hd else 1,
+                                     max_sqrt_vertices=10000 if hd else 5000))
         Kc = K
         if hd:                                   # bounded sample: a 20 M-surfel frame takes seconds on one core
             o.upload_model(seed_model); o.set_tick(300)

@@ -134,6 +134,7 @@ struct sm_ctx {
     // cull scratch
     uint64_t *d_cm = nullptr, *d_dm = nullptr, *d_zm = nullptr;
     uint32_t *d_tile_cnt = nullptr, *d_tile_allow = nullptr, *d_tile_keep = nullptr, *d_tile_flag = nullptr;
+    uint32_t *d_group_tot = nullptr, *d_group_base = nullptr;
     uint32_t cull_epoch = 0;
     int compact_grid = COMPACT_GRID;
     // association scratch
@@ -290,8 +291,12 @@ int launch_conflict(sm_ctx *s, const FrameParams &fp, bool timed = false)
                        s->d_rgbsT, s->d_cm, s->d_dm, s->d_zm, s->d_tile_cnt);
     HIPCK(hipGetLastError());
     if (mark(s, 2, timed)) return SM_E_HIP;
-    hipLaunchKernelGGL(k_scan_cull, dim3(1), dim3(1024), 0, s->stream, s->d_state, fp, s->d_cm, s->d_dm, s->d_zm,
-                       s->d_tile_cnt, s->d_tile_allow, s->d_tile_keep);
+    const int ngroups = std::max<int>(1, (int)((((uint64_t)s->count_bound + TILE - 1) / TILE + GROUP - 1) / GROUP));
+    hipLaunchKernelGGL(k_scan_cull, dim3(ngroups), dim3(1024), 0, s->stream, s->d_state, s->d_tile_cnt, s->d_tile_allow,
+                       s->d_tile_keep, s->d_group_tot);
+    HIPCK(hipGetLastError());
+    hipLaunchKernelGGL(k_cull_finalize, dim3(1), dim3(1024), 0, s->stream, s->d_state, fp, s->d_cm, s->d_dm, s->d_zm,
+                       s->d_tile_cnt, s->d_tile_allow, s->d_tile_keep, s->d_group_tot, s->d_group_base);
     HIPCK(hipGetLastError());
     if (mark(s, 3, timed)) return SM_E_HIP;
     return SM_OK;
@@ -304,11 +309,11 @@ int launch_compact(sm_ctx *s, const FrameParams &fp, bool splat, bool timed)
     if (splat)
         hipLaunchKernelGGL(k_compact<true>, dim3(grid), dim3(256), 0, s->stream, s->M, s->d_state, fp, s->d_cm,
                            s->d_dm, s->d_zm, s->d_tile_cnt, s->d_tile_allow, s->d_tile_keep, s->d_keyT, s->d_tile_flag, epoch,
-                           s->d_seg_lstart, s->d_seg_gbase);
+                           s->d_seg_lstart, s->d_seg_gbase, s->d_group_base);
     else
         hipLaunchKernelGGL(k_compact<false>, dim3(grid), dim3(256), 0, s->stream, s->M, s->d_state, fp, s->d_cm,
                            s->d_dm, s->d_zm, s->d_tile_cnt, s->d_tile_allow, s->d_tile_keep, s->d_keyT, s->d_tile_flag, epoch,
-                           s->d_seg_lstart, s->d_seg_gbase);
+                           s->d_seg_lstart, s->d_seg_gbase, s->d_group_base);
     HIPCK(hipGetLastError());
     if (mark(s, 4, timed)) return SM_E_HIP;
     return SM_OK;
@@ -527,7 +532,8 @@ sm_ctx *sm_create(const sm_config *c)
     ok = ok && dalloc(&s->d_cm, nwords) == SM_OK && dalloc(&s->d_dm, nwords) == SM_OK && dalloc(&s->d_zm, nwords) == SM_OK;
     ok = ok && dalloc(&s->d_tile_cnt, ntiles * 3) == SM_OK && dalloc(&s->d_tile_allow, ntiles) == SM_OK &&
          dalloc(&s->d_tile_keep, ntiles) == SM_OK && dalloc(&s->d_tile_flag, ntiles) == SM_OK &&
-         hipMemset(s->d_tile_flag, 0, ntiles * 4) == hipSuccess;
+         hipMemset(s->d_tile_flag, 0, ntiles * 4) == hipSuccess &&
+         dalloc(&s->d_group_tot, (ntiles / GROUP + 2) * 4) == SM_OK && dalloc(&s->d_group_base, ntiles / GROUP + 2) == SM_OK;
     ok = ok && dalloc(&s->d_validmask, (P + 63) / 64 + 4) == SM_OK && dalloc(&s->d_fusedmask, (P + 63) / 64 + 4) == SM_OK;
     ok = ok && dalloc(&s->d_blk_prefix, (size_t)s->n_pix_blocks) == SM_OK;
     if (!ok) { if (g_err.empty()) g_err = "sm_create: allocation failed"; sm_destroy(s); return nullptr; }
@@ -614,7 +620,7 @@ void sm_destroy(sm_ctx *s)
     (void)hipFree(s->d_rgb); (void)hipFree(s->d_sem); (void)hipFree(s->d_depth_raw); (void)hipFree(s->d_depth_f32);
     (void)hipFree(s->d_xs); (void)hipFree(s->d_ys); (void)hipFree(s->d_wtab);
     (void)hipFree(s->d_cm); (void)hipFree(s->d_dm); (void)hipFree(s->d_zm);
-    (void)hipFree(s->d_tile_cnt); (void)hipFree(s->d_tile_allow); (void)hipFree(s->d_tile_keep); (void)hipFree(s->d_tile_flag);
+    (void)hipFree(s->d_tile_cnt); (void)hipFree(s->d_tile_allow); (void)hipFree(s->d_tile_keep); (void)hipFree(s->d_tile_flag); (void)hipFree(s->d_group_tot); (void)hipFree(s->d_group_base);
     (void)hipFree(s->d_validmask); (void)hipFree(s->d_fusedmask); (void)hipFree(s->d_blk_prefix);
     (void)hipFree(s->d_seg_lstart); (void)hipFree(s->d_seg_gbase); (void)hipFree(s->d_gseg_base); (void)hipFree(s->d_seg_keep);
     if (s->d_export) (void)hipFree(s->d_export);
@@ -1108,7 +1114,7 @@ int sm_shard_conflict(sm_ctx *s, uint32_t exempt_local, const uint32_t *seg_lsta
     if ((rc = launch_conflict(s, fp, false))) return rc;
     if (nseg) {
         hipLaunchKernelGGL(k_seg_counts, dim3((nseg + 255) / 256), dim3(256), 0, s->stream, s->d_state, s->d_cm, s->d_dm, s->d_zm,
-                           s->d_tile_keep, s->d_seg_lstart, nseg, s->d_seg_keep);
+                           s->d_tile_keep, s->d_group_base, s->d_seg_lstart, nseg, s->d_seg_keep);
         HIPCK(hipGetLastError());
         HIPCK(hipMemcpyAsync(seg_keep_out, s->d_seg_keep, (size_t)nseg * 4, hipMemcpyDeviceToHost, s->stream));
     }

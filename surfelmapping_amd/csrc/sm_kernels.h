@@ -235,12 +235,13 @@ __global__ __launch_bounds__(256) void k_conflict(Model M, const DevState *__res
             bool conflict = false;
             if (valid) {
                 const float3 ph = xform3(fp.t_inv, v.x, v.y, v.z);
+                // the depth-range test first: it needs no division (conflict.vert:35 is one || chain)
+                if (!(ph.z <= fp.min_depth || ph.z >= fp.max_depth)) {
                 const float xl = ph.x / ph.z;
                 const float yl = ph.y / ph.z;
                 const float u = fp.fx * xl + fp.cx;
                 const float vv = fp.fy * yl + fp.cy;
-                if (!(u < fp.stereo_border || u > fp.cols || vv < 0.0f || vv > fp.rows ||
-                      ph.z <= fp.min_depth || ph.z >= fp.max_depth)) {
+                if (!(u < fp.stereo_border || u > fp.cols || vv < 0.0f || vv > fp.rows)) {
                     const float lambda = sqrtf((xl * xl + yl * yl) + 1.0f);
                     const int ti = tex_idx(u / fp.cols, fp.W), tj = tex_idx(vv / fp.rows, fp.H);
                     const size_t q = (size_t)ti * fp.H + tj;
@@ -249,6 +250,7 @@ __global__ __launch_bounds__(256) void k_conflict(Model M, const DevState *__res
                     if (sem == 10u) depth = fp.max_depth + 1.0f;
                     if (fp.is_clean == 0 && depth == 0.0f) depth = fp.max_depth + 20.0f;
                     conflict = (depth * lambda - ph.z * lambda > fp.conflict_thresh * ph.z) && (k != fp.exempt_local);
+                }
                 }
             }
             const bool dies = valid && !(v.w - 1.0f > 0.0f);
@@ -272,97 +274,136 @@ __global__ __launch_bounds__(256) void k_conflict(Model M, const DevState *__res
 }
 
 // ---------------------------------------------------------------------------------------------
-// Scan of the per-tile counts (single 1024-thread workgroup): applies the "first cap conflicts
-// only" rule (conflictVbo holds W*H records: src/GlobalModel.cpp:54-57), derives
-// the per-tile survivor prefix for the stable compaction (p4, back_map.geom:15-28) and publishes
-// the new count/offset in DevState.
+// Two-level scan of the per-tile counts -> survivor prefix for the stable compaction (p4,
+// back_map.geom:15-28), the new count/offset (src/GlobalModel.cpp:575) and the "first cap conflicts
+// only" rule (conflictVbo holds W*H records: src/GlobalModel.cpp:54-57).
+//   k_scan_cull      one workgroup per group of 1024 tiles: group-local exclusive prefixes + totals
+//   k_cull_finalize  one workgroup: scans the (<= a few hundred) group totals into group bases and
+//                    publishes DevState; if the conflict cap binds (rare) it redoes the scan
+//                    sequentially with the cap applied tile by tile (exact, straddling tile from masks)
+// consumers use  prefix(t) = tile_keep_prefix[t] + group_keep_base[t / 1024].
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_scan_cull(DevState *__restrict__ st, FrameParams fp,
-                                                    const uint64_t *__restrict__ cm,
-                                                    const uint64_t *__restrict__ dm,
-                                                    const uint64_t *__restrict__ zm,
+constexpr int GROUP = 1024;   // tiles per scan group
+
+__global__ __launch_bounds__(1024) void k_scan_cull(const DevState *__restrict__ st,
                                                     const uint32_t *__restrict__ tile_cnt,
                                                     uint32_t *__restrict__ tile_allow,
-                                                    uint32_t *__restrict__ tile_keep_prefix)
+                                                    uint32_t *__restrict__ tile_keep_prefix,
+                                                    uint32_t *__restrict__ group_tot /* [g][4]: conf, keep, first killing tile, - */)
 {
     __shared__ uint32_t s_scan[17];
+    __shared__ uint32_t s_first;
     const uint32_t N = st->count;
     const uint32_t ntiles = (N + TILE - 1) / TILE;
-    const uint32_t per = (ntiles + 1023u) / 1024u;
-    const uint32_t t0 = min(threadIdx.x * per, ntiles), t1 = min(t0 + per, ntiles);
-    // pass 1: conflicts
-    uint32_t csum = 0;
-#pragma unroll 8
-    for (uint32_t t = t0; t < t1; ++t) csum += tile_cnt[t * 3];
-    uint32_t ctotal;
-    uint32_t cpre = block_scan_1024(csum, &ctotal, s_scan);
-    // pass 2: allowed conflicts + effective kills per tile
-    const uint32_t cap = fp.conflict_cap;
-    uint32_t ksum = 0;
-#pragma unroll 4
-    for (uint32_t t = t0; t < t1; ++t) {
-        const uint32_t nconf = tile_cnt[t * 3];
-        uint32_t allow = nconf;
-        if (cpre >= cap) allow = 0;
-        else if (cap - cpre < nconf) allow = cap - cpre;
-        tile_allow[t] = allow;
-        uint32_t kills;
-        if (allow == nconf) kills = tile_cnt[t * 3 + 1];
-        else if (allow == 0) kills = tile_cnt[t * 3 + 2];
-        else {   // the one tile straddling the cap
-            kills = 0;
-            uint32_t rem = allow;
-            for (int w = 0; w < TILE_WORDS; ++w) {
-                const uint32_t word = t * TILE_WORDS + w;
-                if ((uint64_t)word * 64u >= N) break;
-                const uint64_t c = cm[word];
-                const uint64_t ce = first_n_bits(c, rem);
-                rem -= (uint32_t)__popcll(ce);
-                kills += (uint32_t)__popcll(zm[word] | (ce & dm[word]));
-            }
-        }
-        const uint32_t nvalid = min((uint32_t)TILE, N - t * TILE);
-        ksum += nvalid - kills;
-        cpre += nconf;
+    const uint32_t t = blockIdx.x * GROUP + threadIdx.x;
+    if (threadIdx.x == 0) s_first = 0xFFFFFFFFu;
+    uint32_t nconf = 0, keep = 0;
+    bool kills = false;
+    if (t < ntiles) {
+        nconf = tile_cnt[t * 3];
+        const uint32_t nkill = tile_cnt[t * 3 + 1];
+        keep = min((uint32_t)TILE, N - t * TILE) - nkill;
+        kills = nkill != 0;
+        tile_allow[t] = nconf;                  // every conflict takes effect unless the cap binds
     }
-    uint32_t ktotal, nstatic = 0;
-    uint32_t kpre = block_scan_1024(ksum, &ktotal, s_scan);
-#pragma unroll 4
-    for (uint32_t t = t0; t < t1; ++t) {
-        const uint32_t nconf = tile_cnt[t * 3];
-        const uint32_t allow = tile_allow[t];
-        uint32_t kills;
-        if (allow == nconf) kills = tile_cnt[t * 3 + 1];
-        else if (allow == 0) kills = tile_cnt[t * 3 + 2];
-        else {
-            kills = 0;
-            uint32_t rem = allow;
-            for (int w = 0; w < TILE_WORDS; ++w) {
-                const uint32_t word = t * TILE_WORDS + w;
-                if ((uint64_t)word * 64u >= N) break;
-                const uint64_t c = cm[word];
-                const uint64_t ce = first_n_bits(c, rem);
-                rem -= (uint32_t)__popcll(ce);
-                kills += (uint32_t)__popcll(zm[word] | (ce & dm[word]));
-            }
-        }
-        tile_keep_prefix[t] = kpre;
-        const uint32_t nv = min((uint32_t)TILE, N - t * TILE);
-        if (kpre == t * TILE && kills == 0) nstatic += nv;
-        kpre += nv - kills;
-    }
-    uint32_t stotal;
-    block_scan_1024(nstatic, &stotal, s_scan);
+    uint32_t ctot, ktot;
+    block_scan_1024(nconf, &ctot, s_scan);
+    const uint32_t kpre = block_scan_1024(keep, &ktot, s_scan);
+    if (kills) atomicMin(&s_first, t);
+    if (t < ntiles) tile_keep_prefix[t] = kpre;
+    __syncthreads();
     if (threadIdx.x == 0) {
-        st->n_static = stotal;
+        group_tot[blockIdx.x * 4 + 0] = ctot;
+        group_tot[blockIdx.x * 4 + 1] = ktot;
+        group_tot[blockIdx.x * 4 + 2] = s_first;
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_cull_finalize(DevState *__restrict__ st, FrameParams fp,
+                                                        const uint64_t *__restrict__ cm,
+                                                        const uint64_t *__restrict__ dm,
+                                                        const uint64_t *__restrict__ zm,
+                                                        const uint32_t *__restrict__ tile_cnt,
+                                                        uint32_t *__restrict__ tile_allow,
+                                                        uint32_t *__restrict__ tile_keep_prefix,
+                                                        const uint32_t *__restrict__ group_tot,
+                                                        uint32_t *__restrict__ group_keep_base)
+{
+    __shared__ uint32_t s_scan[17];
+    __shared__ uint32_t s_first;
+    const uint32_t N = st->count;
+    const uint32_t ntiles = (N + TILE - 1) / TILE;
+    const uint32_t ngroups = (ntiles + GROUP - 1) / GROUP;
+    const uint32_t cap = fp.conflict_cap;
+    if (threadIdx.x == 0) s_first = 0xFFFFFFFFu;
+    __syncthreads();
+    // ---- fast path: scan the group totals (ngroups <= 1024 covers 1 G surfels)
+    uint32_t gc = 0, gk = 0;
+    if (threadIdx.x < ngroups) {
+        gc = group_tot[threadIdx.x * 4 + 0];
+        gk = group_tot[threadIdx.x * 4 + 1];
+        atomicMin(&s_first, group_tot[threadIdx.x * 4 + 2]);
+    }
+    uint32_t ctotal, ktotal;
+    block_scan_1024(gc, &ctotal, s_scan);
+    const uint32_t gkpre = block_scan_1024(gk, &ktotal, s_scan);
+    uint32_t nstatic = (s_first == 0xFFFFFFFFu) ? N : min(N, s_first * (uint32_t)TILE);
+    if (ctotal <= cap) {
+        if (threadIdx.x < ngroups) group_keep_base[threadIdx.x] = gkpre;
+    } else {
+        // ---- slow path: the cap binds; exact sequential-order scan with absolute prefixes
+        if (threadIdx.x < ngroups) group_keep_base[threadIdx.x] = 0;
+        const uint32_t per = (ntiles + 1023u) / 1024u;
+        const uint32_t t0 = min(threadIdx.x * per, ntiles), t1 = min(t0 + per, ntiles);
+        uint32_t csum = 0;
+        for (uint32_t t = t0; t < t1; ++t) csum += tile_cnt[t * 3];
+        uint32_t dummy;
+        uint32_t cpre = block_scan_1024(csum, &dummy, s_scan);
+        uint32_t ksum = 0;
+        for (uint32_t t = t0; t < t1; ++t) {
+            const uint32_t nconf = tile_cnt[t * 3];
+            uint32_t allow = nconf;
+            if (cpre >= cap) allow = 0;
+            else if (cap - cpre < nconf) allow = cap - cpre;
+            tile_allow[t] = allow;
+            uint32_t kills;
+            if (allow == nconf) kills = tile_cnt[t * 3 + 1];
+            else if (allow == 0) kills = tile_cnt[t * 3 + 2];
+            else {   // the one tile straddling the cap
+                kills = 0;
+                uint32_t rem = allow;
+                for (int w = 0; w < TILE_WORDS; ++w) {
+                    const uint32_t word = t * TILE_WORDS + w;
+                    if ((uint64_t)word * 64u >= N) break;
+                    const uint64_t c = cm[word];
+                    const uint64_t ce = first_n_bits(c, rem);
+                    rem -= (uint32_t)__popcll(ce);
+                    kills += (uint32_t)__popcll(zm[word] | (ce & dm[word]));
+                }
+            }
+            tile_keep_prefix[t] = kills;          // parked: rewritten with the prefix below
+            ksum += min((uint32_t)TILE, N - t * TILE) - kills;
+            cpre += nconf;
+        }
+        uint32_t kpre = block_scan_1024(ksum, &ktotal, s_scan);
+        uint32_t ns = 0;
+        for (uint32_t t = t0; t < t1; ++t) {
+            const uint32_t kills = tile_keep_prefix[t];
+            const uint32_t nv = min((uint32_t)TILE, N - t * TILE);
+            if (kpre == t * TILE && kills == 0) ns += nv;
+            tile_keep_prefix[t] = kpre;
+            kpre += nv - kills;
+        }
+        block_scan_1024(ns, &nstatic, s_scan);
+    }
+    if (threadIdx.x == 0) {
         const uint32_t kept = ktotal;
-        const uint32_t nk = N - kept;
+        st->n_static = nstatic;
         st->cull_n = N;
-        st->n_kill = nk;
+        st->n_kill = N - kept;
         st->conflict_count = min(ctotal, cap);
         st->cull_src = st->cur;
         st->cull_dst = st->cur;                           // compaction is in place
-        st->cur = st->cull_dst;
         st->count = kept;                                 // src/GlobalModel.cpp:575
         st->offset = kept;
         if (fp.splat_follows) st->visible_count = 0;
@@ -421,7 +462,8 @@ __global__ __launch_bounds__(256) void k_compact(Model M, DevState *__restrict__
                                                  uint64_t *__restrict__ keyT,
                                                  uint32_t *__restrict__ tile_flag, uint32_t epoch,
                                                  const uint32_t *__restrict__ seg_lstart,
-                                                 const uint32_t *__restrict__ seg_gbase)
+                                                 const uint32_t *__restrict__ seg_gbase,
+                                                 const uint32_t *__restrict__ group_keep_base)
 {
     __shared__ uint64_t s_keep[TILE_WORDS], s_ceff[TILE_WORDS];
     __shared__ uint32_t s_cpop[TILE_WORDS], s_kpre[TILE_WORDS + 1];
@@ -463,7 +505,7 @@ __global__ __launch_bounds__(256) void k_compact(Model M, DevState *__restrict__
             s_kpre[threadIdx.x] = before;                 // s_kpre[TILE_WORDS] = survivors of the tile
         }
         __syncthreads();
-        const uint32_t base_id = tile_keep_prefix[tile];
+        const uint32_t base_id = tile_keep_prefix[tile] + group_keep_base[tile / GROUP];
         const uint32_t kcount = s_kpre[TILE_WORDS];
         const uint32_t nvalid = min((uint32_t)TILE, N - tile * TILE);
         const bool moving = (base_id != tile * TILE) || (kcount != nvalid);   // block-uniform
@@ -724,31 +766,30 @@ __global__ __launch_bounds__(1024) void k_scan_new(DevState *__restrict__ st, Fr
     __shared__ uint32_t s_scan[17];
     const uint32_t nb = (uint32_t)nblocks;
     const uint32_t nwords = ((uint32_t)fp.P + 63u) >> 6;
-    const uint32_t per = (nb + 1023u) / 1024u;
-    const uint32_t b0 = min(threadIdx.x * per, nb), b1 = min(b0 + per, nb);
-    uint32_t ns = 0, fs = 0;
-    for (uint32_t b = b0; b < b1; ++b) {
+    uint32_t ncarry = 0, fcarry = 0;
+    // rounds of 1024 pixel blocks, thread <-> block: the 4+4 mask words of a block are one 32-byte run
+    for (uint32_t b0 = 0; b0 < nb; b0 += 1024u) {
+        const uint32_t b = b0 + threadIdx.x;
+        uint32_t ns = 0, fs = 0;
+        if (b < nb) {
 #pragma unroll
-        for (uint32_t w = 0; w < PIX_BLOCK / 64; ++w) {
-            const uint32_t word = b * (PIX_BLOCK / 64) + w;
-            if (word < nwords) {
-                const uint64_t v = validmask[word], f = fusedmask[word];
-                ns += (uint32_t)__popcll(v & ~f);
-                fs += (uint32_t)__popcll(f);
+            for (uint32_t w = 0; w < PIX_BLOCK / 64; ++w) {
+                const uint32_t word = b * (PIX_BLOCK / 64) + w;
+                if (word < nwords) {
+                    const uint64_t v = validmask[word], f = fusedmask[word];
+                    ns += (uint32_t)__popcll(v & ~f);
+                    fs += (uint32_t)__popcll(f);
+                }
             }
         }
+        uint32_t nt, ft;
+        const uint32_t npre = block_scan_1024(ns, &nt, s_scan);
+        block_scan_1024(fs, &ft, s_scan);
+        if (b < nb) blk_prefix[b] = ncarry + npre;
+        ncarry += nt;
+        fcarry += ft;
     }
-    uint32_t ntot, ftot;
-    uint32_t npre = block_scan_1024(ns, &ntot, s_scan);
-    block_scan_1024(fs, &ftot, s_scan);
-    for (uint32_t b = b0; b < b1; ++b) {
-        blk_prefix[b] = npre;
-#pragma unroll
-        for (uint32_t w = 0; w < PIX_BLOCK / 64; ++w) {
-            const uint32_t word = b * (PIX_BLOCK / 64) + w;
-            if (word < nwords) npre += (uint32_t)__popcll(validmask[word] & ~fusedmask[word]);
-        }
-    }
+    const uint32_t ntot = ncarry, ftot = fcarry;
     if (threadIdx.x == 0) {
         st->unstable_count = ntot;
         st->fused_count = ftot;
@@ -813,8 +854,8 @@ __global__ __launch_bounds__(PIX_BLOCK) void k_append(Model M, const DevState *_
 // is off in sharded runs, so keep = ~(zm | cm & dm))
 __global__ void k_seg_counts(const DevState *__restrict__ st, const uint64_t *__restrict__ cm,
                              const uint64_t *__restrict__ dm, const uint64_t *__restrict__ zm,
-                             const uint32_t *__restrict__ tile_keep_prefix, const uint32_t *__restrict__ seg_lstart,
-                             int nseg, uint32_t *__restrict__ out)
+                             const uint32_t *__restrict__ tile_keep_prefix, const uint32_t *__restrict__ group_keep_base,
+                             const uint32_t *__restrict__ seg_lstart, int nseg, uint32_t *__restrict__ out)
 {
     const int sidx = blockIdx.x * blockDim.x + threadIdx.x;
     if (sidx >= nseg) return;
@@ -822,7 +863,7 @@ __global__ void k_seg_counts(const DevState *__restrict__ st, const uint64_t *__
     auto kept_before = [&](uint32_t x) -> uint32_t {
         if (x >= N) return st->count;                       // k_scan_cull already published the survivor total
         const uint32_t tile = x / TILE, within = x % TILE;
-        uint32_t sum = tile_keep_prefix[tile];
+        uint32_t sum = tile_keep_prefix[tile] + group_keep_base[tile / GROUP];
         const uint32_t w0 = tile * TILE_WORDS;
         for (uint32_t w = 0; w <= within / 64; ++w) {
             const uint32_t word = w0 + w;
