@@ -225,36 +225,57 @@ __global__ __launch_bounds__(256) void k_conflict(Model M, const DevState *__res
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         uint32_t nconf = 0, nkill = 0, nzero = 0;
+        // phase 1: all four 16-byte loads of the lane in flight together
+        float4 v[4];
+        bool valid[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const uint32_t k = (tile * TILE_WORDS + r * 4 + wave) * 64u + lane;
+            valid[r] = k < N;
+            v[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (valid[r]) v[r] = pc[k];
+        }
+        // phase 2: projection + view test; phase 3: the dependent depth/class gathers, again together
+        float zc[4], lam[4], dep[4];
+        uint32_t cls[4];
+        bool inview[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            inview[r] = false; zc[r] = 0.f; lam[r] = 0.f; dep[r] = 0.f; cls[r] = 0u;
+            if (valid[r]) {
+                const float3 ph = xform3(fp.t_inv, v[r].x, v[r].y, v[r].z);
+                // the depth-range test first: it needs no division (conflict.vert:35 is one || chain)
+                if (!(ph.z <= fp.min_depth || ph.z >= fp.max_depth)) {
+                    const float xl = ph.x / ph.z;
+                    const float yl = ph.y / ph.z;
+                    const float u = fp.fx * xl + fp.cx;
+                    const float vv = fp.fy * yl + fp.cy;
+                    if (!(u < fp.stereo_border || u > fp.cols || vv < 0.0f || vv > fp.rows)) {
+                        const int ti = tex_idx(u / fp.cols, fp.W), tj = tex_idx(vv / fp.rows, fp.H);
+                        const size_t q = (size_t)ti * fp.H + tj;
+                        dep[r] = depthT[q];
+                        cls[r] = rgbsT[q] >> 24;
+                        lam[r] = sqrtf((xl * xl + yl * yl) + 1.0f);
+                        zc[r] = ph.z;
+                        inview[r] = true;
+                    }
+                }
+            }
+        }
+        // phase 4: conflict rule + ballots
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const uint32_t word = tile * TILE_WORDS + r * 4 + wave;
             const uint32_t k = word * 64u + lane;
-            const bool valid = k < N;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (valid) v = pc[k];
             bool conflict = false;
-            if (valid) {
-                const float3 ph = xform3(fp.t_inv, v.x, v.y, v.z);
-                // the depth-range test first: it needs no division (conflict.vert:35 is one || chain)
-                if (!(ph.z <= fp.min_depth || ph.z >= fp.max_depth)) {
-                const float xl = ph.x / ph.z;
-                const float yl = ph.y / ph.z;
-                const float u = fp.fx * xl + fp.cx;
-                const float vv = fp.fy * yl + fp.cy;
-                if (!(u < fp.stereo_border || u > fp.cols || vv < 0.0f || vv > fp.rows)) {
-                    const float lambda = sqrtf((xl * xl + yl * yl) + 1.0f);
-                    const int ti = tex_idx(u / fp.cols, fp.W), tj = tex_idx(vv / fp.rows, fp.H);
-                    const size_t q = (size_t)ti * fp.H + tj;
-                    float depth = depthT[q];
-                    const uint32_t sem = rgbsT[q] >> 24;
-                    if (sem == 10u) depth = fp.max_depth + 1.0f;
-                    if (fp.is_clean == 0 && depth == 0.0f) depth = fp.max_depth + 20.0f;
-                    conflict = (depth * lambda - ph.z * lambda > fp.conflict_thresh * ph.z) && (k != fp.exempt_local);
-                }
-                }
+            if (inview[r]) {
+                float depth = dep[r];
+                if (cls[r] == 10u) depth = fp.max_depth + 1.0f;
+                if (fp.is_clean == 0 && depth == 0.0f) depth = fp.max_depth + 20.0f;
+                conflict = (depth * lam[r] - zc[r] * lam[r] > fp.conflict_thresh * zc[r]) && (k != fp.exempt_local);
             }
-            const bool dies = valid && !(v.w - 1.0f > 0.0f);
-            const bool dead = valid && !(v.w > 0.0f);
+            const bool dies = valid[r] && !(v[r].w - 1.0f > 0.0f);
+            const bool dead = valid[r] && !(v[r].w > 0.0f);
             const uint64_t cw = __ballot(conflict), dw = __ballot(dies), zw = __ballot(dead);
             if (lane == 0 && (uint64_t)word * 64u < N) {
                 cm[word] = cw; dm[word] = dw; zm[word] = zw;
@@ -782,14 +803,15 @@ __global__ __launch_bounds__(1024) void k_scan_new(DevState *__restrict__ st, Fr
                 }
             }
         }
-        uint32_t nt, ft;
+        uint32_t nt;
         const uint32_t npre = block_scan_1024(ns, &nt, s_scan);
-        block_scan_1024(fs, &ft, s_scan);
         if (b < nb) blk_prefix[b] = ncarry + npre;
         ncarry += nt;
-        fcarry += ft;
+        fcarry += fs;                              // per-thread partial, reduced once below
     }
-    const uint32_t ntot = ncarry, ftot = fcarry;
+    uint32_t ftot;
+    block_scan_1024(fcarry, &ftot, s_scan);
+    const uint32_t ntot = ncarry;
     if (threadIdx.x == 0) {
         st->unstable_count = ntot;
         st->fused_count = ftot;
