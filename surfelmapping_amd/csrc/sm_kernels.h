@@ -232,16 +232,15 @@ __global__ __launch_bounds__(256) void k_conflict(Model M, const DevState *__res
         for (int r = 0; r < 4; ++r) {
             const uint32_t k = (tile * TILE_WORDS + r * 4 + wave) * 64u + lane;
             valid[r] = k < N;
-            v[r] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (valid[r]) v[r] = pc[k];
+            v[r] = pc[min(k, N - 1u)];          // unconditional (clamped): a branch here would serialise the loads
         }
         // phase 2: projection + view test; phase 3: the dependent depth/class gathers, again together
         float zc[4], lam[4], dep[4];
-        uint32_t cls[4];
+        uint32_t cls[4], qq[4];
         bool inview[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            inview[r] = false; zc[r] = 0.f; lam[r] = 0.f; dep[r] = 0.f; cls[r] = 0u;
+            inview[r] = false; zc[r] = 0.f; lam[r] = 0.f; qq[r] = 0u;
             if (valid[r]) {
                 const float3 ph = xform3(fp.t_inv, v[r].x, v[r].y, v[r].z);
                 // the depth-range test first: it needs no division (conflict.vert:35 is one || chain)
@@ -252,15 +251,18 @@ __global__ __launch_bounds__(256) void k_conflict(Model M, const DevState *__res
                     const float vv = fp.fy * yl + fp.cy;
                     if (!(u < fp.stereo_border || u > fp.cols || vv < 0.0f || vv > fp.rows)) {
                         const int ti = tex_idx(u / fp.cols, fp.W), tj = tex_idx(vv / fp.rows, fp.H);
-                        const size_t q = (size_t)ti * fp.H + tj;
-                        dep[r] = depthT[q];
-                        cls[r] = rgbsT[q] >> 24;
+                        qq[r] = (uint32_t)(ti * fp.H + tj);
                         lam[r] = sqrtf((xl * xl + yl * yl) + 1.0f);
                         zc[r] = ph.z;
                         inview[r] = true;
                     }
                 }
             }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {                 // gathers, unconditional (pixel 0 for out-of-view lanes)
+            dep[r] = depthT[qq[r]];
+            cls[r] = rgbsT[qq[r]] >> 24;
         }
         // phase 4: conflict rule + ballots
 #pragma unroll
@@ -543,15 +545,19 @@ __global__ __launch_bounds__(256) void k_compact(Model M, DevState *__restrict__
             const uint32_t k = (tile * TILE_WORDS + w) * 64u + lane;
             kept[r] = (keepw >> lane) & 1ull;
             nid[r] = base_id + s_kpre[w] + (uint32_t)__popcll(keepw & ((1ull << lane) - 1ull));
-            v[r] = make_float4(0.f, 0.f, 0.f, 0.f); nr[r] = v[r]; col[r] = 0; it[r] = 0.f; tl[r] = 0.f;
-            if (kept[r]) {
-                v[r] = set.pos_conf[k];
-                tl[r] = set.time[k];
-                if (moving) { nr[r] = set.norm_rad[k]; col[r] = set.color[k]; it[r] = set.init_time[k]; }
-                if ((s_ceff[w] >> lane) & 1ull) {
-                    v[r].w -= 1.0f;                       // conflict.vert:72
-                    if (!moving) set.pos_conf[k].w = v[r].w;
-                }
+            // unconditional, clamped loads: a per-lane branch would serialise them behind s_waitcnt
+            const uint32_t kc = min(k, N - 1u);
+            v[r] = set.pos_conf[kc];
+            tl[r] = set.time[kc];
+            nr[r] = make_float4(0.f, 0.f, 0.f, 0.f); col[r] = 0; it[r] = 0.f;
+            if (moving) { nr[r] = set.norm_rad[kc]; col[r] = set.color[kc]; it[r] = set.init_time[kc]; }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int w = r * 4 + wave;
+            if (kept[r] && ((s_ceff[w] >> lane) & 1ull)) {
+                v[r].w -= 1.0f;                           // conflict.vert:72
+                if (!moving) set.pos_conf[(tile * TILE_WORDS + w) * 64u + lane].w = v[r].w;
             }
         }
         if (moving) {
