@@ -219,6 +219,7 @@ __global__ __launch_bounds__(256) void k_conflict(Model M, const DevState *__res
                                                   uint64_t *__restrict__ zm, uint32_t *__restrict__ tile_cnt)
 {
     __shared__ uint32_t s_red[4][3];
+    __shared__ uint64_t s_m[3][TILE_WORDS];
     const uint32_t N = st->count;
     const float4 *__restrict__ pc = M.s[st->cur].pos_conf;
     const uint32_t ntiles = (N + TILE - 1) / TILE;
@@ -279,9 +280,7 @@ __global__ __launch_bounds__(256) void k_conflict(Model M, const DevState *__res
             const bool dies = valid[r] && !(v[r].w - 1.0f > 0.0f);
             const bool dead = valid[r] && !(v[r].w > 0.0f);
             const uint64_t cw = __ballot(conflict), dw = __ballot(dies), zw = __ballot(dead);
-            if (lane == 0 && (uint64_t)word * 64u < N) {
-                cm[word] = cw; dm[word] = dw; zm[word] = zw;
-            }
+            if (lane == 0) { s_m[0][r * 4 + wave] = cw; s_m[1][r * 4 + wave] = dw; s_m[2][r * 4 + wave] = zw; }
             nconf += __popcll(cw);
             nkill += __popcll(zw | (cw & dw));
             nzero += __popcll(zw);
@@ -291,6 +290,15 @@ __global__ __launch_bounds__(256) void k_conflict(Model M, const DevState *__res
         if (threadIdx.x < 3) {
             tile_cnt[tile * 3 + threadIdx.x] = s_red[0][threadIdx.x] + s_red[1][threadIdx.x] +
                                                s_red[2][threadIdx.x] + s_red[3][threadIdx.x];
+        }
+        if (threadIdx.x >= 64 && threadIdx.x < 64 + 3 * TILE_WORDS) {
+            // one store instruction for the tile's 3 x 16 ballot words (48 lanes, three 128-byte runs)
+            const int m = (threadIdx.x - 64) / TILE_WORDS, w = (threadIdx.x - 64) % TILE_WORDS;
+            const uint32_t word = tile * TILE_WORDS + w;
+            if ((uint64_t)word * 64u < N) {
+                uint64_t *dst = m == 0 ? cm : (m == 1 ? dm : zm);
+                dst[word] = s_m[m][w];
+            }
         }
         __syncthreads();
     }
