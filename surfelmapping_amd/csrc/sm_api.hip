@@ -140,6 +140,10 @@ struct sm_ctx {
     // association scratch
     uint64_t *d_validmask = nullptr, *d_fusedmask = nullptr;
     uint32_t *d_blk_prefix = nullptr;
+    unsigned long long *d_desc = nullptr;   // look-back granules of k_associate_append
+    uint32_t assoc_epoch = 0;
+    int assoc_grid = 1024;
+    bool force_three_kernel = false;
     // multi-GPU segment tables (device copies; nseg == 0 on a single GPU)
     uint32_t *d_seg_lstart = nullptr, *d_seg_gbase = nullptr, *d_gseg_base = nullptr, *d_seg_keep = nullptr;
     uint32_t seg_cap = 0;
@@ -341,8 +345,25 @@ int launch_append(sm_ctx *s, const FrameParams &fp, bool timed)
     return SM_OK;
 }
 
+// single-GPU form: association + ordered append in one persistent kernel (decoupled look-back)
+int launch_associate_fused(sm_ctx *s, const FrameParams &fp, bool timed)
+{
+    if ((++s->assoc_epoch & 0xFFFFu) == 0) {      // the 16-bit granule tag wrapped: retire all old granules
+        HIPCK(hipMemsetAsync(s->d_desc, 0, (size_t)s->n_pix_blocks * 8, s->stream));
+        s->assoc_epoch++;
+    }
+    const int grid = std::min(s->n_pix_blocks, s->assoc_grid);
+    hipLaunchKernelGGL(k_associate_append, dim3(grid), dim3(PIX_BLOCK), 0, s->stream, s->M, s->d_state, fp, s->d_depthT,
+                       s->d_rgbsT, s->d_keyT, s->d_xs, s->d_ys, s->d_desc, s->assoc_epoch, s->n_pix_blocks, s->d_log);
+    HIPCK(hipGetLastError());
+    if (mark(s, 5, timed) || mark(s, 6, timed) || mark(s, 7, timed)) return SM_E_HIP;
+    return SM_OK;
+}
+
 int launch_associate(sm_ctx *s, const FrameParams &fp, bool timed)
 {
+    // 23-bit counters in the granule: images above 8 Mpixel keep the three-kernel form
+    if (s->sh_world <= 1 && s->P < (1 << 23) && !s->force_three_kernel) return launch_associate_fused(s, fp, timed);
     int rc = launch_associate_only(s, fp);
     if (rc) return rc;
     if (mark(s, 5, timed)) return SM_E_HIP;
@@ -535,7 +556,8 @@ sm_ctx *sm_create(const sm_config *c)
          hipMemset(s->d_tile_flag, 0, ntiles * 4) == hipSuccess &&
          dalloc(&s->d_group_tot, (ntiles / GROUP + 2) * 4) == SM_OK && dalloc(&s->d_group_base, ntiles / GROUP + 2) == SM_OK;
     ok = ok && dalloc(&s->d_validmask, (P + 63) / 64 + 4) == SM_OK && dalloc(&s->d_fusedmask, (P + 63) / 64 + 4) == SM_OK;
-    ok = ok && dalloc(&s->d_blk_prefix, (size_t)s->n_pix_blocks) == SM_OK;
+    ok = ok && dalloc(&s->d_blk_prefix, (size_t)s->n_pix_blocks) == SM_OK && dalloc(&s->d_desc, (size_t)s->n_pix_blocks) == SM_OK &&
+         hipMemset(s->d_desc, 0, (size_t)s->n_pix_blocks * 8) == hipSuccess;
     if (!ok) { if (g_err.empty()) g_err = "sm_create: allocation failed"; sm_destroy(s); return nullptr; }
 
     // pixel-centre coordinates exactly as data.vert sees them:
@@ -591,7 +613,11 @@ sm_ctx *sm_create(const sm_config *c)
     if (!ok) { g_err = "sm_create: device initialisation failed"; sm_destroy(s); return nullptr; }
     {
         // the in-place compaction needs every workgroup of k_compact resident at once
-        int cus = 0, per_cu = 0;
+        int cus = 0, per_cu = 0, per_cu_a = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess && cus > 0 &&
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_a, k_associate_append, PIX_BLOCK, 0) == hipSuccess && per_cu_a > 0)
+            s->assoc_grid = std::max(1, cus * std::min(4, std::max(1, per_cu_a - 1)));
+        s->force_three_kernel = std::getenv("SM_THREE_KERNEL_ASSOC") != nullptr;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess && cus > 0 &&
             hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_compact<true>, 256, 0) == hipSuccess && per_cu > 0) {
             // the occupancy API can over-report by one block per CU (MI355X_MICROARCH.md): stay at <= 4 and below it
@@ -621,7 +647,7 @@ void sm_destroy(sm_ctx *s)
     (void)hipFree(s->d_xs); (void)hipFree(s->d_ys); (void)hipFree(s->d_wtab);
     (void)hipFree(s->d_cm); (void)hipFree(s->d_dm); (void)hipFree(s->d_zm);
     (void)hipFree(s->d_tile_cnt); (void)hipFree(s->d_tile_allow); (void)hipFree(s->d_tile_keep); (void)hipFree(s->d_tile_flag); (void)hipFree(s->d_group_tot); (void)hipFree(s->d_group_base);
-    (void)hipFree(s->d_validmask); (void)hipFree(s->d_fusedmask); (void)hipFree(s->d_blk_prefix);
+    (void)hipFree(s->d_validmask); (void)hipFree(s->d_fusedmask); (void)hipFree(s->d_blk_prefix); (void)hipFree(s->d_desc);
     (void)hipFree(s->d_seg_lstart); (void)hipFree(s->d_seg_gbase); (void)hipFree(s->d_gseg_base); (void)hipFree(s->d_seg_keep);
     if (s->d_export) (void)hipFree(s->d_export);
     for (void *p : s->user_allocs) (void)hipFree(p);

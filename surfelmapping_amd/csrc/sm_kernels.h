@@ -707,23 +707,19 @@ __device__ __forceinline__ bool local_surfel(int q, const FrameParams &fp, const
     return true;
 }
 
-// Association + in-place fuse (p8 + p9 + p10).  Every surfel id occupies at most one key-map
-// pixel, so the read-modify-write of surfel `id` by this thread is race-free.
-// New surfels are only flagged here (ballot word per wave) and counted per block.
-__global__ __launch_bounds__(PIX_BLOCK) void k_associate(Model M, const DevState *__restrict__ st, FrameParams fp,
-                                                         const float *__restrict__ depthT,
-                                                         const uint32_t *__restrict__ rgbsT,
-                                                         const uint64_t *__restrict__ keyT,
-                                                         const float *__restrict__ xs, const float *__restrict__ ys,
-                                                         uint64_t *__restrict__ validmask, uint64_t *__restrict__ fusedmask,
-                                                         const uint32_t *__restrict__ gseg_base,
-                                                         const uint32_t *__restrict__ seg_lstart)
+// Association + in-place fuse (p8 + p9 + p10) of pixel q.  Every surfel id occupies at most one
+// key-map pixel, so the read-modify-write of surfel `id` by this thread is race-free.
+// Returns is_valid (candidate pixel) / is_fused (matched and fused into an existing surfel);
+// a valid, not fused pixel is a new surfel described by L.
+__device__ __forceinline__ void associate_pixel(int q, const SurfelSet &cur, const FrameParams &fp,
+                                                const float *__restrict__ depthT, const uint32_t *__restrict__ rgbsT,
+                                                const uint64_t *__restrict__ keyT, const float *__restrict__ xs,
+                                                const float *__restrict__ ys, const uint32_t *__restrict__ gseg_base,
+                                                const uint32_t *__restrict__ seg_lstart, LocalSurfel &L, bool &is_valid,
+                                                bool &is_fused)
 {
-    const SurfelSet cur = M.s[st->cur];
-    const int q = blockIdx.x * PIX_BLOCK + threadIdx.x;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    bool is_valid = false, is_fused = false;
-    LocalSurfel L;
+    is_valid = false;
+    is_fused = false;
     if (q < fp.P && local_surfel(q, fp, depthT, rgbsT, xs, ys, L)) {
         is_valid = true;
         const uint64_t key = keyT[q];
@@ -781,12 +777,155 @@ __global__ __launch_bounds__(PIX_BLOCK) void k_associate(Model M, const DevState
             }
         }
     }
+}
+
+// data.vert:210-225: the new surfel of a valid, unmatched pixel, written to model slot `slot`
+__device__ __forceinline__ void write_new_surfel(const SurfelSet &cur, uint32_t slot, const LocalSurfel &L, const FrameParams &fp)
+{
+    const float3 pw = xform3(fp.pose, L.pos.x, L.pos.y, L.pos.z);
+    const float3 nw = normalize3(rot3(fp.pose, L.nrm.x, L.nrm.y, L.nrm.z));
+    cur.pos_conf[slot] = make_float4(pw.x, pw.y, pw.z, 0.9f);
+    cur.norm_rad[slot] = make_float4(nw.x, nw.y, nw.z, L.radius);
+    cur.color[slot] = encode_color(L.cr, L.cg, L.cb, L.sem);
+    cur.init_time[slot] = (float)fp.time;
+    cur.time[slot] = (float)fp.time;
+}
+
+// Three-kernel form (used when a reduction over ranks must happen between association and append):
+// new surfels are only flagged here (two ballot words per wave).
+__global__ __launch_bounds__(PIX_BLOCK) void k_associate(Model M, const DevState *__restrict__ st, FrameParams fp,
+                                                         const float *__restrict__ depthT,
+                                                         const uint32_t *__restrict__ rgbsT,
+                                                         const uint64_t *__restrict__ keyT,
+                                                         const float *__restrict__ xs, const float *__restrict__ ys,
+                                                         uint64_t *__restrict__ validmask, uint64_t *__restrict__ fusedmask,
+                                                         const uint32_t *__restrict__ gseg_base,
+                                                         const uint32_t *__restrict__ seg_lstart)
+{
+    const SurfelSet cur = M.s[st->cur];
+    const int q = blockIdx.x * PIX_BLOCK + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    bool is_valid, is_fused;
+    LocalSurfel L;
+    associate_pixel(q, cur, fp, depthT, rgbsT, keyT, xs, ys, gseg_base, seg_lstart, L, is_valid, is_fused);
     // two ballot words per wave: candidate pixels, and pixels fused by THIS rank (disjoint across ranks,
     // so a sum-reduction of the words over the ranks is their union)
     const uint64_t vw = __ballot(is_valid), fw = __ballot(is_fused);
     if (lane == 0) {
         const int word = blockIdx.x * (PIX_BLOCK / 64) + wave;
         if (word * 64 < fp.P) { validmask[word] = vw; fusedmask[word] = fw; }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Single-kernel form: association + in-place fuse + ORDERED append of the new surfels (p8..p11).
+// Persistent workgroups take pixel blocks round-robin in increasing order; the position of a
+// block's new surfels in the model is offset + (new surfels of all lower blocks), obtained with a
+// decoupled look-back over 8-byte granules {epoch:16 | status:2 | new:23 | fused:23}: a block
+// publishes its AGGREGATE, sums the granules of its predecessors 64 at a time (one per lane) down
+// to the first PREFIX, publishes its own PREFIX, then writes its surfels -- still in registers --
+// straight to their final slots (pixel order = src/GlobalModel.cpp:67-74 order).  A granule is
+// written by one sc1 8-byte store and polled with sc1 loads (MI355X_MICROARCH.md, hand-off
+// granules); blocks only wait for lower-numbered blocks and the grid is fully co-resident.
+// ---------------------------------------------------------------------------------------------
+constexpr uint64_t G_AGG = 1, G_PREFIX = 2;
+
+__device__ __forceinline__ uint64_t granule(uint32_t epoch, uint64_t status, uint32_t nnew, uint32_t nfused)
+{
+    return ((uint64_t)(epoch & 0xFFFFu) << 48) | (status << 46) | ((uint64_t)(nnew & 0x7FFFFFu) << 23) | (uint64_t)(nfused & 0x7FFFFFu);
+}
+
+__global__ __launch_bounds__(PIX_BLOCK) void k_associate_append(Model M, DevState *__restrict__ st, FrameParams fp,
+                                                                const float *__restrict__ depthT,
+                                                                const uint32_t *__restrict__ rgbsT,
+                                                                const uint64_t *__restrict__ keyT,
+                                                                const float *__restrict__ xs, const float *__restrict__ ys,
+                                                                unsigned long long *__restrict__ desc, uint32_t epoch, int nblocks,
+                                                                FrameLog *__restrict__ log)
+{
+    __shared__ uint64_t s_nw[4];
+    __shared__ uint32_t s_f[4];
+    __shared__ uint32_t s_excl[2];
+    const SurfelSet cur = M.s[st->cur];
+    const uint32_t offset = st->offset;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int b = blockIdx.x; b < nblocks; b += gridDim.x) {
+        const int q = b * PIX_BLOCK + threadIdx.x;
+        bool is_valid, is_fused;
+        LocalSurfel L;
+        associate_pixel(q, cur, fp, depthT, rgbsT, keyT, xs, ys, nullptr, nullptr, L, is_valid, is_fused);
+        const bool is_new = is_valid && !is_fused;
+        const uint64_t nw = __ballot(is_new), fw = __ballot(is_fused);
+        if (lane == 0) { s_nw[wave] = nw; s_f[wave] = (uint32_t)__popcll(fw); }
+        __syncthreads();
+        const uint32_t own_new = (uint32_t)(__popcll(s_nw[0]) + __popcll(s_nw[1]) + __popcll(s_nw[2]) + __popcll(s_nw[3]));
+        const uint32_t own_f = s_f[0] + s_f[1] + s_f[2] + s_f[3];
+        if (wave == 0) {
+            if (lane == 0)
+                __hip_atomic_store(&desc[b], granule(epoch, G_AGG, own_new, own_f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            uint32_t excl_n = 0, excl_f = 0;
+            int base = b - 1;
+            uint32_t spins = 0;
+            while (base >= 0) {
+                const int j = base - lane;
+                uint64_t g = granule(epoch, G_PREFIX, 0, 0);                  // virtual predecessor of block 0
+                if (j >= 0) g = __hip_atomic_load(&desc[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const bool ready = ((g >> 48) == (uint64_t)(epoch & 0xFFFFu)) && (((g >> 46) & 3ull) != 0ull);
+                const bool ispre = ready && (((g >> 46) & 3ull) == G_PREFIX);
+                const uint64_t pm = __ballot(ispre), rm = __ballot(ready);
+                const int first = pm ? __ffsll((long long)pm) - 1 : 64;
+                const uint64_t need = first < 63 ? ((1ull << (first + 1)) - 1ull) : ~0ull;
+                if ((rm & need) != need) {                                    // a granule in the window is not there yet
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > (1u << 22)) { if (lane == 0) st->error = -6; break; }
+                    continue;
+                }
+                uint32_t vn = (lane <= first) ? (uint32_t)((g >> 23) & 0x7FFFFFull) : 0u;
+                uint32_t vf = (lane <= first) ? (uint32_t)(g & 0x7FFFFFull) : 0u;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) { vn += __shfl_xor(vn, o); vf += __shfl_xor(vf, o); }
+                excl_n += vn; excl_f += vf;
+                if (first < 64) break;
+                base -= 64;
+            }
+            if (lane == 0) {
+                __hip_atomic_store(&desc[b], granule(epoch, G_PREFIX, excl_n + own_new, excl_f + own_f), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+                s_excl[0] = excl_n; s_excl[1] = excl_f;
+            }
+        }
+        __syncthreads();
+        const uint32_t excl_n = s_excl[0];
+        const bool fits = (uint64_t)offset + excl_n + own_new <= (uint64_t)fp.max_vertices;
+        if (is_new && fits) {
+            uint32_t rank = (uint32_t)__popcll(nw & ((1ull << lane) - 1ull));
+            for (int w = 0; w < wave; ++w) rank += (uint32_t)__popcll(s_nw[w]);
+            write_new_surfel(cur, offset + excl_n + rank, L, fp);
+        }
+        if (b == nblocks - 1 && threadIdx.x == 0) {
+            // this block's inclusive prefix is the frame total (GlobalModel::concatenate src/GlobalModel.cpp:629)
+            const uint32_t ntot = excl_n + own_new, ftot = s_excl[1] + own_f;
+            st->unstable_count = ntot;
+            st->fused_count = ftot;
+            st->data_count = ntot + ftot;
+            if ((uint64_t)offset + ntot > (uint64_t)fp.max_vertices) {
+                st->error = -2;          // SM_E_CAPACITY: the frame's new surfels are dropped
+                st->append_n = 0;
+                st->count = offset;
+            } else {
+                st->append_n = ntot;
+                st->count = offset + ntot;
+            }
+            if (fp.log_frame && log) {
+                FrameLog e;
+                e.tick = (uint32_t)fp.time; e.n_before = st->cull_n; e.n_after_cull = offset; e.n_kill = st->n_kill;
+                e.conflict_count = st->conflict_count; e.visible_count = st->visible_count;
+                e.fused_count = ftot; e.unstable_count = ntot; e.n_static = st->n_static; e.pad = 0;
+                log[st->frames_logged % FRAME_LOG_LEN] = e;
+                st->frames_logged = st->frames_logged + 1;
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -876,14 +1015,7 @@ __global__ __launch_bounds__(PIX_BLOCK) void k_append(Model M, const DevState *_
     const uint32_t slot = st->offset + blk_prefix[blockIdx.x] + before + (uint32_t)__popcll(mw & ((1ull << lane) - 1ull));
     LocalSurfel L;
     if (!local_surfel(q, fp, depthT, rgbsT, xs, ys, L)) return;   // cannot happen: flagged pixels are valid
-    // data.vert:210-225
-    const float3 pw = xform3(fp.pose, L.pos.x, L.pos.y, L.pos.z);
-    const float3 nw = normalize3(rot3(fp.pose, L.nrm.x, L.nrm.y, L.nrm.z));
-    cur.pos_conf[slot] = make_float4(pw.x, pw.y, pw.z, 0.9f);
-    cur.norm_rad[slot] = make_float4(nw.x, nw.y, nw.z, L.radius);
-    cur.color[slot] = encode_color(L.cr, L.cg, L.cb, L.sem);
-    cur.init_time[slot] = (float)fp.time;
-    cur.time[slot] = (float)fp.time;
+    write_new_surfel(cur, slot, L, fp);
 }
 
 // survivors per creation-frame segment after the pending cull (multi-GPU bookkeeping; the conflict cap
