@@ -143,7 +143,7 @@ struct sm_ctx {
     unsigned long long *d_desc = nullptr;   // look-back granules of k_associate_append
     uint32_t assoc_epoch = 0;
     int assoc_grid = 1024;
-    bool force_three_kernel = false;
+    bool use_fused_assoc = false;
     // multi-GPU segment tables (device copies; nseg == 0 on a single GPU)
     uint32_t *d_seg_lstart = nullptr, *d_seg_gbase = nullptr, *d_gseg_base = nullptr, *d_seg_keep = nullptr;
     uint32_t seg_cap = 0;
@@ -363,7 +363,10 @@ int launch_associate_fused(sm_ctx *s, const FrameParams &fp, bool timed)
 int launch_associate(sm_ctx *s, const FrameParams &fp, bool timed)
 {
     // 23-bit counters in the granule: images above 8 Mpixel keep the three-kernel form
-    if (s->sh_world <= 1 && s->P < (1 << 23) && !s->force_three_kernel) return launch_associate_fused(s, fp, timed);
+    // Measured on MI355X (round 1): the look-back chain costs ~14 us per pass over 1024 workgroups (cross-XCD granule
+    // visibility is ~1-2 us per hop), i.e. no better than the two extra launches at 1242x375 and worse at 1920x1080,
+    // so the three-kernel form stays the default; SM_FUSED_ASSOC=1 selects the single-kernel form.
+    if (s->use_fused_assoc && s->sh_world <= 1 && s->P < (1 << 23)) return launch_associate_fused(s, fp, timed);
     int rc = launch_associate_only(s, fp);
     if (rc) return rc;
     if (mark(s, 5, timed)) return SM_E_HIP;
@@ -617,7 +620,7 @@ sm_ctx *sm_create(const sm_config *c)
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess && cus > 0 &&
             hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_a, k_associate_append, PIX_BLOCK, 0) == hipSuccess && per_cu_a > 0)
             s->assoc_grid = std::max(1, cus * std::min(4, std::max(1, per_cu_a - 1)));
-        s->force_three_kernel = std::getenv("SM_THREE_KERNEL_ASSOC") != nullptr;
+        s->use_fused_assoc = std::getenv("SM_FUSED_ASSOC") != nullptr;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess && cus > 0 &&
             hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_compact<true>, 256, 0) == hipSuccess && per_cu > 0) {
             // the occupancy API can over-report by one block per CU (MI355X_MICROARCH.md): stay at <= 4 and below it
