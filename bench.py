@@ -265,8 +265,16 @@ def main():
         kern[name] = {"ms": tim[name], "MB": None, "GBs": None}
     dom = max(kb.keys(), key=lambda n: tim[n])
     achieved = kern[dom]["GBs"] or 0.0
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", f"traffic_{args.workload}.json")
+    if os.path.exists(tpath):
+        # HBM bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this very
+        # command (profiles/README.md), gfx950-corrected by tools/prof_summary.py
+        tj = json.load(open(tpath))
+        if tj.get("steps") == K and tj.get("warmup") == Wm:
+            traffic = tj.get("kernels", {}).get(dom, {}).get("hbm_bytes_per_launch")
     roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "ms_per_launch": kern[dom]["ms"], "alg_bytes_per_launch": kern[dom]["MB"] * 1e6}
 
     # ---- CPU baseline: the oracle over the very same frames (rank 0, N=1 only)

@@ -254,3 +254,15 @@ def test_preprocess_chain_kitti_size():
         check_depth_textures(o, h, f"frame {k}")
     check(o, h, "kitti preprocess")
     assert o.counts()["count"] > 100000
+
+
+def test_fused_associate_append_variant_matches_oracle():
+    """SM_FUSED_ASSOC=1 selects the single-kernel association+append (decoupled look-back); it is not the
+    default (measured slower) but must stay bit-exact."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SM_FUSED_ASSOC="1")
+    r = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.smoke()"], cwd=root, env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "smoke ok" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]

@@ -29,6 +29,8 @@ def main():
     ap.add_argument("dir")
     ap.add_argument("--last", type=int, default=0)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--steps", type=int, default=None, help="recorded in the json (bench.py --steps of the profiled command)")
+    ap.add_argument("--warmup", type=int, default=None)
     a = ap.parse_args()
     res = collections.defaultdict(dict)
     tr = glob.glob(os.path.join(a.dir, "trace", "*", "*_kernel_trace.csv"))
@@ -64,7 +66,7 @@ def main():
         print(f"{k:28s} {v.get('calls', 0):6d} {v.get('avg_us', 0):9.2f} {v.get('min_us', 0):8.2f} {v.get('max_us', 0):8.2f} "
               f"{(hb / 1e6 if hb else float('nan')):14.2f}")
     if a.out:
-        json.dump({"last": a.last, "kernels": {k: v for k, v in rows if k.startswith('k_')}}, open(a.out, "w"), indent=1)
+        json.dump({"last": a.last, "steps": a.steps, "warmup": a.warmup, "kernels": {k: v for k, v in rows if k.startswith('k_')}}, open(a.out, "w"), indent=1)
 
 
 if __name__ == "__main__":
