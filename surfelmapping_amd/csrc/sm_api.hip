@@ -140,6 +140,7 @@ struct sm_ctx {
     // association scratch
     uint64_t *d_validmask = nullptr, *d_fusedmask = nullptr;
     uint32_t *d_blk_prefix = nullptr;
+    uint2 *d_blk_cnt = nullptr;
     unsigned long long *d_desc = nullptr;   // look-back granules of k_associate_append
     uint32_t assoc_epoch = 0;
     int assoc_grid = 1024;
@@ -327,7 +328,7 @@ int launch_associate_only(sm_ctx *s, const FrameParams &fp)
 {
     hipLaunchKernelGGL(k_associate, dim3(s->n_pix_blocks), dim3(PIX_BLOCK), 0, s->stream, s->M, s->d_state, fp,
                        s->d_depthT, s->d_rgbsT, s->d_keyT, s->d_xs, s->d_ys, s->d_validmask, s->d_fusedmask,
-                       s->d_gseg_base, s->d_seg_lstart);
+                       s->d_gseg_base, s->d_seg_lstart, s->d_blk_cnt);
     HIPCK(hipGetLastError());
     return SM_OK;
 }
@@ -370,6 +371,15 @@ int launch_associate(sm_ctx *s, const FrameParams &fp, bool timed)
     int rc = launch_associate_only(s, fp);
     if (rc) return rc;
     if (mark(s, 5, timed)) return SM_E_HIP;
+    if (s->sh_world <= 1) {
+        // single GPU: the append derives its own prefix from the per-block counts (no scan kernel)
+        if (mark(s, 6, timed)) return SM_E_HIP;
+        hipLaunchKernelGGL(k_append_scan, dim3(s->n_pix_blocks), dim3(PIX_BLOCK), 0, s->stream, s->M, s->d_state, fp, s->d_depthT,
+                           s->d_rgbsT, s->d_xs, s->d_ys, s->d_validmask, s->d_fusedmask, s->d_blk_cnt, s->d_log);
+        HIPCK(hipGetLastError());
+        if (mark(s, 7, timed)) return SM_E_HIP;
+        return SM_OK;
+    }
     return launch_append(s, fp, timed);
 }
 
@@ -559,6 +569,7 @@ sm_ctx *sm_create(const sm_config *c)
          hipMemset(s->d_tile_flag, 0, ntiles * 4) == hipSuccess &&
          dalloc(&s->d_group_tot, (ntiles / GROUP + 2) * 4) == SM_OK && dalloc(&s->d_group_base, ntiles / GROUP + 2) == SM_OK;
     ok = ok && dalloc(&s->d_validmask, (P + 63) / 64 + 4) == SM_OK && dalloc(&s->d_fusedmask, (P + 63) / 64 + 4) == SM_OK;
+    ok = ok && dalloc(&s->d_blk_cnt, (size_t)s->n_pix_blocks) == SM_OK;
     ok = ok && dalloc(&s->d_blk_prefix, (size_t)s->n_pix_blocks) == SM_OK && dalloc(&s->d_desc, (size_t)s->n_pix_blocks) == SM_OK &&
          hipMemset(s->d_desc, 0, (size_t)s->n_pix_blocks * 8) == hipSuccess;
     if (!ok) { if (g_err.empty()) g_err = "sm_create: allocation failed"; sm_destroy(s); return nullptr; }
@@ -650,7 +661,7 @@ void sm_destroy(sm_ctx *s)
     (void)hipFree(s->d_xs); (void)hipFree(s->d_ys); (void)hipFree(s->d_wtab);
     (void)hipFree(s->d_cm); (void)hipFree(s->d_dm); (void)hipFree(s->d_zm);
     (void)hipFree(s->d_tile_cnt); (void)hipFree(s->d_tile_allow); (void)hipFree(s->d_tile_keep); (void)hipFree(s->d_tile_flag); (void)hipFree(s->d_group_tot); (void)hipFree(s->d_group_base);
-    (void)hipFree(s->d_validmask); (void)hipFree(s->d_fusedmask); (void)hipFree(s->d_blk_prefix); (void)hipFree(s->d_desc);
+    (void)hipFree(s->d_validmask); (void)hipFree(s->d_fusedmask); (void)hipFree(s->d_blk_prefix); (void)hipFree(s->d_desc); (void)hipFree(s->d_blk_cnt);
     (void)hipFree(s->d_seg_lstart); (void)hipFree(s->d_seg_gbase); (void)hipFree(s->d_gseg_base); (void)hipFree(s->d_seg_keep);
     if (s->d_export) (void)hipFree(s->d_export);
     for (void *p : s->user_allocs) (void)hipFree(p);

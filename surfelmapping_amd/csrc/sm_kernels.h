@@ -800,8 +800,10 @@ __global__ __launch_bounds__(PIX_BLOCK) void k_associate(Model M, const DevState
                                                          const float *__restrict__ xs, const float *__restrict__ ys,
                                                          uint64_t *__restrict__ validmask, uint64_t *__restrict__ fusedmask,
                                                          const uint32_t *__restrict__ gseg_base,
-                                                         const uint32_t *__restrict__ seg_lstart)
+                                                         const uint32_t *__restrict__ seg_lstart,
+                                                         uint2 *__restrict__ blk_cnt /* (new, fused) per block */)
 {
+    __shared__ uint32_t s_n[4], s_f[4];
     const SurfelSet cur = M.s[st->cur];
     const int q = blockIdx.x * PIX_BLOCK + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -814,7 +816,11 @@ __global__ __launch_bounds__(PIX_BLOCK) void k_associate(Model M, const DevState
     if (lane == 0) {
         const int word = blockIdx.x * (PIX_BLOCK / 64) + wave;
         if (word * 64 < fp.P) { validmask[word] = vw; fusedmask[word] = fw; }
+        s_n[wave] = (uint32_t)__popcll(vw & ~fw);
+        s_f[wave] = (uint32_t)__popcll(fw);
     }
+    __syncthreads();
+    if (threadIdx.x == 0) blk_cnt[blockIdx.x] = make_uint2(s_n[0] + s_n[1] + s_n[2] + s_n[3], s_f[0] + s_f[1] + s_f[2] + s_f[3]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1015,6 +1021,73 @@ __global__ __launch_bounds__(PIX_BLOCK) void k_append(Model M, const DevState *_
     const uint32_t slot = st->offset + blk_prefix[blockIdx.x] + before + (uint32_t)__popcll(mw & ((1ull << lane) - 1ull));
     LocalSurfel L;
     if (!local_surfel(q, fp, depthT, rgbsT, xs, ys, L)) return;   // cannot happen: flagged pixels are valid
+    write_new_surfel(cur, slot, L, fp);
+}
+
+// Single-GPU form of p11 without the separate scan kernel: every block sums the (new, fused) counts of
+// the blocks before it (a few KB, L2-resident) and the last block publishes the frame totals.
+__global__ __launch_bounds__(PIX_BLOCK) void k_append_scan(Model M, DevState *__restrict__ st, FrameParams fp,
+                                                           const float *__restrict__ depthT,
+                                                           const uint32_t *__restrict__ rgbsT,
+                                                           const float *__restrict__ xs, const float *__restrict__ ys,
+                                                           const uint64_t *__restrict__ validmask,
+                                                           const uint64_t *__restrict__ fusedmask,
+                                                           const uint2 *__restrict__ blk_cnt, FrameLog *__restrict__ log)
+{
+    __shared__ uint32_t s_red[2][4];
+    const SurfelSet cur = M.s[st->cur];
+    const uint32_t offset = st->offset;
+    const int q = blockIdx.x * PIX_BLOCK + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool last = blockIdx.x == gridDim.x - 1;
+    const int upto = last ? (int)gridDim.x : (int)blockIdx.x;     // the last block needs the totals
+    uint32_t pn = 0, pf = 0, tn = 0;                              // prefix of new; totals (last block only)
+    for (int b = threadIdx.x; b < upto; b += PIX_BLOCK) {
+        const uint2 c = blk_cnt[b];
+        if (b < (int)blockIdx.x) pn += c.x;
+        if (last) { pf += c.y; tn += c.x; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { pn += __shfl_xor(pn, o); pf += __shfl_xor(pf, o); tn += __shfl_xor(tn, o); }
+    if (lane == 0) { s_red[0][wave] = pn; s_red[1][wave] = pf; }
+    __shared__ uint32_t s_tn[4];
+    if (lane == 0) s_tn[wave] = tn;
+    __syncthreads();
+    const uint32_t prefix = s_red[0][0] + s_red[0][1] + s_red[0][2] + s_red[0][3];
+    if (last && threadIdx.x == 0) {
+        const uint32_t ntot = s_tn[0] + s_tn[1] + s_tn[2] + s_tn[3];
+        const uint32_t ftot = s_red[1][0] + s_red[1][1] + s_red[1][2] + s_red[1][3];
+        st->unstable_count = ntot;
+        st->fused_count = ftot;
+        st->data_count = ntot + ftot;
+        if ((uint64_t)offset + ntot > (uint64_t)fp.max_vertices) {
+            st->error = -2;          // SM_E_CAPACITY: the frame's new surfels are dropped (no block writes, see below)
+            st->append_n = 0;
+            st->count = offset;
+        } else {
+            st->append_n = ntot;
+            st->count = offset + ntot;
+        }
+        if (fp.log_frame && log) {
+            FrameLog e;
+            e.tick = (uint32_t)fp.time; e.n_before = st->cull_n; e.n_after_cull = offset; e.n_kill = st->n_kill;
+            e.conflict_count = st->conflict_count; e.visible_count = st->visible_count;
+            e.fused_count = ftot; e.unstable_count = ntot; e.n_static = st->n_static; e.pad = 0;
+            log[st->frames_logged % FRAME_LOG_LEN] = e;
+            st->frames_logged = st->frames_logged + 1;
+        }
+    }
+    const int word0 = blockIdx.x * (PIX_BLOCK / 64);
+    const int nwords = (fp.P + 63) >> 6;
+    if (word0 + wave >= nwords) return;
+    const uint64_t mw = validmask[word0 + wave] & ~fusedmask[word0 + wave];
+    if (!((mw >> lane) & 1ull)) return;
+    uint32_t before = 0;
+    for (int w = 0; w < wave; ++w) before += (uint32_t)__popcll(validmask[word0 + w] & ~fusedmask[word0 + w]);
+    const uint32_t slot = offset + prefix + before + (uint32_t)__popcll(mw & ((1ull << lane) - 1ull));
+    if ((uint64_t)slot >= (uint64_t)fp.max_vertices) return;      // beyond capacity: the frame is dropped anyway
+    LocalSurfel L;
+    if (!local_surfel(q, fp, depthT, rgbsT, xs, ys, L)) return;
     write_new_surfel(cur, slot, L, fp);
 }
 
