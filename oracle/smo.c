@@ -28,6 +28,7 @@ struct smo_ctx {
     float *xs, *ys;        /* x = texcoord.x * cols                       data.vert:62-63 */
     int *ixm, *ixc, *ixp;  /* nearest/clamp texel of texcoord.x -1/cols, +0, +1/cols (A1) */
     int *iym, *iyc, *iyp;
+    float *xs_fb, *ys_fb;  /* FeedbackBuffer's uvo: float(i/(float)W + 1.0/(2W)) * cols  src/FeedbackBuffer.cpp:47-53 */
     /* "textures" (src/SurfelMapping.cpp:51-87) */
     float *rgb;            /* RGB32F, P*3 */
     uint16_t *depth_raw;
@@ -48,6 +49,9 @@ struct smo_ctx {
     int32_t exempt_id;        /* surfel that never fuses / conflicts: id 0 (A5); shard tests move it */
     int32_t *data_pix;        /* column-major pixel index of every dataVbo record */
 };
+
+int smo_end_frame(smo_ctx *s);
+int smo_stage_initialize(smo_ctx *s, const float *pose, int time_i, float max_depth);
 
 /* ------------------------------------------------------------------ scalar helpers */
 
@@ -255,6 +259,7 @@ smo_ctx *smo_create(const smo_config *c)
     s->tcy = xcalloc(H, 4); s->ys = xcalloc(H, 4);
     s->ixm = xcalloc(W, 4); s->ixc = xcalloc(W, 4); s->ixp = xcalloc(W, 4);
     s->iym = xcalloc(H, 4); s->iyc = xcalloc(H, 4); s->iyp = xcalloc(H, 4);
+    s->xs_fb = xcalloc(W, 4); s->ys_fb = xcalloc(H, 4);
     float cols = (float)W, rows = (float)H;
     float px = 1.0f / cols, py = 1.0f / rows;   /* geometry.glsl:14-18 "1.0 / cols" */
     for (int i = 0; i < W; ++i) {
@@ -263,6 +268,7 @@ smo_ctx *smo_create(const smo_config *c)
         s->ixm[i] = tex_idx(s->tcx[i] - px, W);
         s->ixc[i] = tex_idx(s->tcx[i], W);
         s->ixp[i] = tex_idx(s->tcx[i] + px, W);
+        s->xs_fb[i] = (float)((double)((float)i / cols) + 1.0 / (double)(2.0f * cols)) * cols;
     }
     for (int j = 0; j < H; ++j) {
         s->tcy[j] = (float)((j + 0.5) / (double)rows);   /* src/GlobalModel.cpp:72 */
@@ -270,6 +276,7 @@ smo_ctx *smo_create(const smo_config *c)
         s->iym[j] = tex_idx(s->tcy[j] - py, H);
         s->iyc[j] = tex_idx(s->tcy[j], H);
         s->iyp[j] = tex_idx(s->tcy[j] + py, H);
+        s->ys_fb[j] = (float)((double)((float)j / rows) + 1.0 / (double)(2.0f * rows)) * rows;
     }
     s->rgb = xcalloc(P * 3, 4);
     s->depth_raw = xcalloc(P, 2);
@@ -294,6 +301,7 @@ void smo_destroy(smo_ctx *s)
     if (!s) return;
     free(s->tcx); free(s->tcy); free(s->xs); free(s->ys);
     free(s->ixm); free(s->ixc); free(s->ixp); free(s->iym); free(s->iyc); free(s->iyp);
+    free(s->xs_fb); free(s->ys_fb);
     free(s->rgb); free(s->depth_raw); free(s->depth_metric); free(s->depth_filtered);
     free(s->last); free(s->sem);
     free(s->model); free(s->mvc); free(s->mct); free(s->mnr);
@@ -827,6 +835,59 @@ int smo_stage_concatenate(smo_ctx *s)
     return SMO_OK;
 }
 
+/* ------------------------------------------------------------------ re-initialisation after reset() */
+
+/* SurfelMapping::computeFeedbackBuffers + GlobalModel::initialize (src/SurfelMapping.cpp:161-169):
+ * surfel_feedback.vert:25-63 + surfel_feedback.geom:17-26 build the raw per-frame cloud (every
+ * checkerboard pixel with 0 < z < maxDepth, NO neighbour test), init_unstable.vert:31-42 moves it to
+ * the world frame; it becomes the whole model.  Vertex order: FeedbackBuffer's uvo, x-outer /
+ * y-inner (src/FeedbackBuffer.cpp:47-54). */
+int smo_stage_initialize(smo_ctx *s, const float *pose, int time_i, float max_depth)
+{
+    const smo_config *c = &s->c;
+    int W = c->width, H = c->height;
+    float camz = 1.0f / c->fx, camw = 1.0f / c->fy;        /* float division here: src/FeedbackBuffer.cpp:93-96 */
+    uint32_t n = 0;
+    for (int i = 0; i < W; ++i)
+        for (int j = 0; j < H; ++j) {
+            float x = s->xs_fb[i], y = s->ys_fb[j];
+            int ci = i, cj = j;
+            float z = s->depth_metric[(size_t)cj * W + ci];
+            if (!(z > 0.0f && z < max_depth)) continue;
+            if (((int)x + (int)y) % 2 != 1) continue;
+            float vp[3] = {(x - c->cx) * z * camz, (y - c->cy) * z * camw, z};
+            float xf[3], xb[3], yf[3], yb[3], dx[3], dy[3], nrm[3];
+            float zr = s->depth_metric[(size_t)cj * W + s->ixp[i]], zl = s->depth_metric[(size_t)cj * W + s->ixm[i]];
+            float zd = s->depth_metric[(size_t)s->iyp[j] * W + ci], zu = s->depth_metric[(size_t)s->iym[j] * W + ci];
+            xf[0] = (x + 1.0f - c->cx) * zr * camz; xf[1] = (y - c->cy) * zr * camw; xf[2] = zr;
+            xb[0] = (x - 1.0f - c->cx) * zl * camz; xb[1] = (y - c->cy) * zl * camw; xb[2] = zl;
+            yf[0] = (x - c->cx) * zd * camz; yf[1] = (y + 1.0f - c->cy) * zd * camw; yf[2] = zd;
+            yb[0] = (x - c->cx) * zu * camz; yb[1] = (y - 1.0f - c->cy) * zu * camw; yb[2] = zu;
+            for (int q = 0; q < 3; ++q) { dx[q] = xb[q] - xf[q]; dy[q] = yb[q] - yf[q]; }
+            cross3(dx, dy, nrm);
+            normalize3(nrm);
+            float radius = smo_get_radius(vp[2], nrm[2], camz, camw);
+            if ((uint64_t)n + 1 > max_vertices(s)) return SMO_E_CAPACITY;
+            ensure_model(s, n + 1);
+            float *o = s->model + (size_t)n * SURFEL_F;
+            float t4[4], n3[3];
+            xform(pose, vp[0], vp[1], vp[2], t4);                      /* init_unstable.vert:33-36 */
+            o[0] = t4[0]; o[1] = t4[1]; o[2] = t4[2]; o[3] = 0.9f;     /* surfel_feedback.vert:96 */
+            size_t p = (size_t)cj * W + ci;
+            o[4] = smo_encode_color(s->rgb[p * 3], s->rgb[p * 3 + 1], s->rgb[p * 3 + 2], s->sem[p]);
+            o[5] = 0.0f;
+            o[6] = (float)time_i; o[7] = (float)time_i;
+            rot3(pose, nrm[0], nrm[1], nrm[2], n3);
+            normalize3(n3);
+            o[8] = n3[0]; o[9] = n3[1]; o[10] = n3[2]; o[11] = radius;
+            n++;
+        }
+    s->count = n;
+    s->offset = 0;
+    s->unstable_count = n; s->data_count = n; s->fused_count = 0; s->conflict_count = 0; s->visible_count = 0;
+    return SMO_OK;
+}
+
 /* ------------------------------------------------------------------ orchestration */
 
 static void run_preprocess_pre(smo_ctx *s)
@@ -871,9 +932,11 @@ int smo_begin_frame(smo_ctx *s, const uint8_t *rgb, const uint16_t *depth_mm, co
         smo_remove_movings(&s->c, s->depth_filtered, s->sem, s->last, t_c2l, s->depth_metric);
     }
     if (s->tick == 0) {
-        /* reachable only after reset(): GlobalModel::initialize from the raw feedback cloud
-         *  -- not restated yet */
-        return SMO_E_UNSUPPORTED;
+        /* reachable only after reset() (src/SurfelMapping.cpp:161-169, 436-441) */
+        int rc = smo_stage_initialize(s, s->curr_pose, s->tick, s->c.far_clip);
+        smo_stage_build_model_map(s);
+        smo_end_frame(s);
+        return rc;      /* 0: this call is complete */
     }
     return 1;
 }

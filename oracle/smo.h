@@ -97,6 +97,8 @@ int smo_stage_data_associate(smo_ctx *s, const float *pose, int time, float dept
                              float depth_max);                       /* p8 */
 int smo_stage_update_fuse(smo_ctx *s);                               /* p9 */
 int smo_stage_concatenate(smo_ctx *s);                               /* p11 */
+/* computeFeedbackBuffers + GlobalModel::initialize, the tick==0 branch after reset() */
+int smo_stage_initialize(smo_ctx *s, const float *pose, int time, float max_depth);
 
 /* ---- helpers for the multi-GPU shard tests: one oracle instance plays one rank ---- */
 int smo_set_exempt_id(smo_ctx *s, int32_t id);

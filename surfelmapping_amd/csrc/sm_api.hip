@@ -226,6 +226,9 @@ FrameParams make_params(const sm_ctx *s, const float *pose)
     fp.rank = s->sh_rank;
     fp.world = s->sh_world;
     fp.append_here = 1;
+    fp.init_mode = 0;
+    fp.inv_fx_fb = 1.0f / c.fx;
+    fp.inv_fy_fb = 1.0f / c.fy;
     return fp;
 }
 
@@ -388,6 +391,8 @@ void bump_bound(sm_ctx *s)
     s->count_bound = (uint32_t)std::min<uint64_t>((uint64_t)s->count_bound + s->n_odd_pixels, s->cap);
 }
 
+void end_frame(sm_ctx *s, bool timed = true);
+
 // First half of SurfelMapping::processFrame once the textures are on the device
 // (src/SurfelMapping.cpp:130-169): pre-processing and the reference-frame early-out.
 // Returns 1 when the fusing passes must follow, 0 when the call ends here, <0 on error.
@@ -430,9 +435,16 @@ int begin_frame(sm_ctx *s, const uint8_t *d_rgb, const uint16_t *d_raw, const ui
         HIPCK(hipGetLastError());
     }
     if ((rc = mark(s, 1, fusing))) return rc;
-    if (s->tick == 0) {                                   // src/SurfelMapping.cpp:161-169 (after reset())
-        g_err = "tick==0 re-initialisation from the raw feedback cloud is not built yet";
-        return SM_E_UNSUPPORTED;
+    if (s->tick == 0) {
+        // after reset(): computeFeedbackBuffers + GlobalModel::initialize + buildModelMap
+        // (src/SurfelMapping.cpp:161-169): the raw cloud of this frame becomes the model
+        if (s->sh_world > 1) { g_err = "reset() is not supported in sharded mode"; return SM_E_UNSUPPORTED; }
+        fp.init_mode = 1;
+        fp.log_frame = 0;
+        if ((rc = launch_associate(s, fp, false))) return rc;
+        bump_bound(s);
+        end_frame(s, false);
+        return 0;
     }
     fp.splat_follows = 1;
     fp.log_frame = 1;
@@ -441,11 +453,11 @@ int begin_frame(sm_ctx *s, const uint8_t *d_rgb, const uint16_t *d_raw, const ui
 }
 
 // tail of processFrame (src/SurfelMapping.cpp:244-248)
-void end_frame(sm_ctx *s)
+void end_frame(sm_ctx *s, bool timed)
 {
     if (s->cfg.preprocess) std::swap(s->d_lastT, s->d_filteredT);   // :244 LAST <- DEPTH_FILTERED without a copy
     memcpy(s->last_pose, s->curr_pose, 64);               // :245 (LAST aliases the metric depth when preprocess == 0)
-    if (s->ev_ok) s->ev_frames++;
+    if (s->ev_ok && timed) s->ev_frames++;
     s->tick++;
 }
 
@@ -562,7 +574,7 @@ sm_ctx *sm_create(const sm_config *c)
     ok = ok && dalloc(&s->d_rgbsT, P) == SM_OK && dalloc(&s->d_keyT, P) == SM_OK;
     ok = ok && dalloc(&s->d_rgb, P * 3) == SM_OK && dalloc(&s->d_sem, P) == SM_OK && dalloc(&s->d_depth_raw, P) == SM_OK;
     ok = ok && dalloc(&s->d_depth_f32, P) == SM_OK;
-    ok = ok && dalloc(&s->d_xs, (size_t)s->W) == SM_OK && dalloc(&s->d_ys, (size_t)s->H) == SM_OK && dalloc(&s->d_wtab, (size_t)169) == SM_OK;
+    ok = ok && dalloc(&s->d_xs, (size_t)s->W * 2) == SM_OK && dalloc(&s->d_ys, (size_t)s->H * 2) == SM_OK && dalloc(&s->d_wtab, (size_t)169) == SM_OK;
     ok = ok && dalloc(&s->d_cm, nwords) == SM_OK && dalloc(&s->d_dm, nwords) == SM_OK && dalloc(&s->d_zm, nwords) == SM_OK;
     ok = ok && dalloc(&s->d_tile_cnt, ntiles * 3) == SM_OK && dalloc(&s->d_tile_allow, ntiles) == SM_OK &&
          dalloc(&s->d_tile_keep, ntiles) == SM_OK && dalloc(&s->d_tile_flag, ntiles) == SM_OK &&
@@ -576,7 +588,7 @@ sm_ctx *sm_create(const sm_config *c)
 
     // pixel-centre coordinates exactly as data.vert sees them:
     // texcoord = float((i+0.5)/(double)(float)W) (src/GlobalModel.cpp:71-72), x = texcoord*cols (data.vert:62-63)
-    std::vector<float> xs(s->W), ys(s->H);
+    std::vector<float> xs(s->W * 2), ys(s->H * 2);   // [0,W): data.vert coordinates; [W,2W): FeedbackBuffer's (src/FeedbackBuffer.cpp:47-53)
     const float cols = (float)s->W, rows = (float)s->H;
     const float px = 1.0f / cols, py = 1.0f / rows;
     bool clamp_ok = true;
@@ -585,12 +597,16 @@ sm_ctx *sm_create(const sm_config *c)
     for (int i = 0; i < s->W; ++i) {
         const float tc = (float)((i + 0.5) / (double)cols);
         xs[i] = tc * cols;
+        xs[s->W + i] = (float)((double)((float)i / cols) + 1.0 / (double)(2.0f * cols)) * cols;
+        clamp_ok = clamp_ok && (int)xs[s->W + i] == i;
         clamp_ok = clamp_ok && tex(tc, s->W) == i && tex(tc - px, s->W) == std::max(i - 1, 0) &&
                    tex(tc + px, s->W) == std::min(i + 1, s->W - 1) && (int)xs[i] == i;
     }
     for (int j = 0; j < s->H; ++j) {
         const float tc = (float)((j + 0.5) / (double)rows);
         ys[j] = tc * rows;
+        ys[s->H + j] = (float)((double)((float)j / rows) + 1.0 / (double)(2.0f * rows)) * rows;
+        clamp_ok = clamp_ok && (int)ys[s->H + j] == j;
         clamp_ok = clamp_ok && tex(tc, s->H) == j && tex(tc - py, s->H) == std::max(j - 1, 0) &&
                    tex(tc + py, s->H) == std::min(j + 1, s->H - 1) && (int)ys[j] == j;
     }

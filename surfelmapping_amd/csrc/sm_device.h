@@ -79,6 +79,9 @@ struct FrameParams {
     int n_gseg;               // global creation-frame segments
     int rank, world;
     int append_here;          // this rank owns the frame's new surfels
+    // ---- re-initialisation after reset(): raw feedback cloud (surfel_feedback.vert) ----
+    int init_mode;            // 1: every checkerboard pixel with 0 < z < far becomes a surfel, no association
+    float inv_fx_fb, inv_fy_fb;   // 1.0f/fx as float division (src/FeedbackBuffer.cpp:93-96)
 };
 
 // local index -> global id through the per-segment tables (segments = surfels created by one frame,

@@ -659,12 +659,12 @@ struct LocalSurfel {
     float xl, yl, lambda;
 };
 
-__device__ __forceinline__ float3 get_vertex(float z, float x, float y, const FrameParams &fp)
+__device__ __forceinline__ float3 get_vertex(float z, float x, float y, const FrameParams &fp, float inv_fx, float inv_fy)
 {
     // geometry.glsl:5-9
     float3 r;
-    r.x = (x - fp.cx) * z * fp.inv_fx;
-    r.y = (y - fp.cy) * z * fp.inv_fy;
+    r.x = (x - fp.cx) * z * inv_fx;
+    r.y = (y - fp.cy) * z * inv_fy;
     r.z = z;
     return r;
 }
@@ -675,26 +675,34 @@ __device__ __forceinline__ bool local_surfel(int q, const FrameParams &fp, const
 {
     const int H = fp.H, W = fp.W;
     const int i = q / H, j = q - i * H;
-    const float x = xs[i], y = ys[j];
+    // init_mode: xs/ys hold the FeedbackBuffer's own pixel coordinates (src/FeedbackBuffer.cpp:47-53); they
+    // follow the association tables in the same arrays at offsets W and H
+    const float x = fp.init_mode ? xs[W + i] : xs[i], y = fp.init_mode ? ys[H + j] : ys[j];
+    const float inv_fx = fp.init_mode ? fp.inv_fx_fb : fp.inv_fx, inv_fy = fp.init_mode ? fp.inv_fy_fb : fp.inv_fy;
     const float z = depthT[q];
     // clamp-to-edge neighbours: at the border the neighbour depth is the pixel's own (A1)
     const float zl = depthT[i > 0 ? q - H : q];
     const float zu = depthT[j > 0 ? q - 1 : q];
     const float zr = depthT[i < W - 1 ? q + H : q];
     const float zd = depthT[j < H - 1 ? q + 1 : q];
-    // checkNeighbours data.vert:33-52 + range + checkerboard data.vert:87-88
-    if (zl == 0.0f || zu == 0.0f || zr == 0.0f || zd == 0.0f) return false;
-    if (!(z > fp.min_depth && z < fp.max_depth)) return false;
-    if ((((int)x + (int)y) % 2) != 1) return false;
-    L.xl = (x - fp.cx) * fp.inv_fx;
-    L.yl = (y - fp.cy) * fp.inv_fy;
+    if (fp.init_mode) {
+        // surfel_feedback.vert:80-92: 0 < z < maxDepth and the checkerboard; no neighbour test
+        if (!(z > 0.0f && z < fp.max_depth)) return false;
+    } else {
+        // checkNeighbours data.vert:33-52 + range data.vert:87
+        if (zl == 0.0f || zu == 0.0f || zr == 0.0f || zd == 0.0f) return false;
+        if (!(z > fp.min_depth && z < fp.max_depth)) return false;
+    }
+    if ((((int)x + (int)y) % 2) != 1) return false;       // data.vert:88 / surfel_feedback.vert:81
+    L.xl = (x - fp.cx) * inv_fx;
+    L.yl = (y - fp.cy) * inv_fy;
     L.lambda = sqrtf((L.xl * L.xl + L.yl * L.yl) + 1.0f);
-    L.pos = get_vertex(z, x, y, fp);
+    L.pos = get_vertex(z, x, y, fp, inv_fx, inv_fy);
     // getNormal geometry.glsl:12-24
-    const float3 xf = get_vertex(zr, x + 1.0f, y, fp);
-    const float3 xb = get_vertex(zl, x - 1.0f, y, fp);
-    const float3 yf = get_vertex(zd, x, y + 1.0f, fp);
-    const float3 yb = get_vertex(zu, x, y - 1.0f, fp);
+    const float3 xf = get_vertex(zr, x + 1.0f, y, fp, inv_fx, inv_fy);
+    const float3 xb = get_vertex(zl, x - 1.0f, y, fp, inv_fx, inv_fy);
+    const float3 yf = get_vertex(zd, x, y + 1.0f, fp, inv_fx, inv_fy);
+    const float3 yb = get_vertex(zu, x, y - 1.0f, fp, inv_fx, inv_fy);
     const float3 del_x = make_float3(xb.x - xf.x, xb.y - xf.y, xb.z - xf.z);
     const float3 del_y = make_float3(yb.x - yf.x, yb.y - yf.y, yb.z - yf.z);
     L.nrm = normalize3(cross3(del_x, del_y));
@@ -703,7 +711,7 @@ __device__ __forceinline__ bool local_surfel(int q, const FrameParams &fp, const
     L.cg = (float)((c >> 8) & 0xFFu) / 255.0f;
     L.cb = (float)(c & 0xFFu) / 255.0f;
     L.sem = c >> 24;
-    L.radius = get_radius(L.pos.z, L.nrm.z, fp.inv_fx, fp.inv_fy);
+    L.radius = get_radius(L.pos.z, L.nrm.z, inv_fx, inv_fy);
     return true;
 }
 
@@ -726,7 +734,7 @@ __device__ __forceinline__ void associate_pixel(int q, const SurfelSet &cur, con
         const int32_t gid = (int32_t)(uint32_t)(key & 0xFFFFFFFFull);
         uint32_t id = 0;
         // data.vert:142 on the GLOBAL id; only the rank that owns the winner tries to fuse it
-        if (key != KEY_EMPTY && gid > 0 &&
+        if (!fp.init_mode && key != KEY_EMPTY && gid > 0 &&
             global_to_local((uint32_t)gid, gseg_base, fp.n_gseg, seg_lstart, fp.rank, fp.world, &id)) {
             const float4 pc = cur.pos_conf[id];
             const uint32_t col = cur.color[id];

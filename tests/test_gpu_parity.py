@@ -266,3 +266,31 @@ def test_fused_associate_append_variant_matches_oracle():
     r = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.smoke()"], cwd=root, env=env,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "smoke ok" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+
+
+def assert_models_equal_nan_tolerant(a, b, what=""):
+    """As assert_models_equal, but any NaN equals any NaN: the raw feedback cloud has no neighbour test
+    (surfel_feedback.vert), so border pixels get 0/0 normals whose NaN payload/sign is not specified."""
+    assert a.shape == b.shape, f"{what}: {a.shape} vs {b.shape}"
+    na, nb = np.isnan(a), np.isnan(b)
+    assert np.array_equal(na, nb), what
+    au, bu = a.view(np.uint32).copy(), b.view(np.uint32).copy()
+    au[na] = 0; bu[nb] = 0
+    assert np.array_equal(au, bu), what
+
+
+def test_reset_then_reinitialise_from_raw_cloud():
+    """SurfelMapping::reset (src/SurfelMapping.cpp:436-441) + the tick==0 branch (:161-169)."""
+    seq = synth.make_sequence(SMALL, synth.kitti_trajectory(7), seed=13)
+    o, h = pair(SMALL, stereo_border=20.0, max_sqrt_vertices=600)
+    run_sequence(o, h, seq[:3])
+    o.reset(); h.reset()
+    assert o.counts()["count"] == h.counts()["count"] == 0 and h.counts()["tick"] == 0
+    o.process_frame(*seq[3]); h.process_frame(*seq[3])
+    co, ch = o.counts(), h.counts()
+    assert co["count"] == ch["count"] > 5000 and ch["tick"] == 1
+    assert_models_equal_nan_tolerant(o.download_model(), h.download_model(), "after re-initialisation")
+    for k, fr in enumerate(seq[4:]):
+        o.process_frame(*fr); h.process_frame(*fr)
+        assert {x: o.counts()[x] for x in COUNT_KEYS} == {x: h.counts()[x] for x in COUNT_KEYS}
+        assert_models_equal_nan_tolerant(o.download_model(), h.download_model(), f"frame {k} after reset")
