@@ -294,3 +294,19 @@ def test_reset_then_reinitialise_from_raw_cloud():
         o.process_frame(*fr); h.process_frame(*fr)
         assert {x: o.counts()[x] for x in COUNT_KEYS} == {x: h.counts()[x] for x in COUNT_KEYS}
         assert_models_equal_nan_tolerant(o.download_model(), h.download_model(), f"frame {k} after reset")
+
+
+def test_seeded_eight_million_surfels_in_place_cull_under_load():
+    """The in-place compaction hand-off (tile flags) with ~8000 tiles in flight: 8 M seeded surfels,
+    kills spread over the whole array, conflict cap off (as in the stress benchmark)."""
+    cam = synth.HD
+    n = 8_000_000
+    o, h = pair(cam, max_sqrt_vertices=3200, conflict_cap=0)
+    m = synth.seeded_model(n, tick=300, seed=5)
+    o.upload_model(m); h.upload_model(m)
+    o.set_tick(300); h.set_tick(300)
+    seq = synth.make_sequence(cam, synth.kitti_trajectory(4), seed=5)
+    for k, fr in enumerate(seq[1:]):
+        o.process_frame(*fr); h.process_frame(*fr)
+        check(o, h, f"8M frame {k}", model=(k == 2))
+    assert h.counts()["offset"] < h.counts()["count"] and o.counts()["conflict_count"] > 10000
