@@ -651,7 +651,10 @@ sm_ctx *sm_create(const sm_config *c)
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess && cus > 0 &&
             hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_compact<true>, 256, 0) == hipSuccess && per_cu > 0) {
             // the occupancy API can over-report by one block per CU (MI355X_MICROARCH.md): stay at <= 4 and below it
-            s->compact_grid = std::max(1, cus * std::min(4, std::max(1, per_cu - 1)));
+            // (SM_COMPACT_WG_PER_CU overrides the margin for experiments)
+            int want = std::min(4, std::max(1, per_cu - 1));
+            if (const char *e = std::getenv("SM_COMPACT_WG_PER_CU")) want = std::max(1, std::min(per_cu, std::atoi(e)));
+            s->compact_grid = std::max(1, cus * want);
         }
     }
     if (c->enable_timing) {

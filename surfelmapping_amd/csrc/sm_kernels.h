@@ -506,6 +506,31 @@ __global__ __launch_bounds__(256) void k_compact(Model M, DevState *__restrict__
     uint32_t vis = 0;
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const uint32_t allow = tile_allow[tile], nconf = tile_cnt[tile * 3];
+        // fast path (workgroup-uniform): nothing of this tile conflicts, dies or moves -- the bulk of the map
+        // once the camera has passed.  No masks, no LDS, no barriers: read pos+time, splat.
+        if (nconf == 0 && tile_cnt[tile * 3 + 1] == 0 &&
+            tile_keep_prefix[tile] + group_keep_base[tile / GROUP] == tile * (uint32_t)TILE) {
+            if (SPLAT) {
+                float4 pv[4];
+                float pt[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const uint32_t k = (tile * TILE_WORDS + r * 4 + wave) * 64u + lane;
+                    const uint32_t kc = min(k, N - 1u);
+                    pv[r] = set.pos_conf[kc];
+                    pt[r] = set.time[kc];
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const uint32_t k = (tile * TILE_WORDS + r * 4 + wave) * 64u + lane;
+                    bool drew = false;
+                    if (k < N)
+                        drew = splat_one(fp, pv[r].x, pv[r].y, pv[r].z, pt[r], local_to_global(k, seg_lstart, seg_gbase, fp.nseg), keyT);
+                    vis += (uint32_t)__popcll(__ballot(drew));
+                }
+            }
+            continue;
+        }
         uint64_t c = 0, d = 0, z = 0, valid = 0;
         if (threadIdx.x < TILE_WORDS) {
             const uint32_t word = tile * TILE_WORDS + threadIdx.x;
