@@ -49,6 +49,7 @@ typedef struct sm_config {
     int32_t conflict_cap;          /* 1: only the first W*H conflicts take effect (conflictVbo size, src/GlobalModel.cpp:54-57) */
     int32_t device;                /* HIP device ordinal */
     int32_t enable_timing;         /* 1: record hipEvents per stage (sm_stage_timings) */
+    int32_t disable_tile_bounds;   /* 1: never skip tiles by their bounding box (A/B switch; results are identical) */
 } sm_config;
 
 /* GlobalModel counters (src/GlobalModel.cpp:860-888) + tick (src/SurfelMapping.h:100) */
@@ -91,6 +92,8 @@ typedef struct sm_frame_log {
     uint32_t fused_count;     /* F */
     uint32_t unstable_count;  /* U */
     uint32_t n_static;        /* surfels the in-place cull did not have to move */
+    uint32_t n_conf_skipped;  /* surfels in tiles the conflict pass skipped by their bounding box */
+    uint32_t n_splat_skipped; /* surfels in static tiles the index-map splat skipped by their bounding box */
     uint32_t reserved;
 } sm_frame_log;
 

@@ -135,6 +135,8 @@ struct sm_ctx {
     uint64_t *d_cm = nullptr, *d_dm = nullptr, *d_zm = nullptr;
     uint32_t *d_tile_cnt = nullptr, *d_tile_allow = nullptr, *d_tile_keep = nullptr, *d_tile_flag = nullptr;
     uint32_t *d_group_tot = nullptr, *d_group_base = nullptr;
+    uint32_t *d_tb = nullptr;          // per-tile bounds (8 words per tile)
+    uint32_t tb_tiles = 0;
     uint32_t cull_epoch = 0;
     int compact_grid = COMPACT_GRID;
     // association scratch
@@ -229,6 +231,7 @@ FrameParams make_params(const sm_ctx *s, const float *pose)
     fp.init_mode = 0;
     fp.inv_fx_fb = 1.0f / c.fx;
     fp.inv_fy_fb = 1.0f / c.fy;
+    fp.use_bounds = c.disable_tile_bounds ? 0 : 1;
     return fp;
 }
 
@@ -296,7 +299,7 @@ int mark(sm_ctx *s, int which, bool timed)
 int launch_conflict(sm_ctx *s, const FrameParams &fp, bool timed = false)
 {
     hipLaunchKernelGGL(k_conflict, dim3(grid_surfels(s)), dim3(256), 0, s->stream, s->M, s->d_state, fp, s->d_depthT,
-                       s->d_rgbsT, s->d_cm, s->d_dm, s->d_zm, s->d_tile_cnt);
+                       s->d_rgbsT, s->d_cm, s->d_dm, s->d_zm, s->d_tile_cnt, s->d_tb, s->d_state);
     HIPCK(hipGetLastError());
     if (mark(s, 2, timed)) return SM_E_HIP;
     const int ngroups = std::max<int>(1, (int)((((uint64_t)s->count_bound + TILE - 1) / TILE + GROUP - 1) / GROUP));
@@ -304,7 +307,7 @@ int launch_conflict(sm_ctx *s, const FrameParams &fp, bool timed = false)
                        s->d_tile_keep, s->d_group_tot);
     HIPCK(hipGetLastError());
     hipLaunchKernelGGL(k_cull_finalize, dim3(1), dim3(1024), 0, s->stream, s->d_state, fp, s->d_cm, s->d_dm, s->d_zm,
-                       s->d_tile_cnt, s->d_tile_allow, s->d_tile_keep, s->d_group_tot, s->d_group_base);
+                       s->d_tile_cnt, s->d_tile_allow, s->d_tile_keep, s->d_group_tot, s->d_group_base, s->d_tb, s->tb_tiles);
     HIPCK(hipGetLastError());
     if (mark(s, 3, timed)) return SM_E_HIP;
     return SM_OK;
@@ -317,11 +320,11 @@ int launch_compact(sm_ctx *s, const FrameParams &fp, bool splat, bool timed)
     if (splat)
         hipLaunchKernelGGL(k_compact<true>, dim3(grid), dim3(256), 0, s->stream, s->M, s->d_state, fp, s->d_cm,
                            s->d_dm, s->d_zm, s->d_tile_cnt, s->d_tile_allow, s->d_tile_keep, s->d_keyT, s->d_tile_flag, epoch,
-                           s->d_seg_lstart, s->d_seg_gbase, s->d_group_base);
+                           s->d_seg_lstart, s->d_seg_gbase, s->d_group_base, s->d_tb);
     else
         hipLaunchKernelGGL(k_compact<false>, dim3(grid), dim3(256), 0, s->stream, s->M, s->d_state, fp, s->d_cm,
                            s->d_dm, s->d_zm, s->d_tile_cnt, s->d_tile_allow, s->d_tile_keep, s->d_keyT, s->d_tile_flag, epoch,
-                           s->d_seg_lstart, s->d_seg_gbase, s->d_group_base);
+                           s->d_seg_lstart, s->d_seg_gbase, s->d_group_base, s->d_tb);
     HIPCK(hipGetLastError());
     if (mark(s, 4, timed)) return SM_E_HIP;
     return SM_OK;
@@ -331,7 +334,7 @@ int launch_associate_only(sm_ctx *s, const FrameParams &fp)
 {
     hipLaunchKernelGGL(k_associate, dim3(s->n_pix_blocks), dim3(PIX_BLOCK), 0, s->stream, s->M, s->d_state, fp,
                        s->d_depthT, s->d_rgbsT, s->d_keyT, s->d_xs, s->d_ys, s->d_validmask, s->d_fusedmask,
-                       s->d_gseg_base, s->d_seg_lstart, s->d_blk_cnt);
+                       s->d_gseg_base, s->d_seg_lstart, s->d_blk_cnt, s->d_tb);
     HIPCK(hipGetLastError());
     return SM_OK;
 }
@@ -343,7 +346,7 @@ int launch_append(sm_ctx *s, const FrameParams &fp, bool timed)
     HIPCK(hipGetLastError());
     if (mark(s, 6, timed)) return SM_E_HIP;
     hipLaunchKernelGGL(k_append, dim3(s->n_pix_blocks), dim3(PIX_BLOCK), 0, s->stream, s->M, s->d_state, fp, s->d_depthT,
-                       s->d_rgbsT, s->d_xs, s->d_ys, s->d_validmask, s->d_fusedmask, s->d_blk_prefix);
+                       s->d_rgbsT, s->d_xs, s->d_ys, s->d_validmask, s->d_fusedmask, s->d_blk_prefix, s->d_tb);
     HIPCK(hipGetLastError());
     if (mark(s, 7, timed)) return SM_E_HIP;
     return SM_OK;
@@ -358,7 +361,7 @@ int launch_associate_fused(sm_ctx *s, const FrameParams &fp, bool timed)
     }
     const int grid = std::min(s->n_pix_blocks, s->assoc_grid);
     hipLaunchKernelGGL(k_associate_append, dim3(grid), dim3(PIX_BLOCK), 0, s->stream, s->M, s->d_state, fp, s->d_depthT,
-                       s->d_rgbsT, s->d_keyT, s->d_xs, s->d_ys, s->d_desc, s->assoc_epoch, s->n_pix_blocks, s->d_log);
+                       s->d_rgbsT, s->d_keyT, s->d_xs, s->d_ys, s->d_desc, s->assoc_epoch, s->n_pix_blocks, s->d_log, s->d_tb);
     HIPCK(hipGetLastError());
     if (mark(s, 5, timed) || mark(s, 6, timed) || mark(s, 7, timed)) return SM_E_HIP;
     return SM_OK;
@@ -378,7 +381,7 @@ int launch_associate(sm_ctx *s, const FrameParams &fp, bool timed)
         // single GPU: the append derives its own prefix from the per-block counts (no scan kernel)
         if (mark(s, 6, timed)) return SM_E_HIP;
         hipLaunchKernelGGL(k_append_scan, dim3(s->n_pix_blocks), dim3(PIX_BLOCK), 0, s->stream, s->M, s->d_state, fp, s->d_depthT,
-                           s->d_rgbsT, s->d_xs, s->d_ys, s->d_validmask, s->d_fusedmask, s->d_blk_cnt, s->d_log);
+                           s->d_rgbsT, s->d_xs, s->d_ys, s->d_validmask, s->d_fusedmask, s->d_blk_cnt, s->d_log, s->d_tb);
         HIPCK(hipGetLastError());
         if (mark(s, 7, timed)) return SM_E_HIP;
         return SM_OK;
@@ -507,6 +510,25 @@ int upload_inputs(sm_ctx *s, const uint8_t *rgb, const uint16_t *depth, const ui
     return SM_OK;
 }
 
+// rebuild the bounds of every tile that holds a surfel with index >= first_surfel (after the model was written
+// from outside the frame pipeline); the state on the device must already carry the new count
+int rebuild_bounds(sm_ctx *s, uint32_t first_surfel, uint32_t count)
+{
+    const uint32_t t0 = first_surfel / TILE;
+    if (t0 < s->tb_tiles) {
+        const uint32_t n = s->tb_tiles - t0;
+        hipLaunchKernelGGL(k_tile_bounds_reset, dim3((n + 255) / 256), dim3(256), 0, s->stream, s->d_tb, t0, n);
+        HIPCK(hipGetLastError());
+    }
+    const uint32_t k0 = t0 * TILE;
+    if (count > k0) {
+        hipLaunchKernelGGL(k_tile_bounds_build, dim3((count - k0 + 255) / 256), dim3(256), 0, s->stream, s->M, s->d_state, s->d_tb, k0);
+        HIPCK(hipGetLastError());
+    }
+    HIPCK(hipStreamSynchronize(s->stream));
+    return SM_OK;
+}
+
 int ensure_export(sm_ctx *s, size_t bytes)
 {
     if (bytes <= s->export_bytes) return SM_OK;
@@ -580,6 +602,8 @@ sm_ctx *sm_create(const sm_config *c)
          dalloc(&s->d_tile_keep, ntiles) == SM_OK && dalloc(&s->d_tile_flag, ntiles) == SM_OK &&
          hipMemset(s->d_tile_flag, 0, ntiles * 4) == hipSuccess &&
          dalloc(&s->d_group_tot, (ntiles / GROUP + 2) * 4) == SM_OK && dalloc(&s->d_group_base, ntiles / GROUP + 2) == SM_OK;
+    s->tb_tiles = (uint32_t)(ntiles + P / 2 / TILE + 8);
+    ok = ok && dalloc(&s->d_tb, (size_t)s->tb_tiles * 8) == SM_OK;
     ok = ok && dalloc(&s->d_validmask, (P + 63) / 64 + 4) == SM_OK && dalloc(&s->d_fusedmask, (P + 63) / 64 + 4) == SM_OK;
     ok = ok && dalloc(&s->d_blk_cnt, (size_t)s->n_pix_blocks) == SM_OK;
     ok = ok && dalloc(&s->d_blk_prefix, (size_t)s->n_pix_blocks) == SM_OK && dalloc(&s->d_desc, (size_t)s->n_pix_blocks) == SM_OK &&
@@ -637,6 +661,7 @@ sm_ctx *sm_create(const sm_config *c)
          hipMemset(s->d_depth_raw, 0, P * 2) == hipSuccess && hipMemset(s->d_depth_f32, 0, P * 4) == hipSuccess;
     ok = ok && hipDeviceSynchronize() == hipSuccess;
     if (ok) {
+        hipLaunchKernelGGL(k_tile_bounds_reset, dim3((s->tb_tiles + 255) / 256), dim3(256), 0, s->stream, s->d_tb, 0u, s->tb_tiles);
         hipLaunchKernelGGL(k_fill_keys, dim3((s->P + 255) / 256), dim3(256), 0, s->stream, s->d_keyT, s->P);
         ok = hipStreamSynchronize(s->stream) == hipSuccess;
     }
@@ -652,7 +677,8 @@ sm_ctx *sm_create(const sm_config *c)
             hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_compact<true>, 256, 0) == hipSuccess && per_cu > 0) {
             // the occupancy API can over-report by one block per CU (MI355X_MICROARCH.md): stay at <= 4 and below it
             // (SM_COMPACT_WG_PER_CU overrides the margin for experiments)
-            int want = std::min(4, std::max(1, per_cu - 1));
+            // <= 4 per CU: in that range the limit is VGPR/LDS-bound and the API is exact; above it keep a margin
+            int want = per_cu <= 4 ? per_cu : 4;
             if (const char *e = std::getenv("SM_COMPACT_WG_PER_CU")) want = std::max(1, std::min(per_cu, std::atoi(e)));
             s->compact_grid = std::max(1, cus * want);
         }
@@ -679,7 +705,7 @@ void sm_destroy(sm_ctx *s)
     (void)hipFree(s->d_rgb); (void)hipFree(s->d_sem); (void)hipFree(s->d_depth_raw); (void)hipFree(s->d_depth_f32);
     (void)hipFree(s->d_xs); (void)hipFree(s->d_ys); (void)hipFree(s->d_wtab);
     (void)hipFree(s->d_cm); (void)hipFree(s->d_dm); (void)hipFree(s->d_zm);
-    (void)hipFree(s->d_tile_cnt); (void)hipFree(s->d_tile_allow); (void)hipFree(s->d_tile_keep); (void)hipFree(s->d_tile_flag); (void)hipFree(s->d_group_tot); (void)hipFree(s->d_group_base);
+    (void)hipFree(s->d_tile_cnt); (void)hipFree(s->d_tile_allow); (void)hipFree(s->d_tile_keep); (void)hipFree(s->d_tile_flag); (void)hipFree(s->d_group_tot); (void)hipFree(s->d_group_base); (void)hipFree(s->d_tb);
     (void)hipFree(s->d_validmask); (void)hipFree(s->d_fusedmask); (void)hipFree(s->d_blk_prefix); (void)hipFree(s->d_desc); (void)hipFree(s->d_blk_cnt);
     (void)hipFree(s->d_seg_lstart); (void)hipFree(s->d_seg_gbase); (void)hipFree(s->d_gseg_base); (void)hipFree(s->d_seg_keep);
     if (s->d_export) (void)hipFree(s->d_export);
@@ -750,6 +776,7 @@ int sm_reset(sm_ctx *s)
     s->tick = 0;                                 // refFrameIsSet stays (src/SurfelMapping.cpp:436-441)
     s->pending_cull = false;
     if ((rc = push_state(s))) return rc;
+    if ((rc = rebuild_bounds(s, 0, 0))) return rc;
     return pull_state(s);
 }
 
@@ -804,6 +831,7 @@ int sm_upload_model_aos(sm_ctx *s, const float *src12, uint32_t n)
     s->h_state->offset = n;
     s->pending_cull = false;
     if ((rc = push_state(s))) return rc;
+    if ((rc = rebuild_bounds(s, 0, n))) return rc;
     return pull_state(s);
 }
 
@@ -1110,6 +1138,7 @@ int sm_append_model_aos_device(sm_ctx *s, const float *d_src12, uint32_t n)
     s->h_state->count = cnt + n;
     s->h_state->offset = cnt;
     if ((rc = push_state(s))) return rc;
+    if ((rc = rebuild_bounds(s, cnt, cnt + n))) return rc;
     return pull_state(s);
 }
 

@@ -49,9 +49,12 @@ struct DevState {
     int32_t error;            // sticky SM_E_*
     uint32_t frames_logged;   // fusing frames completed (frame-log write index)
     uint32_t n_static;        // surfels in tiles the last cull left in place
+    uint32_t n_conf_skipped;  // surfels in tiles the conflict pass skipped by their bounds
+    uint32_t n_splat_skipped; // surfels in static tiles the splat skipped by their bounds
+    uint32_t pad2[2];
 };
 
-struct FrameLog { uint32_t tick, n_before, n_after_cull, n_kill, conflict_count, visible_count, fused_count, unstable_count, n_static, pad; };
+struct FrameLog { uint32_t tick, n_before, n_after_cull, n_kill, conflict_count, visible_count, fused_count, unstable_count, n_static, n_conf_skipped, n_splat_skipped, pad; };
 constexpr uint32_t FRAME_LOG_LEN = 1024;
 
 struct FrameParams {
@@ -82,6 +85,7 @@ struct FrameParams {
     // ---- re-initialisation after reset(): raw feedback cloud (surfel_feedback.vert) ----
     int init_mode;            // 1: every checkerboard pixel with 0 < z < far becomes a surfel, no association
     float inv_fx_fb, inv_fy_fb;   // 1.0f/fx as float division (src/FeedbackBuffer.cpp:93-96)
+    int use_bounds;           // 1: whole 1024-surfel tiles are skipped when their bounding box is outside the view
 };
 
 // local index -> global id through the per-segment tables (segments = surfels created by one frame,
@@ -243,6 +247,89 @@ __device__ __forceinline__ uint32_t block_scan_1024(uint32_t v, uint32_t *total,
     *total = lds[16];
     __syncthreads();
     return excl;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Per-tile bounds (work skipping).  Tile t = surfels [1024 t, 1024 t + 1024).  Because the model is
+// kept in creation order, a tile holds surfels born in the same few image columns of one frame, so
+// its world-space box is small and whole tiles fall out of view once the camera has moved on.
+// tb[t*8 + 0..2] = min xyz, [3] = number of surfels that defeat the box (conf <= 0 / NaN: only an
+// uploaded model can contain them), [4..6] = max xyz, [7] = max last-update time; floats are stored
+// in an order-preserving unsigned encoding so that atomicMin/atomicMax maintain them.  Bounds are
+// conservative (they only ever grow between rebuilds), skipping decisions add a 2-pixel / 1-cm
+// margin, so a skipped tile provably contains no surfel the exact per-surfel test would accept.
+// ---------------------------------------------------------------------------------------------
+constexpr uint32_t TB_LO_EMPTY = 0xFFFFFFFFu, TB_HI_EMPTY = 0u;
+
+__device__ __forceinline__ uint32_t f2ord(float f)
+{
+    const uint32_t b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(uint32_t o)
+{
+    return __uint_as_float((o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o);
+}
+
+// expand the bounds of the tiles touched by this wave: each active lane contributes one surfel
+// (position, time, "bad") to tile `tile`; lanes are grouped by tile with ballots, reduced with
+// shuffles, and one lane per group issues the 7-8 atomics.
+__device__ __forceinline__ void bounds_expand_wave(uint32_t *__restrict__ tb, bool active, uint32_t tile, float x, float y,
+                                                   float z, float t, bool bad)
+{
+    uint64_t todo = __ballot(active);
+    const int lane = threadIdx.x & 63;
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const uint32_t tcur = (uint32_t)__shfl((int)tile, leader);
+        const bool mine = active && tile == tcur;
+        const uint64_t grp = __ballot(mine);
+        uint32_t lx = mine ? f2ord(x) : TB_LO_EMPTY, ly = mine ? f2ord(y) : TB_LO_EMPTY, lz = mine ? f2ord(z) : TB_LO_EMPTY;
+        uint32_t hx = mine ? f2ord(x) : TB_HI_EMPTY, hy = mine ? f2ord(y) : TB_HI_EMPTY, hz = mine ? f2ord(z) : TB_HI_EMPTY;
+        uint32_t ht = mine ? f2ord(t) : TB_HI_EMPTY;
+        const uint32_t nb = (uint32_t)__popcll(__ballot(mine && (bad || x != x || y != y || z != z)));
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            lx = min(lx, (uint32_t)__shfl_xor((int)lx, o)); ly = min(ly, (uint32_t)__shfl_xor((int)ly, o));
+            lz = min(lz, (uint32_t)__shfl_xor((int)lz, o));
+            hx = max(hx, (uint32_t)__shfl_xor((int)hx, o)); hy = max(hy, (uint32_t)__shfl_xor((int)hy, o));
+            hz = max(hz, (uint32_t)__shfl_xor((int)hz, o)); ht = max(ht, (uint32_t)__shfl_xor((int)ht, o));
+        }
+        if (lane == leader) {
+            uint32_t *b = tb + (size_t)tcur * 8;
+            atomicMin(&b[0], lx); atomicMin(&b[1], ly); atomicMin(&b[2], lz);
+            atomicMax(&b[4], hx); atomicMax(&b[5], hy); atomicMax(&b[6], hz); atomicMax(&b[7], ht);
+            if (nb) atomicAdd(&b[3], nb);
+        }
+        todo &= ~grp;
+    }
+}
+
+// true if no point of the tile's box can pass the view test  zlo < Z < zhi, ulo <= u <= uhi, vlo <= v <= vhi
+// (conflict.vert:35 / index_map.vert:45-55), with a 1 cm / 2 pixel safety margin.  An empty, non-finite or
+// "bad" box is never reported outside unless it is empty.
+__device__ __forceinline__ bool box_outside_view(const uint32_t *__restrict__ b, const float *t_inv, float fx, float fy, float cx,
+                                                 float cy, float zlo, float zhi, float ulo, float uhi, float vlo, float vhi)
+{
+    if (b[0] == TB_LO_EMPTY && b[4] == TB_HI_EMPTY) return b[3] == 0u;       // no surfel recorded at all
+    if (b[3] != 0u) return false;
+    const float lx = ord2f(b[0]), ly = ord2f(b[1]), lz = ord2f(b[2]), hx = ord2f(b[4]), hy = ord2f(b[5]), hz = ord2f(b[6]);
+    float zmin = 3.0e38f, zmax = -3.0e38f;
+    bool all_right = true, all_left = true, all_below = true, all_above = true, finite = true;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const float3 p = xform3(t_inv, (c & 1) ? hx : lx, (c & 2) ? hy : ly, (c & 4) ? hz : lz);
+        finite = finite && (p.x - p.x == 0.0f) && (p.y - p.y == 0.0f) && (p.z - p.z == 0.0f);
+        zmin = fminf(zmin, p.z); zmax = fmaxf(zmax, p.z);
+        all_right = all_right && (fx * p.x + (cx - uhi - 2.0f) * p.z > 0.0f);
+        all_left = all_left && (fx * p.x + (cx - ulo + 2.0f) * p.z < 0.0f);
+        all_below = all_below && (fy * p.y + (cy - vhi - 2.0f) * p.z > 0.0f);
+        all_above = all_above && (fy * p.y + (cy - vlo + 2.0f) * p.z < 0.0f);
+    }
+    if (!finite) return false;
+    if (zmax < zlo - 0.01f || zmin > zhi + 0.01f) return true;
+    if (zmin > 1.0e-3f && (all_right || all_left || all_below || all_above)) return true;
+    return false;
 }
 
 // the first `n` set bits of `m` (n may exceed popcount)

@@ -216,7 +216,8 @@ __global__ __launch_bounds__(256) void k_conflict(Model M, const DevState *__res
                                                   const float *__restrict__ depthT,
                                                   const uint32_t *__restrict__ rgbsT,
                                                   uint64_t *__restrict__ cm, uint64_t *__restrict__ dm,
-                                                  uint64_t *__restrict__ zm, uint32_t *__restrict__ tile_cnt)
+                                                  uint64_t *__restrict__ zm, uint32_t *__restrict__ tile_cnt,
+                                                  const uint32_t *__restrict__ tb, DevState *__restrict__ st_rw)
 {
     __shared__ uint32_t s_red[4][3];
     __shared__ uint64_t s_m[3][TILE_WORDS];
@@ -224,8 +225,22 @@ __global__ __launch_bounds__(256) void k_conflict(Model M, const DevState *__res
     const float4 *__restrict__ pc = M.s[st->cur].pos_conf;
     const uint32_t ntiles = (N + TILE - 1) / TILE;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t skipped = 0;
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         uint32_t nconf = 0, nkill = 0, nzero = 0;
+        // whole tile outside the conflict view volume (conflict.vert:35)?  Then nothing conflicts, and a tile
+        // without "bad" surfels has nothing dead either: zero masks, zero counts, no surfel read.
+        if (fp.use_bounds && box_outside_view(tb + (size_t)tile * 8, fp.t_inv, fp.fx, fp.fy, fp.cx, fp.cy, fp.min_depth,
+                                              fp.max_depth, fp.stereo_border, fp.cols, 0.0f, fp.rows)) {
+            if (threadIdx.x < 3) tile_cnt[tile * 3 + threadIdx.x] = 0u;
+            if (threadIdx.x >= 64 && threadIdx.x < 64 + 3 * TILE_WORDS) {
+                const int m = (threadIdx.x - 64) / TILE_WORDS, w = (threadIdx.x - 64) % TILE_WORDS;
+                const uint32_t word = tile * TILE_WORDS + w;
+                if ((uint64_t)word * 64u < N) { uint64_t *dst = m == 0 ? cm : (m == 1 ? dm : zm); dst[word] = 0ull; }
+            }
+            skipped += min((uint32_t)TILE, N - tile * TILE);
+            continue;
+        }
         // phase 1: all four 16-byte loads of the lane in flight together
         float4 v[4];
         bool valid[4];
@@ -302,6 +317,7 @@ __global__ __launch_bounds__(256) void k_conflict(Model M, const DevState *__res
         }
         __syncthreads();
     }
+    if (threadIdx.x == 0 && skipped) atomicAdd(&st_rw->n_conf_skipped, skipped);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -358,7 +374,8 @@ __global__ __launch_bounds__(1024) void k_cull_finalize(DevState *__restrict__ s
                                                         uint32_t *__restrict__ tile_allow,
                                                         uint32_t *__restrict__ tile_keep_prefix,
                                                         const uint32_t *__restrict__ group_tot,
-                                                        uint32_t *__restrict__ group_keep_base)
+                                                        uint32_t *__restrict__ group_keep_base,
+                                                        uint32_t *__restrict__ tb, uint32_t tb_tiles)
 {
     __shared__ uint32_t s_scan[17];
     __shared__ uint32_t s_first;
@@ -427,8 +444,21 @@ __global__ __launch_bounds__(1024) void k_cull_finalize(DevState *__restrict__ s
         }
         block_scan_1024(ns, &nstatic, s_scan);
     }
+    {
+        // tile bounds: every tile from the first one that loses a surfel onwards is rewritten by the compaction
+        // (and re-expanded there); tiles past the survivors will receive this frame's new surfels
+        const uint32_t kept_tiles = (ktotal + TILE - 1) / TILE;
+        const uint32_t first = (ktotal == N) ? kept_tiles : min(nstatic / (uint32_t)TILE, kept_tiles);
+        const uint32_t last = min(tb_tiles, ntiles + ((uint32_t)fp.P / 2u) / (uint32_t)TILE + 3u);
+        for (uint32_t t = first + threadIdx.x; t < last; t += 1024u) {
+            uint32_t *b = tb + (size_t)t * 8;
+            b[0] = TB_LO_EMPTY; b[1] = TB_LO_EMPTY; b[2] = TB_LO_EMPTY; b[3] = 0u;
+            b[4] = TB_HI_EMPTY; b[5] = TB_HI_EMPTY; b[6] = TB_HI_EMPTY; b[7] = TB_HI_EMPTY;
+        }
+    }
     if (threadIdx.x == 0) {
         const uint32_t kept = ktotal;
+        st->n_splat_skipped = 0;
         st->n_static = nstatic;
         st->cull_n = N;
         st->n_kill = N - kept;
@@ -494,7 +524,8 @@ __global__ __launch_bounds__(256) void k_compact(Model M, DevState *__restrict__
                                                  uint32_t *__restrict__ tile_flag, uint32_t epoch,
                                                  const uint32_t *__restrict__ seg_lstart,
                                                  const uint32_t *__restrict__ seg_gbase,
-                                                 const uint32_t *__restrict__ group_keep_base)
+                                                 const uint32_t *__restrict__ group_keep_base,
+                                                 uint32_t *__restrict__ tb)
 {
     __shared__ uint64_t s_keep[TILE_WORDS], s_ceff[TILE_WORDS];
     __shared__ uint32_t s_cpop[TILE_WORDS], s_kpre[TILE_WORDS + 1];
@@ -503,13 +534,23 @@ __global__ __launch_bounds__(256) void k_compact(Model M, DevState *__restrict__
     const SurfelSet set = M.s[st->cull_src];
     const uint32_t ntiles = (N + TILE - 1) / TILE;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t vis = 0;
+    uint32_t vis = 0, skipped = 0;
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const uint32_t allow = tile_allow[tile], nconf = tile_cnt[tile * 3];
         // fast path (workgroup-uniform): nothing of this tile conflicts, dies or moves -- the bulk of the map
         // once the camera has passed.  No masks, no LDS, no barriers: read pos+time, splat.
         if (nconf == 0 && tile_cnt[tile * 3 + 1] == 0 &&
             tile_keep_prefix[tile] + group_keep_base[tile / GROUP] == tile * (uint32_t)TILE) {
+            // ... and if its box cannot reach the index map (index_map.vert:45-55: 0 < z < far inside the image,
+            // updated within timeDelta frames) it is not even read
+            if (SPLAT && fp.use_bounds &&
+                ((float)fp.time - ord2f(tb[(size_t)tile * 8 + 7]) > (float)fp.time_delta ||
+                 box_outside_view(tb + (size_t)tile * 8, fp.t_inv, fp.fx, fp.fy, fp.cx, fp.cy, 0.0f, fp.depth_cutoff, 0.0f,
+                                  fp.cols, 0.0f, fp.rows)) &&
+                tb[(size_t)tile * 8 + 3] == 0u && tb[(size_t)tile * 8 + 4] != TB_HI_EMPTY) {
+                skipped += min((uint32_t)TILE, N - tile * TILE);
+                continue;
+            }
             if (SPLAT) {
                 float4 pv[4];
                 float pt[4];
@@ -621,6 +662,7 @@ __global__ __launch_bounds__(256) void k_compact(Model M, DevState *__restrict__
                     set.init_time[nid[r]] = it[r];
                     set.time[nid[r]] = tl[r];
                 }
+                bounds_expand_wave(tb, kept[r], nid[r] / (uint32_t)TILE, v[r].x, v[r].y, v[r].z, tl[r], false);
             }
         }
         if (SPLAT) {
@@ -640,6 +682,7 @@ __global__ __launch_bounds__(256) void k_compact(Model M, DevState *__restrict__
         if (threadIdx.x == 0) {
             const uint32_t t = s_vis[0] + s_vis[1] + s_vis[2] + s_vis[3];
             if (t) atomicAdd(&st->visible_count, t);
+            if (skipped) atomicAdd(&st->n_splat_skipped, skipped);
         }
     }
 }
@@ -749,7 +792,7 @@ __device__ __forceinline__ void associate_pixel(int q, const SurfelSet &cur, con
                                                 const uint64_t *__restrict__ keyT, const float *__restrict__ xs,
                                                 const float *__restrict__ ys, const uint32_t *__restrict__ gseg_base,
                                                 const uint32_t *__restrict__ seg_lstart, LocalSurfel &L, bool &is_valid,
-                                                bool &is_fused)
+                                                bool &is_fused, uint32_t *__restrict__ tb)
 {
     is_valid = false;
     is_fused = false;
@@ -806,6 +849,18 @@ __device__ __forceinline__ void associate_pixel(int q, const SurfelSet &cur, con
                     cur.norm_rad[id] = onr;
                     cur.color[id] = ocol;
                     cur.time[id] = (float)fp.time;   // initTime kept (data.vert:187)
+                    {   // the fused surfel moved: grow its tile's box if it left it (stale reads only cause a redundant atomic)
+                        uint32_t *b = tb + (size_t)(id / (uint32_t)TILE) * 8;
+                        const uint32_t ox = f2ord(opc.x), oy = f2ord(opc.y), oz = f2ord(opc.z), ot = f2ord((float)fp.time);
+                        if (ox < b[0]) atomicMin(&b[0], ox);
+                        if (oy < b[1]) atomicMin(&b[1], oy);
+                        if (oz < b[2]) atomicMin(&b[2], oz);
+                        if (ox > b[4]) atomicMax(&b[4], ox);
+                        if (oy > b[5]) atomicMax(&b[5], oy);
+                        if (oz > b[6]) atomicMax(&b[6], oz);
+                        if (ot > b[7]) atomicMax(&b[7], ot);
+                        if (opc.x != opc.x || opc.y != opc.y || opc.z != opc.z) atomicAdd(&b[3], 1u);
+                    }
                 }
             }
         }
@@ -813,7 +868,7 @@ __device__ __forceinline__ void associate_pixel(int q, const SurfelSet &cur, con
 }
 
 // data.vert:210-225: the new surfel of a valid, unmatched pixel, written to model slot `slot`
-__device__ __forceinline__ void write_new_surfel(const SurfelSet &cur, uint32_t slot, const LocalSurfel &L, const FrameParams &fp)
+__device__ __forceinline__ float3 write_new_surfel(const SurfelSet &cur, uint32_t slot, const LocalSurfel &L, const FrameParams &fp)
 {
     const float3 pw = xform3(fp.pose, L.pos.x, L.pos.y, L.pos.z);
     const float3 nw = normalize3(rot3(fp.pose, L.nrm.x, L.nrm.y, L.nrm.z));
@@ -822,6 +877,7 @@ __device__ __forceinline__ void write_new_surfel(const SurfelSet &cur, uint32_t 
     cur.color[slot] = encode_color(L.cr, L.cg, L.cb, L.sem);
     cur.init_time[slot] = (float)fp.time;
     cur.time[slot] = (float)fp.time;
+    return pw;
 }
 
 // Three-kernel form (used when a reduction over ranks must happen between association and append):
@@ -834,7 +890,8 @@ __global__ __launch_bounds__(PIX_BLOCK) void k_associate(Model M, const DevState
                                                          uint64_t *__restrict__ validmask, uint64_t *__restrict__ fusedmask,
                                                          const uint32_t *__restrict__ gseg_base,
                                                          const uint32_t *__restrict__ seg_lstart,
-                                                         uint2 *__restrict__ blk_cnt /* (new, fused) per block */)
+                                                         uint2 *__restrict__ blk_cnt /* (new, fused) per block */,
+                                                         uint32_t *__restrict__ tb)
 {
     __shared__ uint32_t s_n[4], s_f[4];
     const SurfelSet cur = M.s[st->cur];
@@ -842,7 +899,7 @@ __global__ __launch_bounds__(PIX_BLOCK) void k_associate(Model M, const DevState
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     bool is_valid, is_fused;
     LocalSurfel L;
-    associate_pixel(q, cur, fp, depthT, rgbsT, keyT, xs, ys, gseg_base, seg_lstart, L, is_valid, is_fused);
+    associate_pixel(q, cur, fp, depthT, rgbsT, keyT, xs, ys, gseg_base, seg_lstart, L, is_valid, is_fused, tb);
     // two ballot words per wave: candidate pixels, and pixels fused by THIS rank (disjoint across ranks,
     // so a sum-reduction of the words over the ranks is their union)
     const uint64_t vw = __ballot(is_valid), fw = __ballot(is_fused);
@@ -880,7 +937,7 @@ __global__ __launch_bounds__(PIX_BLOCK) void k_associate_append(Model M, DevStat
                                                                 const uint64_t *__restrict__ keyT,
                                                                 const float *__restrict__ xs, const float *__restrict__ ys,
                                                                 unsigned long long *__restrict__ desc, uint32_t epoch, int nblocks,
-                                                                FrameLog *__restrict__ log)
+                                                                FrameLog *__restrict__ log, uint32_t *__restrict__ tb)
 {
     __shared__ uint64_t s_nw[4];
     __shared__ uint32_t s_f[4];
@@ -892,7 +949,7 @@ __global__ __launch_bounds__(PIX_BLOCK) void k_associate_append(Model M, DevStat
         const int q = b * PIX_BLOCK + threadIdx.x;
         bool is_valid, is_fused;
         LocalSurfel L;
-        associate_pixel(q, cur, fp, depthT, rgbsT, keyT, xs, ys, nullptr, nullptr, L, is_valid, is_fused);
+        associate_pixel(q, cur, fp, depthT, rgbsT, keyT, xs, ys, nullptr, nullptr, L, is_valid, is_fused, tb);
         const bool is_new = is_valid && !is_fused;
         const uint64_t nw = __ballot(is_new), fw = __ballot(is_fused);
         if (lane == 0) { s_nw[wave] = nw; s_f[wave] = (uint32_t)__popcll(fw); }
@@ -936,10 +993,14 @@ __global__ __launch_bounds__(PIX_BLOCK) void k_associate_append(Model M, DevStat
         __syncthreads();
         const uint32_t excl_n = s_excl[0];
         const bool fits = (uint64_t)offset + excl_n + own_new <= (uint64_t)fp.max_vertices;
-        if (is_new && fits) {
+        {
             uint32_t rank = (uint32_t)__popcll(nw & ((1ull << lane) - 1ull));
             for (int w = 0; w < wave; ++w) rank += (uint32_t)__popcll(s_nw[w]);
-            write_new_surfel(cur, offset + excl_n + rank, L, fp);
+            const uint32_t slot = offset + excl_n + rank;
+            const bool wr = is_new && fits;
+            float3 pw = make_float3(0.f, 0.f, 0.f);
+            if (wr) pw = write_new_surfel(cur, slot, L, fp);
+            bounds_expand_wave(tb, wr, slot / (uint32_t)TILE, pw.x, pw.y, pw.z, (float)fp.time, false);
         }
         if (b == nblocks - 1 && threadIdx.x == 0) {
             // this block's inclusive prefix is the frame total (GlobalModel::concatenate src/GlobalModel.cpp:629)
@@ -959,7 +1020,9 @@ __global__ __launch_bounds__(PIX_BLOCK) void k_associate_append(Model M, DevStat
                 FrameLog e;
                 e.tick = (uint32_t)fp.time; e.n_before = st->cull_n; e.n_after_cull = offset; e.n_kill = st->n_kill;
                 e.conflict_count = st->conflict_count; e.visible_count = st->visible_count;
-                e.fused_count = ftot; e.unstable_count = ntot; e.n_static = st->n_static; e.pad = 0;
+                e.fused_count = ftot; e.unstable_count = ntot; e.n_static = st->n_static;
+            e.n_conf_skipped = st->n_conf_skipped; e.n_splat_skipped = st->n_splat_skipped; e.pad = 0;
+            st->n_conf_skipped = 0;
                 log[st->frames_logged % FRAME_LOG_LEN] = e;
                 st->frames_logged = st->frames_logged + 1;
             }
@@ -1023,7 +1086,9 @@ __global__ __launch_bounds__(1024) void k_scan_new(DevState *__restrict__ st, Fr
             FrameLog e;
             e.tick = (uint32_t)fp.time; e.n_before = st->cull_n; e.n_after_cull = st->offset; e.n_kill = st->n_kill;
             e.conflict_count = st->conflict_count; e.visible_count = st->visible_count;
-            e.fused_count = ftot; e.unstable_count = ntot; e.n_static = st->n_static; e.pad = 0;
+            e.fused_count = ftot; e.unstable_count = ntot; e.n_static = st->n_static;
+            e.n_conf_skipped = st->n_conf_skipped; e.n_splat_skipped = st->n_splat_skipped; e.pad = 0;
+            st->n_conf_skipped = 0;
             log[st->frames_logged % FRAME_LOG_LEN] = e;
             st->frames_logged = st->frames_logged + 1;
         }
@@ -1038,7 +1103,7 @@ __global__ __launch_bounds__(PIX_BLOCK) void k_append(Model M, const DevState *_
                                                       const float *__restrict__ xs, const float *__restrict__ ys,
                                                       const uint64_t *__restrict__ validmask,
                                                       const uint64_t *__restrict__ fusedmask,
-                                                      const uint32_t *__restrict__ blk_prefix)
+                                                      const uint32_t *__restrict__ blk_prefix, uint32_t *__restrict__ tb)
 {
     if (st->append_n == 0) return;
     const SurfelSet cur = M.s[st->cur];
@@ -1046,15 +1111,16 @@ __global__ __launch_bounds__(PIX_BLOCK) void k_append(Model M, const DevState *_
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int word0 = blockIdx.x * (PIX_BLOCK / 64);
     const int nwords = (fp.P + 63) >> 6;
-    if (word0 + wave >= nwords) return;
+    if (word0 + wave >= nwords) return;                         // wave-uniform
     const uint64_t mw = validmask[word0 + wave] & ~fusedmask[word0 + wave];
-    if (!((mw >> lane) & 1ull)) return;
     uint32_t before = 0;
     for (int w = 0; w < wave; ++w) before += (uint32_t)__popcll(validmask[word0 + w] & ~fusedmask[word0 + w]);
     const uint32_t slot = st->offset + blk_prefix[blockIdx.x] + before + (uint32_t)__popcll(mw & ((1ull << lane) - 1ull));
     LocalSurfel L;
-    if (!local_surfel(q, fp, depthT, rgbsT, xs, ys, L)) return;   // cannot happen: flagged pixels are valid
-    write_new_surfel(cur, slot, L, fp);
+    const bool wr = ((mw >> lane) & 1ull) && local_surfel(q, fp, depthT, rgbsT, xs, ys, L);   // flagged pixels are valid
+    float3 pw = make_float3(0.f, 0.f, 0.f);
+    if (wr) pw = write_new_surfel(cur, slot, L, fp);
+    bounds_expand_wave(tb, wr, slot / (uint32_t)TILE, pw.x, pw.y, pw.z, (float)fp.time, false);
 }
 
 // Single-GPU form of p11 without the separate scan kernel: every block sums the (new, fused) counts of
@@ -1065,7 +1131,8 @@ __global__ __launch_bounds__(PIX_BLOCK) void k_append_scan(Model M, DevState *__
                                                            const float *__restrict__ xs, const float *__restrict__ ys,
                                                            const uint64_t *__restrict__ validmask,
                                                            const uint64_t *__restrict__ fusedmask,
-                                                           const uint2 *__restrict__ blk_cnt, FrameLog *__restrict__ log)
+                                                           const uint2 *__restrict__ blk_cnt, FrameLog *__restrict__ log,
+                                                           uint32_t *__restrict__ tb)
 {
     __shared__ uint32_t s_red[2][4];
     const SurfelSet cur = M.s[st->cur];
@@ -1105,23 +1172,50 @@ __global__ __launch_bounds__(PIX_BLOCK) void k_append_scan(Model M, DevState *__
             FrameLog e;
             e.tick = (uint32_t)fp.time; e.n_before = st->cull_n; e.n_after_cull = offset; e.n_kill = st->n_kill;
             e.conflict_count = st->conflict_count; e.visible_count = st->visible_count;
-            e.fused_count = ftot; e.unstable_count = ntot; e.n_static = st->n_static; e.pad = 0;
+            e.fused_count = ftot; e.unstable_count = ntot; e.n_static = st->n_static;
+            e.n_conf_skipped = st->n_conf_skipped; e.n_splat_skipped = st->n_splat_skipped; e.pad = 0;
+            st->n_conf_skipped = 0;
             log[st->frames_logged % FRAME_LOG_LEN] = e;
             st->frames_logged = st->frames_logged + 1;
         }
     }
     const int word0 = blockIdx.x * (PIX_BLOCK / 64);
     const int nwords = (fp.P + 63) >> 6;
-    if (word0 + wave >= nwords) return;
+    if (word0 + wave >= nwords) return;                         // wave-uniform
     const uint64_t mw = validmask[word0 + wave] & ~fusedmask[word0 + wave];
-    if (!((mw >> lane) & 1ull)) return;
     uint32_t before = 0;
     for (int w = 0; w < wave; ++w) before += (uint32_t)__popcll(validmask[word0 + w] & ~fusedmask[word0 + w]);
     const uint32_t slot = offset + prefix + before + (uint32_t)__popcll(mw & ((1ull << lane) - 1ull));
-    if ((uint64_t)slot >= (uint64_t)fp.max_vertices) return;      // beyond capacity: the frame is dropped anyway
     LocalSurfel L;
-    if (!local_surfel(q, fp, depthT, rgbsT, xs, ys, L)) return;
-    write_new_surfel(cur, slot, L, fp);
+    // beyond capacity the frame is dropped anyway (see the totals above)
+    const bool wr = ((mw >> lane) & 1ull) && (uint64_t)slot < (uint64_t)fp.max_vertices &&
+                    local_surfel(q, fp, depthT, rgbsT, xs, ys, L);
+    float3 pw = make_float3(0.f, 0.f, 0.f);
+    if (wr) pw = write_new_surfel(cur, slot, L, fp);
+    bounds_expand_wave(tb, wr, slot / (uint32_t)TILE, pw.x, pw.y, pw.z, (float)fp.time, false);
+}
+
+// rebuild of the tile bounds from the stored model (upload / import / device append)
+__global__ void k_tile_bounds_reset(uint32_t *__restrict__ tb, uint32_t first, uint32_t n)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    uint32_t *b = tb + (size_t)(first + t) * 8;
+    b[0] = TB_LO_EMPTY; b[1] = TB_LO_EMPTY; b[2] = TB_LO_EMPTY; b[3] = 0u;
+    b[4] = TB_HI_EMPTY; b[5] = TB_HI_EMPTY; b[6] = TB_HI_EMPTY; b[7] = TB_HI_EMPTY;
+}
+
+__global__ __launch_bounds__(256) void k_tile_bounds_build(Model M, const DevState *__restrict__ st, uint32_t *__restrict__ tb,
+                                                           uint32_t first_surfel)
+{
+    const SurfelSet cur = M.s[st->cur];
+    const uint32_t N = st->count;
+    const uint32_t k = first_surfel + blockIdx.x * 256u + threadIdx.x;
+    const bool a = k < N;
+    float4 v = make_float4(0.f, 0.f, 0.f, 1.f);
+    float t = 0.f;
+    if (a) { v = cur.pos_conf[k]; t = cur.time[k]; }
+    bounds_expand_wave(tb, a, k / (uint32_t)TILE, v.x, v.y, v.z, t, !(v.w > 0.0f));
 }
 
 // survivors per creation-frame segment after the pending cull (multi-GPU bookkeeping; the conflict cap

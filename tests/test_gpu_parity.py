@@ -310,3 +310,35 @@ def test_seeded_eight_million_surfels_in_place_cull_under_load():
         o.process_frame(*fr); h.process_frame(*fr)
         check(o, h, f"8M frame {k}", model=(k == 2))
     assert h.counts()["offset"] < h.counts()["count"] and o.counts()["conflict_count"] > 10000
+
+
+def test_tile_bounds_skip_tiles_without_changing_results():
+    """Whole 1024-surfel tiles whose bounding box is outside the view are skipped by the conflict pass and the
+    splat; the result must not depend on it (A/B against disable_tile_bounds=1 and against the oracle)."""
+    poses = synth.kitti_trajectory(40, step=1.6)            # drive away from the early surfels
+    seq = synth.make_sequence(SMALL, poses, seed=14)
+    o, h = pair(SMALL, stereo_border=20.0, max_sqrt_vertices=800)
+    args = (SMALL["width"], SMALL["height"], SMALL["fx"], SMALL["fy"], SMALL["cx"], SMALL["cy"])
+    h_off = make("hip", *args, preprocess=0, stereo_border=20.0, max_sqrt_vertices=800, disable_tile_bounds=1)
+    for k, fr in enumerate(seq):
+        o.process_frame(*fr); h.process_frame(*fr); h_off.process_frame(*fr)
+        if k % 8 == 7 or k == len(seq) - 1:
+            check(o, h, f"bounds on, frame {k}")
+            check(o, h_off, f"bounds off, frame {k}")
+    log_on, log_off = h.read_frame_log(), h_off.read_frame_log()
+    assert log_on["n_conf_skipped"][-1] > 50_000 and log_on["n_splat_skipped"][-1] > 10_000, log_on[-3:]
+    assert log_off["n_conf_skipped"].sum() == 0 and log_off["n_splat_skipped"].sum() == 0
+    assert np.array_equal(log_on["visible_count"], log_off["visible_count"])
+
+
+def test_tile_bounds_with_yaw_and_turning_back():
+    """The camera turns around and looks at old parts of the map again: skipped tiles must come back."""
+    import math
+    poses = ([synth.pose_matrix(0, 0, 0.8 * k, 0.0) for k in range(12)] +
+             [synth.pose_matrix(0, 0, 0.8 * 11, 15.0 * k) for k in range(1, 13)] +      # turn 180 degrees
+             [synth.pose_matrix(0, 0, 0.8 * 11 - 0.8 * k, 180.0) for k in range(1, 8)])  # drive back
+    seq = synth.make_sequence(SMALL, poses, seed=15)
+    o, h = pair(SMALL, stereo_border=20.0, max_sqrt_vertices=800)
+    run_sequence(o, h, seq, every=4)
+    log = h.read_frame_log()
+    assert log["n_conf_skipped"].max() > 10_000
