@@ -63,14 +63,16 @@ def kernel_bytes(log):
     """Algorithmic HBM bytes per launch of each kernel from the per-frame counters
     (DESIGN.md "Measurement"; SoA surfel = 44 B, key = 8 B)."""
     P = log["P"]
-    N, Np, V, F, U, Ns = (log[k].astype(np.float64) for k in
-                          ("n_before", "n_after_cull", "visible_count", "fused_count", "unstable_count", "n_static"))
-    # in-place cull: static tiles are only read for the splat (pos_conf 16 + time 4), the rest is
-    # read and rewritten in full (44 + 44); every drawn surfel costs one 8-byte key atomic
-    compact = 20.0 * Ns + 88.0 * np.maximum(Np - Ns, 0.0) + 8.0 * V
+    N, Np, V, F, U, Ns, Cs, Ss = (log[k].astype(np.float64) for k in
+                                  ("n_before", "n_after_cull", "visible_count", "fused_count", "unstable_count", "n_static",
+                                   "n_conf_skipped", "n_splat_skipped"))
+    # in-place cull: static tiles are only read for the splat (pos_conf 16 + time 4) unless their bounding box
+    # is out of view (then not at all), the rest is read and rewritten in full (44 + 44); every drawn surfel
+    # costs one 8-byte key atomic
+    compact = 20.0 * np.maximum(Ns - Ss, 0.0) + 88.0 * np.maximum(Np - Ns, 0.0) + 8.0 * V
     return {
         "k_prep": np.full_like(N, 6.0 * P + 16.0 * P),          # u8x3+u16+u8 in, f32+u32+u64 out
-        "k_conflict": 16.0 * N,
+        "k_conflict": 16.0 * np.maximum(N - Cs, 0.0),             # tiles skipped by their bounds are not read
         "k_compact": compact,
         "k_associate": 16.0 * P + 84.0 * F,                       # depth+rgbs+key per pixel, gather 44 + scatter 40 per fuse
         "k_append": 8.0 * (P / 64.0) + 44.0 * U,
