@@ -136,6 +136,7 @@ struct sm_ctx {
     uint32_t *d_tile_cnt = nullptr, *d_tile_allow = nullptr, *d_tile_keep = nullptr, *d_tile_flag = nullptr;
     uint32_t *d_group_tot = nullptr, *d_group_base = nullptr;
     uint32_t *d_tb = nullptr;          // per-tile bounds (8 words per tile)
+    uint8_t *d_tile_flags = nullptr;   // per-tile skip flags of the current frame
     uint32_t tb_tiles = 0;
     uint32_t cull_epoch = 0;
     int compact_grid = COMPACT_GRID;
@@ -280,12 +281,33 @@ int take_error(sm_ctx *s)
 
 // ---- launches ----
 
+uint32_t flag_tiles(const sm_ctx *s)
+{
+    return (uint32_t)std::min<uint64_t>(((uint64_t)s->count_bound + TILE - 1) / TILE, s->tb_tiles);
+}
+
+// skip flags when no k_prep precedes the cull (per-pass entry points)
+int launch_tile_flags(sm_ctx *s, FrameParams fp)
+{
+    fp.n_flag_tiles = flag_tiles(s);
+    if (fp.n_flag_tiles == 0) return SM_OK;
+    hipLaunchKernelGGL(k_tile_flags, dim3((fp.n_flag_tiles + 255) / 256), dim3(256), 0, s->stream, fp, s->d_tb, s->d_tile_flags);
+    HIPCK(hipGetLastError());
+    return SM_OK;
+}
+
 int launch_prep(sm_ctx *s, const uint8_t *rgb, const uint16_t *raw, const uint8_t *sem, const float *dm,
-                const FrameParams &fp, bool clear_keys)
+                FrameParams fp, bool clear_keys, bool with_flags = true)
 {
     const int tiles = ((s->W + 31) / 32) * ((s->H + 31) / 32);
+    fp.n_flag_tiles = with_flags ? flag_tiles(s) : 0;
+    if (fp.n_flag_tiles > (uint32_t)tiles * 1024u) {           // more tiles than k_prep has threads (> 470 M surfels at KITTI size)
+        int rc = launch_tile_flags(s, fp);
+        if (rc) return rc;
+        fp.n_flag_tiles = 0;
+    }
     hipLaunchKernelGGL(k_prep, dim3(tiles), dim3(1024), 0, s->stream, rgb, raw, sem, dm, s->d_depthT, s->d_rgbsT,
-                       clear_keys ? s->d_keyT : nullptr, fp);
+                       clear_keys ? s->d_keyT : nullptr, fp, s->d_tb, fp.n_flag_tiles ? s->d_tile_flags : (uint8_t *)nullptr);
     HIPCK(hipGetLastError());
     return SM_OK;
 }
@@ -299,7 +321,7 @@ int mark(sm_ctx *s, int which, bool timed)
 int launch_conflict(sm_ctx *s, const FrameParams &fp, bool timed = false)
 {
     hipLaunchKernelGGL(k_conflict, dim3(grid_surfels(s)), dim3(256), 0, s->stream, s->M, s->d_state, fp, s->d_depthT,
-                       s->d_rgbsT, s->d_cm, s->d_dm, s->d_zm, s->d_tile_cnt, s->d_tb, s->d_state);
+                       s->d_rgbsT, s->d_cm, s->d_dm, s->d_zm, s->d_tile_cnt, s->d_tile_flags, s->d_state);
     HIPCK(hipGetLastError());
     if (mark(s, 2, timed)) return SM_E_HIP;
     const int ngroups = std::max<int>(1, (int)((((uint64_t)s->count_bound + TILE - 1) / TILE + GROUP - 1) / GROUP));
@@ -320,11 +342,11 @@ int launch_compact(sm_ctx *s, const FrameParams &fp, bool splat, bool timed)
     if (splat)
         hipLaunchKernelGGL(k_compact<true>, dim3(grid), dim3(256), 0, s->stream, s->M, s->d_state, fp, s->d_cm,
                            s->d_dm, s->d_zm, s->d_tile_cnt, s->d_tile_allow, s->d_tile_keep, s->d_keyT, s->d_tile_flag, epoch,
-                           s->d_seg_lstart, s->d_seg_gbase, s->d_group_base, s->d_tb);
+                           s->d_seg_lstart, s->d_seg_gbase, s->d_group_base, s->d_tb, s->d_tile_flags);
     else
         hipLaunchKernelGGL(k_compact<false>, dim3(grid), dim3(256), 0, s->stream, s->M, s->d_state, fp, s->d_cm,
                            s->d_dm, s->d_zm, s->d_tile_cnt, s->d_tile_allow, s->d_tile_keep, s->d_keyT, s->d_tile_flag, epoch,
-                           s->d_seg_lstart, s->d_seg_gbase, s->d_group_base, s->d_tb);
+                           s->d_seg_lstart, s->d_seg_gbase, s->d_group_base, s->d_tb, s->d_tile_flags);
     HIPCK(hipGetLastError());
     if (mark(s, 4, timed)) return SM_E_HIP;
     return SM_OK;
@@ -603,7 +625,8 @@ sm_ctx *sm_create(const sm_config *c)
          hipMemset(s->d_tile_flag, 0, ntiles * 4) == hipSuccess &&
          dalloc(&s->d_group_tot, (ntiles / GROUP + 2) * 4) == SM_OK && dalloc(&s->d_group_base, ntiles / GROUP + 2) == SM_OK;
     s->tb_tiles = (uint32_t)(ntiles + P / 2 / TILE + 8);
-    ok = ok && dalloc(&s->d_tb, (size_t)s->tb_tiles * 8) == SM_OK;
+    ok = ok && dalloc(&s->d_tb, (size_t)s->tb_tiles * 8) == SM_OK && dalloc(&s->d_tile_flags, (size_t)s->tb_tiles) == SM_OK &&
+         hipMemset(s->d_tile_flags, 0, s->tb_tiles) == hipSuccess;
     ok = ok && dalloc(&s->d_validmask, (P + 63) / 64 + 4) == SM_OK && dalloc(&s->d_fusedmask, (P + 63) / 64 + 4) == SM_OK;
     ok = ok && dalloc(&s->d_blk_cnt, (size_t)s->n_pix_blocks) == SM_OK;
     ok = ok && dalloc(&s->d_blk_prefix, (size_t)s->n_pix_blocks) == SM_OK && dalloc(&s->d_desc, (size_t)s->n_pix_blocks) == SM_OK &&
@@ -705,7 +728,7 @@ void sm_destroy(sm_ctx *s)
     (void)hipFree(s->d_rgb); (void)hipFree(s->d_sem); (void)hipFree(s->d_depth_raw); (void)hipFree(s->d_depth_f32);
     (void)hipFree(s->d_xs); (void)hipFree(s->d_ys); (void)hipFree(s->d_wtab);
     (void)hipFree(s->d_cm); (void)hipFree(s->d_dm); (void)hipFree(s->d_zm);
-    (void)hipFree(s->d_tile_cnt); (void)hipFree(s->d_tile_allow); (void)hipFree(s->d_tile_keep); (void)hipFree(s->d_tile_flag); (void)hipFree(s->d_group_tot); (void)hipFree(s->d_group_base); (void)hipFree(s->d_tb);
+    (void)hipFree(s->d_tile_cnt); (void)hipFree(s->d_tile_allow); (void)hipFree(s->d_tile_keep); (void)hipFree(s->d_tile_flag); (void)hipFree(s->d_group_tot); (void)hipFree(s->d_group_base); (void)hipFree(s->d_tb); (void)hipFree(s->d_tile_flags);
     (void)hipFree(s->d_validmask); (void)hipFree(s->d_fusedmask); (void)hipFree(s->d_blk_prefix); (void)hipFree(s->d_desc); (void)hipFree(s->d_blk_cnt);
     (void)hipFree(s->d_seg_lstart); (void)hipFree(s->d_seg_gbase); (void)hipFree(s->d_gseg_base); (void)hipFree(s->d_seg_keep);
     if (s->d_export) (void)hipFree(s->d_export);
@@ -755,10 +778,11 @@ int sm_clean_points(sm_ctx *s, const uint16_t *depth_mm, const uint8_t *semantic
     if (rc) return rc;
     memcpy(s->curr_pose, pose16, 64);
     FrameParams fp = make_params(s, pose16);
-    if ((rc = launch_prep(s, s->d_rgb, s->d_depth_raw, s->d_sem, nullptr, fp, false))) return rc;   // metriciseDepth only
+    if ((rc = launch_prep(s, s->d_rgb, s->d_depth_raw, s->d_sem, nullptr, fp, false, false))) return rc;   // metriciseDepth only
     fp.max_depth = s->cfg.far_clip - 15.0f;     // src/SurfelMapping.cpp:515
     fp.conflict_thresh = 0.1f;                  // :516
     fp.is_clean = 1;                            // :517
+    if ((rc = launch_tile_flags(s, fp))) return rc;
     if ((rc = launch_conflict(s, fp))) return rc;
     if ((rc = launch_compact(s, fp, false, false))) return rc;
     return sm_sync(s);
@@ -924,7 +948,7 @@ int sm_set_frame(sm_ctx *s, const uint8_t *rgb, const float *depth_metric, const
     const int tiles = ((s->W + 31) / 32) * ((s->H + 31) / 32);
     hipLaunchKernelGGL(k_prep, dim3(tiles), dim3(1024), 0, s->stream, s->d_rgb, (const uint16_t *)nullptr, s->d_sem,
                        depth_metric ? s->d_depth_f32 : nullptr, depth_metric ? s->d_depthT : nullptr, s->d_rgbsT,
-                       (uint64_t *)nullptr, fp);
+                       (uint64_t *)nullptr, fp, s->d_tb, (uint8_t *)nullptr);
     HIPCK(hipGetLastError());
     HIPCK(hipStreamSynchronize(s->stream));
     return SM_OK;
@@ -959,6 +983,7 @@ int sm_stage_conflict(sm_ctx *s, const float *pose16, float min_depth, float max
     fp.min_depth = min_depth; fp.max_depth = max_depth; fp.conflict_thresh = fuse_thresh; fp.is_clean = is_clean;
     s->count_before_cull = s->h_state->count;
     s->offset_before_cull = s->h_state->offset;
+    if ((rc = launch_tile_flags(s, fp))) return rc;
     if ((rc = launch_conflict(s, fp))) return rc;
     s->pending_cull = true;
     return sm_sync(s);

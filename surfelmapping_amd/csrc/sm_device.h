@@ -86,6 +86,7 @@ struct FrameParams {
     int init_mode;            // 1: every checkerboard pixel with 0 < z < far becomes a surfel, no association
     float inv_fx_fb, inv_fy_fb;   // 1.0f/fx as float division (src/FeedbackBuffer.cpp:93-96)
     int use_bounds;           // 1: whole 1024-surfel tiles are skipped when their bounding box is outside the view
+    uint32_t n_flag_tiles;    // tiles whose skip flags k_prep computes (host upper bound of the tile count)
 };
 
 // local index -> global id through the per-segment tables (segments = surfels created by one frame,
@@ -259,8 +260,9 @@ __device__ __forceinline__ uint32_t block_scan_1024(uint32_t v, uint32_t *total,
 // conservative (they only ever grow between rebuilds), skipping decisions add a 2-pixel / 1-cm
 // margin, so a skipped tile provably contains no surfel the exact per-surfel test would accept.
 // ---------------------------------------------------------------------------------------------
-constexpr uint32_t TB_LO_EMPTY = 0xFFFFFFFFu, TB_HI_EMPTY = 0u;
-
+// Encoding: every word is maintained with atomicMax only, so that one wave instruction (7 lanes, one word each)
+// updates a tile: [0..2] hold max(~ord(x)) = "negated minimum", [4..6] max(ord(x)), [7] max(ord(time));
+// an empty tile is all zeros (a memset).
 __device__ __forceinline__ uint32_t f2ord(float f)
 {
     const uint32_t b = __float_as_uint(f);
@@ -273,7 +275,7 @@ __device__ __forceinline__ float ord2f(uint32_t o)
 
 // expand the bounds of the tiles touched by this wave: each active lane contributes one surfel
 // (position, time, "bad") to tile `tile`; lanes are grouped by tile with ballots, reduced with
-// shuffles, and one lane per group issues the 7-8 atomics.
+// shuffles, and ONE atomicMax wave instruction (lanes 0..7 -> words 0..7 of the tile) publishes the group.
 __device__ __forceinline__ void bounds_expand_wave(uint32_t *__restrict__ tb, bool active, uint32_t tile, float x, float y,
                                                    float z, float t, bool bad)
 {
@@ -284,23 +286,21 @@ __device__ __forceinline__ void bounds_expand_wave(uint32_t *__restrict__ tb, bo
         const uint32_t tcur = (uint32_t)__shfl((int)tile, leader);
         const bool mine = active && tile == tcur;
         const uint64_t grp = __ballot(mine);
-        uint32_t lx = mine ? f2ord(x) : TB_LO_EMPTY, ly = mine ? f2ord(y) : TB_LO_EMPTY, lz = mine ? f2ord(z) : TB_LO_EMPTY;
-        uint32_t hx = mine ? f2ord(x) : TB_HI_EMPTY, hy = mine ? f2ord(y) : TB_HI_EMPTY, hz = mine ? f2ord(z) : TB_HI_EMPTY;
-        uint32_t ht = mine ? f2ord(t) : TB_HI_EMPTY;
+        uint32_t w0 = mine ? ~f2ord(x) : 0u, w1 = mine ? ~f2ord(y) : 0u, w2 = mine ? ~f2ord(z) : 0u;
+        uint32_t w4 = mine ? f2ord(x) : 0u, w5 = mine ? f2ord(y) : 0u, w6 = mine ? f2ord(z) : 0u, w7 = mine ? f2ord(t) : 0u;
         const uint32_t nb = (uint32_t)__popcll(__ballot(mine && (bad || x != x || y != y || z != z)));
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
-            lx = min(lx, (uint32_t)__shfl_xor((int)lx, o)); ly = min(ly, (uint32_t)__shfl_xor((int)ly, o));
-            lz = min(lz, (uint32_t)__shfl_xor((int)lz, o));
-            hx = max(hx, (uint32_t)__shfl_xor((int)hx, o)); hy = max(hy, (uint32_t)__shfl_xor((int)hy, o));
-            hz = max(hz, (uint32_t)__shfl_xor((int)hz, o)); ht = max(ht, (uint32_t)__shfl_xor((int)ht, o));
+            w0 = max(w0, (uint32_t)__shfl_xor((int)w0, o)); w1 = max(w1, (uint32_t)__shfl_xor((int)w1, o));
+            w2 = max(w2, (uint32_t)__shfl_xor((int)w2, o)); w4 = max(w4, (uint32_t)__shfl_xor((int)w4, o));
+            w5 = max(w5, (uint32_t)__shfl_xor((int)w5, o)); w6 = max(w6, (uint32_t)__shfl_xor((int)w6, o));
+            w7 = max(w7, (uint32_t)__shfl_xor((int)w7, o));
         }
-        if (lane == leader) {
-            uint32_t *b = tb + (size_t)tcur * 8;
-            atomicMin(&b[0], lx); atomicMin(&b[1], ly); atomicMin(&b[2], lz);
-            atomicMax(&b[4], hx); atomicMax(&b[5], hy); atomicMax(&b[6], hz); atomicMax(&b[7], ht);
-            if (nb) atomicAdd(&b[3], nb);
+        if (lane < 8 && lane != 3) {
+            const uint32_t val = lane == 0 ? w0 : lane == 1 ? w1 : lane == 2 ? w2 : lane == 4 ? w4 : lane == 5 ? w5 : lane == 6 ? w6 : w7;
+            atomicMax(&tb[(size_t)tcur * 8 + lane], val);
         }
+        if (nb && lane == 3) atomicAdd(&tb[(size_t)tcur * 8 + 3], nb);
         todo &= ~grp;
     }
 }
@@ -311,9 +311,9 @@ __device__ __forceinline__ void bounds_expand_wave(uint32_t *__restrict__ tb, bo
 __device__ __forceinline__ bool box_outside_view(const uint32_t *__restrict__ b, const float *t_inv, float fx, float fy, float cx,
                                                  float cy, float zlo, float zhi, float ulo, float uhi, float vlo, float vhi)
 {
-    if (b[0] == TB_LO_EMPTY && b[4] == TB_HI_EMPTY) return b[3] == 0u;       // no surfel recorded at all
     if (b[3] != 0u) return false;
-    const float lx = ord2f(b[0]), ly = ord2f(b[1]), lz = ord2f(b[2]), hx = ord2f(b[4]), hy = ord2f(b[5]), hz = ord2f(b[6]);
+    if (b[0] == 0u && b[4] == 0u) return true;                               // no surfel recorded at all
+    const float lx = ord2f(~b[0]), ly = ord2f(~b[1]), lz = ord2f(~b[2]), hx = ord2f(b[4]), hy = ord2f(b[5]), hz = ord2f(b[6]);
     float zmin = 3.0e38f, zmax = -3.0e38f;
     bool all_right = true, all_left = true, all_below = true, all_above = true, finite = true;
 #pragma unroll

@@ -12,6 +12,34 @@
 namespace sm {
 
 // ---------------------------------------------------------------------------------------------
+// Per-tile skip flags of the frame (bit 0: outside the conflict view volume, conflict.vert:35; bit 1:
+// cannot reach the index map, index_map.vert:45-55 incl. the timeDelta gate), from the tile bounds as they
+// stand at frame start.  One thread per tile; folded into k_prep so that it costs no launch.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void tile_flags_one(uint32_t t, const FrameParams &fp, const uint32_t *__restrict__ tb,
+                                               uint8_t *__restrict__ tile_flags)
+{
+    uint32_t f = 0;
+    if (fp.use_bounds) {
+        const uint32_t *b = tb + (size_t)t * 8;
+        if (box_outside_view(b, fp.t_inv, fp.fx, fp.fy, fp.cx, fp.cy, fp.min_depth, fp.max_depth, fp.stereo_border, fp.cols, 0.0f,
+                             fp.rows))
+            f |= 1u;
+        if (b[3] == 0u && ((b[0] == 0u && b[4] == 0u) || (float)fp.time - ord2f(b[7]) > (float)fp.time_delta ||
+                           box_outside_view(b, fp.t_inv, fp.fx, fp.fy, fp.cx, fp.cy, 0.0f, fp.depth_cutoff, 0.0f, fp.cols, 0.0f,
+                                            fp.rows)))
+            f |= 2u;
+    }
+    tile_flags[t] = (uint8_t)f;
+}
+
+__global__ void k_tile_flags(FrameParams fp, const uint32_t *__restrict__ tb, uint8_t *__restrict__ tile_flags)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < fp.n_flag_tiles) tile_flags_one(t, fp, tb, tile_flags);
+}
+
+// ---------------------------------------------------------------------------------------------
 // p0a metricise (depth_metric.frag:15-35) + u8 RGB/semantic pack + LDS-tiled transpose to the
 // column-major frame layout + key-map clear.  32x32 pixel tile per 1024-thread workgroup.
 // ---------------------------------------------------------------------------------------------
@@ -20,9 +48,14 @@ __global__ __launch_bounds__(1024) void k_prep(const uint8_t *__restrict__ rgb,
                                                const uint8_t *__restrict__ sem,
                                                const float *__restrict__ depth_f32,  // optional: metric depth given directly
                                                float *__restrict__ depthT, uint32_t *__restrict__ rgbsT,
-                                               uint64_t *__restrict__ keyT, FrameParams fp)
+                                               uint64_t *__restrict__ keyT, FrameParams fp,
+                                               const uint32_t *__restrict__ tb, uint8_t *__restrict__ tile_flags)
 {
     __shared__ float s_d[32][33];
+    if (tile_flags) {
+        const uint32_t t = blockIdx.x * 1024u + threadIdx.x;
+        if (t < fp.n_flag_tiles) tile_flags_one(t, fp, tb, tile_flags);
+    }
     __shared__ uint32_t s_c[32][33];
     const int W = fp.W, H = fp.H;
     const int tiles_x = (W + 31) >> 5;
@@ -217,7 +250,7 @@ __global__ __launch_bounds__(256) void k_conflict(Model M, const DevState *__res
                                                   const uint32_t *__restrict__ rgbsT,
                                                   uint64_t *__restrict__ cm, uint64_t *__restrict__ dm,
                                                   uint64_t *__restrict__ zm, uint32_t *__restrict__ tile_cnt,
-                                                  const uint32_t *__restrict__ tb, DevState *__restrict__ st_rw)
+                                                  const uint8_t *__restrict__ tile_flags, DevState *__restrict__ st_rw)
 {
     __shared__ uint32_t s_red[4][3];
     __shared__ uint64_t s_m[3][TILE_WORDS];
@@ -226,12 +259,18 @@ __global__ __launch_bounds__(256) void k_conflict(Model M, const DevState *__res
     const uint32_t ntiles = (N + TILE - 1) / TILE;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t skipped = 0;
-    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    uint64_t skipmask = 0;
+    uint32_t iter = 0;
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x, ++iter) {
         uint32_t nconf = 0, nkill = 0, nzero = 0;
+        if ((iter & 63u) == 0u) {
+            // the skip flags of this workgroup's next 64 tiles in one load (lane i <-> i-th tile)
+            const uint64_t tl = (uint64_t)tile + (uint64_t)lane * gridDim.x;
+            skipmask = __ballot(tl < ntiles && (tile_flags[tl < ntiles ? tl : 0] & 1u));
+        }
         // whole tile outside the conflict view volume (conflict.vert:35)?  Then nothing conflicts, and a tile
         // without "bad" surfels has nothing dead either: zero masks, zero counts, no surfel read.
-        if (fp.use_bounds && box_outside_view(tb + (size_t)tile * 8, fp.t_inv, fp.fx, fp.fy, fp.cx, fp.cy, fp.min_depth,
-                                              fp.max_depth, fp.stereo_border, fp.cols, 0.0f, fp.rows)) {
+        if ((skipmask >> (iter & 63u)) & 1ull) {
             if (threadIdx.x < 3) tile_cnt[tile * 3 + threadIdx.x] = 0u;
             if (threadIdx.x >= 64 && threadIdx.x < 64 + 3 * TILE_WORDS) {
                 const int m = (threadIdx.x - 64) / TILE_WORDS, w = (threadIdx.x - 64) % TILE_WORDS;
@@ -451,9 +490,9 @@ __global__ __launch_bounds__(1024) void k_cull_finalize(DevState *__restrict__ s
         const uint32_t first = (ktotal == N) ? kept_tiles : min(nstatic / (uint32_t)TILE, kept_tiles);
         const uint32_t last = min(tb_tiles, ntiles + ((uint32_t)fp.P / 2u) / (uint32_t)TILE + 3u);
         for (uint32_t t = first + threadIdx.x; t < last; t += 1024u) {
-            uint32_t *b = tb + (size_t)t * 8;
-            b[0] = TB_LO_EMPTY; b[1] = TB_LO_EMPTY; b[2] = TB_LO_EMPTY; b[3] = 0u;
-            b[4] = TB_HI_EMPTY; b[5] = TB_HI_EMPTY; b[6] = TB_HI_EMPTY; b[7] = TB_HI_EMPTY;
+            uint4 *b = reinterpret_cast<uint4 *>(tb + (size_t)t * 8);
+            b[0] = make_uint4(0u, 0u, 0u, 0u);
+            b[1] = make_uint4(0u, 0u, 0u, 0u);
         }
     }
     if (threadIdx.x == 0) {
@@ -525,7 +564,7 @@ __global__ __launch_bounds__(256) void k_compact(Model M, DevState *__restrict__
                                                  const uint32_t *__restrict__ seg_lstart,
                                                  const uint32_t *__restrict__ seg_gbase,
                                                  const uint32_t *__restrict__ group_keep_base,
-                                                 uint32_t *__restrict__ tb)
+                                                 uint32_t *__restrict__ tb, const uint8_t *__restrict__ tile_flags)
 {
     __shared__ uint64_t s_keep[TILE_WORDS], s_ceff[TILE_WORDS];
     __shared__ uint32_t s_cpop[TILE_WORDS], s_kpre[TILE_WORDS + 1];
@@ -534,8 +573,13 @@ __global__ __launch_bounds__(256) void k_compact(Model M, DevState *__restrict__
     const SurfelSet set = M.s[st->cull_src];
     const uint32_t ntiles = (N + TILE - 1) / TILE;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t vis = 0, skipped = 0;
-    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    uint32_t vis = 0, skipped = 0, iter = 0;
+    uint64_t skipmask = 0;
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x, ++iter) {
+        if ((iter & 63u) == 0u) {
+            const uint64_t tl = (uint64_t)tile + (uint64_t)lane * gridDim.x;
+            skipmask = __ballot(tl < ntiles && (tile_flags[tl < ntiles ? tl : 0] & 2u));
+        }
         const uint32_t allow = tile_allow[tile], nconf = tile_cnt[tile * 3];
         // fast path (workgroup-uniform): nothing of this tile conflicts, dies or moves -- the bulk of the map
         // once the camera has passed.  No masks, no LDS, no barriers: read pos+time, splat.
@@ -543,11 +587,7 @@ __global__ __launch_bounds__(256) void k_compact(Model M, DevState *__restrict__
             tile_keep_prefix[tile] + group_keep_base[tile / GROUP] == tile * (uint32_t)TILE) {
             // ... and if its box cannot reach the index map (index_map.vert:45-55: 0 < z < far inside the image,
             // updated within timeDelta frames) it is not even read
-            if (SPLAT && fp.use_bounds &&
-                ((float)fp.time - ord2f(tb[(size_t)tile * 8 + 7]) > (float)fp.time_delta ||
-                 box_outside_view(tb + (size_t)tile * 8, fp.t_inv, fp.fx, fp.fy, fp.cx, fp.cy, 0.0f, fp.depth_cutoff, 0.0f,
-                                  fp.cols, 0.0f, fp.rows)) &&
-                tb[(size_t)tile * 8 + 3] == 0u && tb[(size_t)tile * 8 + 4] != TB_HI_EMPTY) {
+            if (SPLAT && ((skipmask >> (iter & 63u)) & 1ull)) {
                 skipped += min((uint32_t)TILE, N - tile * TILE);
                 continue;
             }
@@ -852,9 +892,9 @@ __device__ __forceinline__ void associate_pixel(int q, const SurfelSet &cur, con
                     {   // the fused surfel moved: grow its tile's box if it left it (stale reads only cause a redundant atomic)
                         uint32_t *b = tb + (size_t)(id / (uint32_t)TILE) * 8;
                         const uint32_t ox = f2ord(opc.x), oy = f2ord(opc.y), oz = f2ord(opc.z), ot = f2ord((float)fp.time);
-                        if (ox < b[0]) atomicMin(&b[0], ox);
-                        if (oy < b[1]) atomicMin(&b[1], oy);
-                        if (oz < b[2]) atomicMin(&b[2], oz);
+                        if (~ox > b[0]) atomicMax(&b[0], ~ox);
+                        if (~oy > b[1]) atomicMax(&b[1], ~oy);
+                        if (~oz > b[2]) atomicMax(&b[2], ~oz);
                         if (ox > b[4]) atomicMax(&b[4], ox);
                         if (oy > b[5]) atomicMax(&b[5], oy);
                         if (oz > b[6]) atomicMax(&b[6], oz);
@@ -1200,9 +1240,9 @@ __global__ void k_tile_bounds_reset(uint32_t *__restrict__ tb, uint32_t first, u
 {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
-    uint32_t *b = tb + (size_t)(first + t) * 8;
-    b[0] = TB_LO_EMPTY; b[1] = TB_LO_EMPTY; b[2] = TB_LO_EMPTY; b[3] = 0u;
-    b[4] = TB_HI_EMPTY; b[5] = TB_HI_EMPTY; b[6] = TB_HI_EMPTY; b[7] = TB_HI_EMPTY;
+    uint4 *b = reinterpret_cast<uint4 *>(tb + (size_t)(first + t) * 8);
+    b[0] = make_uint4(0u, 0u, 0u, 0u);
+    b[1] = make_uint4(0u, 0u, 0u, 0u);
 }
 
 __global__ __launch_bounds__(256) void k_tile_bounds_build(Model M, const DevState *__restrict__ st, uint32_t *__restrict__ tb,
