@@ -137,6 +137,9 @@ struct sm_ctx {
     uint32_t *d_group_tot = nullptr, *d_group_base = nullptr;
     uint32_t *d_tb = nullptr;          // per-tile bounds (8 words per tile)
     uint8_t *d_tile_flags = nullptr;   // per-tile skip flags of the current frame
+    uint32_t *d_conf_part = nullptr;   // per-workgroup partial counters (instead of same-address atomics)
+    uint2 *d_compact_part = nullptr;
+    uint32_t n_conf_part = 0, n_compact_part = 0;
     uint32_t tb_tiles = 0;
     uint32_t cull_epoch = 0;
     int compact_grid = COMPACT_GRID;
@@ -320,8 +323,9 @@ int mark(sm_ctx *s, int which, bool timed)
 
 int launch_conflict(sm_ctx *s, const FrameParams &fp, bool timed = false)
 {
-    hipLaunchKernelGGL(k_conflict, dim3(grid_surfels(s)), dim3(256), 0, s->stream, s->M, s->d_state, fp, s->d_depthT,
-                       s->d_rgbsT, s->d_cm, s->d_dm, s->d_zm, s->d_tile_cnt, s->d_tile_flags, s->d_state);
+    s->n_conf_part = (uint32_t)grid_surfels(s);
+    hipLaunchKernelGGL(k_conflict, dim3(s->n_conf_part), dim3(256), 0, s->stream, s->M, s->d_state, fp, s->d_depthT,
+                       s->d_rgbsT, s->d_cm, s->d_dm, s->d_zm, s->d_tile_cnt, s->d_tile_flags, s->d_conf_part);
     HIPCK(hipGetLastError());
     if (mark(s, 2, timed)) return SM_E_HIP;
     const int ngroups = std::max<int>(1, (int)((((uint64_t)s->count_bound + TILE - 1) / TILE + GROUP - 1) / GROUP));
@@ -329,7 +333,7 @@ int launch_conflict(sm_ctx *s, const FrameParams &fp, bool timed = false)
                        s->d_tile_keep, s->d_group_tot);
     HIPCK(hipGetLastError());
     hipLaunchKernelGGL(k_cull_finalize, dim3(1), dim3(1024), 0, s->stream, s->d_state, fp, s->d_cm, s->d_dm, s->d_zm,
-                       s->d_tile_cnt, s->d_tile_allow, s->d_tile_keep, s->d_group_tot, s->d_group_base, s->d_tb, s->tb_tiles);
+                       s->d_tile_cnt, s->d_tile_allow, s->d_tile_keep, s->d_group_tot, s->d_group_base, s->d_conf_part, s->n_conf_part);
     HIPCK(hipGetLastError());
     if (mark(s, 3, timed)) return SM_E_HIP;
     return SM_OK;
@@ -339,14 +343,15 @@ int launch_compact(sm_ctx *s, const FrameParams &fp, bool splat, bool timed)
 {
     const int grid = std::min(grid_surfels(s), s->compact_grid);
     const uint32_t epoch = ++s->cull_epoch;
+    s->n_compact_part = splat ? (uint32_t)grid : 0u;
     if (splat)
         hipLaunchKernelGGL(k_compact<true>, dim3(grid), dim3(256), 0, s->stream, s->M, s->d_state, fp, s->d_cm,
                            s->d_dm, s->d_zm, s->d_tile_cnt, s->d_tile_allow, s->d_tile_keep, s->d_keyT, s->d_tile_flag, epoch,
-                           s->d_seg_lstart, s->d_seg_gbase, s->d_group_base, s->d_tb, s->d_tile_flags);
+                           s->d_seg_lstart, s->d_seg_gbase, s->d_group_base, s->d_tb, s->d_tile_flags, s->d_compact_part);
     else
         hipLaunchKernelGGL(k_compact<false>, dim3(grid), dim3(256), 0, s->stream, s->M, s->d_state, fp, s->d_cm,
                            s->d_dm, s->d_zm, s->d_tile_cnt, s->d_tile_allow, s->d_tile_keep, s->d_keyT, s->d_tile_flag, epoch,
-                           s->d_seg_lstart, s->d_seg_gbase, s->d_group_base, s->d_tb, s->d_tile_flags);
+                           s->d_seg_lstart, s->d_seg_gbase, s->d_group_base, s->d_tb, s->d_tile_flags, s->d_compact_part);
     HIPCK(hipGetLastError());
     if (mark(s, 4, timed)) return SM_E_HIP;
     return SM_OK;
@@ -364,7 +369,7 @@ int launch_associate_only(sm_ctx *s, const FrameParams &fp)
 int launch_append(sm_ctx *s, const FrameParams &fp, bool timed)
 {
     hipLaunchKernelGGL(k_scan_new, dim3(1), dim3(1024), 0, s->stream, s->d_state, fp, s->n_pix_blocks, s->d_validmask,
-                       s->d_fusedmask, s->d_blk_prefix, s->d_log);
+                       s->d_fusedmask, s->d_blk_prefix, s->d_log, s->d_compact_part, s->n_compact_part);
     HIPCK(hipGetLastError());
     if (mark(s, 6, timed)) return SM_E_HIP;
     hipLaunchKernelGGL(k_append, dim3(s->n_pix_blocks), dim3(PIX_BLOCK), 0, s->stream, s->M, s->d_state, fp, s->d_depthT,
@@ -383,7 +388,8 @@ int launch_associate_fused(sm_ctx *s, const FrameParams &fp, bool timed)
     }
     const int grid = std::min(s->n_pix_blocks, s->assoc_grid);
     hipLaunchKernelGGL(k_associate_append, dim3(grid), dim3(PIX_BLOCK), 0, s->stream, s->M, s->d_state, fp, s->d_depthT,
-                       s->d_rgbsT, s->d_keyT, s->d_xs, s->d_ys, s->d_desc, s->assoc_epoch, s->n_pix_blocks, s->d_log, s->d_tb);
+                       s->d_rgbsT, s->d_keyT, s->d_xs, s->d_ys, s->d_desc, s->assoc_epoch, s->n_pix_blocks, s->d_log, s->d_tb,
+                       s->d_compact_part, s->n_compact_part);
     HIPCK(hipGetLastError());
     if (mark(s, 5, timed) || mark(s, 6, timed) || mark(s, 7, timed)) return SM_E_HIP;
     return SM_OK;
@@ -403,7 +409,8 @@ int launch_associate(sm_ctx *s, const FrameParams &fp, bool timed)
         // single GPU: the append derives its own prefix from the per-block counts (no scan kernel)
         if (mark(s, 6, timed)) return SM_E_HIP;
         hipLaunchKernelGGL(k_append_scan, dim3(s->n_pix_blocks), dim3(PIX_BLOCK), 0, s->stream, s->M, s->d_state, fp, s->d_depthT,
-                           s->d_rgbsT, s->d_xs, s->d_ys, s->d_validmask, s->d_fusedmask, s->d_blk_cnt, s->d_log, s->d_tb);
+                           s->d_rgbsT, s->d_xs, s->d_ys, s->d_validmask, s->d_fusedmask, s->d_blk_cnt, s->d_log, s->d_tb, s->d_compact_part,
+                           s->n_compact_part);
         HIPCK(hipGetLastError());
         if (mark(s, 7, timed)) return SM_E_HIP;
         return SM_OK;
@@ -625,6 +632,7 @@ sm_ctx *sm_create(const sm_config *c)
          hipMemset(s->d_tile_flag, 0, ntiles * 4) == hipSuccess &&
          dalloc(&s->d_group_tot, (ntiles / GROUP + 2) * 4) == SM_OK && dalloc(&s->d_group_base, ntiles / GROUP + 2) == SM_OK;
     s->tb_tiles = (uint32_t)(ntiles + P / 2 / TILE + 8);
+    ok = ok && dalloc(&s->d_conf_part, (size_t)MAX_GRID) == SM_OK && dalloc(&s->d_compact_part, (size_t)MAX_GRID) == SM_OK;
     ok = ok && dalloc(&s->d_tb, (size_t)s->tb_tiles * 8) == SM_OK && dalloc(&s->d_tile_flags, (size_t)s->tb_tiles) == SM_OK &&
          hipMemset(s->d_tile_flags, 0, s->tb_tiles) == hipSuccess;
     ok = ok && dalloc(&s->d_validmask, (P + 63) / 64 + 4) == SM_OK && dalloc(&s->d_fusedmask, (P + 63) / 64 + 4) == SM_OK;
@@ -728,7 +736,7 @@ void sm_destroy(sm_ctx *s)
     (void)hipFree(s->d_rgb); (void)hipFree(s->d_sem); (void)hipFree(s->d_depth_raw); (void)hipFree(s->d_depth_f32);
     (void)hipFree(s->d_xs); (void)hipFree(s->d_ys); (void)hipFree(s->d_wtab);
     (void)hipFree(s->d_cm); (void)hipFree(s->d_dm); (void)hipFree(s->d_zm);
-    (void)hipFree(s->d_tile_cnt); (void)hipFree(s->d_tile_allow); (void)hipFree(s->d_tile_keep); (void)hipFree(s->d_tile_flag); (void)hipFree(s->d_group_tot); (void)hipFree(s->d_group_base); (void)hipFree(s->d_tb); (void)hipFree(s->d_tile_flags);
+    (void)hipFree(s->d_tile_cnt); (void)hipFree(s->d_tile_allow); (void)hipFree(s->d_tile_keep); (void)hipFree(s->d_tile_flag); (void)hipFree(s->d_group_tot); (void)hipFree(s->d_group_base); (void)hipFree(s->d_tb); (void)hipFree(s->d_tile_flags); (void)hipFree(s->d_conf_part); (void)hipFree(s->d_compact_part);
     (void)hipFree(s->d_validmask); (void)hipFree(s->d_fusedmask); (void)hipFree(s->d_blk_prefix); (void)hipFree(s->d_desc); (void)hipFree(s->d_blk_cnt);
     (void)hipFree(s->d_seg_lstart); (void)hipFree(s->d_seg_gbase); (void)hipFree(s->d_gseg_base); (void)hipFree(s->d_seg_keep);
     if (s->d_export) (void)hipFree(s->d_export);
@@ -1012,6 +1020,7 @@ int sm_stage_splat(sm_ctx *s, const float *pose16, int32_t time, float depth_cut
     FrameParams fp = make_params(s, pose16);
     fp.time = time; fp.depth_cutoff = depth_cutoff; fp.time_delta = time_delta;
     HIPCK(hipMemsetAsync(&s->d_state->visible_count, 0, 4, s->stream));
+    s->n_compact_part = 0;                       // k_splat counts with an atomic; no k_compact partials to fold in
     hipLaunchKernelGGL(k_fill_keys, dim3((s->P + 255) / 256), dim3(256), 0, s->stream, s->d_keyT, s->P);
     HIPCK(hipGetLastError());
     const int grid = (int)std::min<uint64_t>(std::max<uint64_t>(((uint64_t)s->h_state->count + 255) / 256, 1), MAX_GRID);

@@ -52,9 +52,9 @@ __global__ __launch_bounds__(1024) void k_prep(const uint8_t *__restrict__ rgb,
                                                const uint32_t *__restrict__ tb, uint8_t *__restrict__ tile_flags)
 {
     __shared__ float s_d[32][33];
-    if (tile_flags) {
-        const uint32_t t = blockIdx.x * 1024u + threadIdx.x;
-        if (t < fp.n_flag_tiles) tile_flags_one(t, fp, tb, tile_flags);
+    if (tile_flags) {       // tile t = block + thread * grid: a handful of lanes of wave 0 in every workgroup
+        const uint64_t t = (uint64_t)blockIdx.x + (uint64_t)threadIdx.x * gridDim.x;
+        if (t < fp.n_flag_tiles) tile_flags_one((uint32_t)t, fp, tb, tile_flags);
     }
     __shared__ uint32_t s_c[32][33];
     const int W = fp.W, H = fp.H;
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(256) void k_conflict(Model M, const DevState *__res
                                                   const uint32_t *__restrict__ rgbsT,
                                                   uint64_t *__restrict__ cm, uint64_t *__restrict__ dm,
                                                   uint64_t *__restrict__ zm, uint32_t *__restrict__ tile_cnt,
-                                                  const uint8_t *__restrict__ tile_flags, DevState *__restrict__ st_rw)
+                                                  const uint8_t *__restrict__ tile_flags, uint32_t *__restrict__ blk_part /* [grid] skipped */)
 {
     __shared__ uint32_t s_red[4][3];
     __shared__ uint64_t s_m[3][TILE_WORDS];
@@ -356,7 +356,7 @@ __global__ __launch_bounds__(256) void k_conflict(Model M, const DevState *__res
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0 && skipped) atomicAdd(&st_rw->n_conf_skipped, skipped);
+    if (threadIdx.x == 0) blk_part[blockIdx.x] = skipped;      // summed by k_cull_finalize (no same-address atomics)
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -414,7 +414,7 @@ __global__ __launch_bounds__(1024) void k_cull_finalize(DevState *__restrict__ s
                                                         uint32_t *__restrict__ tile_keep_prefix,
                                                         const uint32_t *__restrict__ group_tot,
                                                         uint32_t *__restrict__ group_keep_base,
-                                                        uint32_t *__restrict__ tb, uint32_t tb_tiles)
+                                                        const uint32_t *__restrict__ conf_part, uint32_t n_conf_part)
 {
     __shared__ uint32_t s_scan[17];
     __shared__ uint32_t s_first;
@@ -483,21 +483,12 @@ __global__ __launch_bounds__(1024) void k_cull_finalize(DevState *__restrict__ s
         }
         block_scan_1024(ns, &nstatic, s_scan);
     }
-    {
-        // tile bounds: every tile from the first one that loses a surfel onwards is rewritten by the compaction
-        // (and re-expanded there); tiles past the survivors will receive this frame's new surfels
-        const uint32_t kept_tiles = (ktotal + TILE - 1) / TILE;
-        const uint32_t first = (ktotal == N) ? kept_tiles : min(nstatic / (uint32_t)TILE, kept_tiles);
-        const uint32_t last = min(tb_tiles, ntiles + ((uint32_t)fp.P / 2u) / (uint32_t)TILE + 3u);
-        for (uint32_t t = first + threadIdx.x; t < last; t += 1024u) {
-            uint4 *b = reinterpret_cast<uint4 *>(tb + (size_t)t * 8);
-            b[0] = make_uint4(0u, 0u, 0u, 0u);
-            b[1] = make_uint4(0u, 0u, 0u, 0u);
-        }
-    }
+    uint32_t cskip = 0, cskip_tot;
+    for (uint32_t b = threadIdx.x; b < n_conf_part; b += 1024u) cskip += conf_part[b];
+    block_scan_1024(cskip, &cskip_tot, s_scan);
     if (threadIdx.x == 0) {
         const uint32_t kept = ktotal;
-        st->n_splat_skipped = 0;
+        st->n_conf_skipped = cskip_tot;
         st->n_static = nstatic;
         st->cull_n = N;
         st->n_kill = N - kept;
@@ -564,7 +555,8 @@ __global__ __launch_bounds__(256) void k_compact(Model M, DevState *__restrict__
                                                  const uint32_t *__restrict__ seg_lstart,
                                                  const uint32_t *__restrict__ seg_gbase,
                                                  const uint32_t *__restrict__ group_keep_base,
-                                                 uint32_t *__restrict__ tb, const uint8_t *__restrict__ tile_flags)
+                                                 uint32_t *__restrict__ tb, const uint8_t *__restrict__ tile_flags,
+                                                 uint2 *__restrict__ blk_part /* [grid] (visible, splat-skipped) */)
 {
     __shared__ uint64_t s_keep[TILE_WORDS], s_ceff[TILE_WORDS];
     __shared__ uint32_t s_cpop[TILE_WORDS], s_kpre[TILE_WORDS + 1];
@@ -675,7 +667,11 @@ __global__ __launch_bounds__(256) void k_compact(Model M, DevState *__restrict__
             }
         }
         if (moving) {
-            // all loads of this workgroup have returned before the flag goes out
+            // This tile's slot is rewritten by the compaction (by this or a higher tile): empty its bounds entry now.
+            // Atomic (memory-side) stores, completed by the wait below, so that the atomicMax of any later writer --
+            // which first waits for this tile's flag -- is ordered after them on every XCD.
+            if (threadIdx.x < 8) atomicExch(&tb[(size_t)tile * 8 + threadIdx.x], 0u);
+            // all loads (and the reset) of this workgroup have completed before the flag goes out
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (threadIdx.x == 0) {
@@ -719,11 +715,8 @@ __global__ __launch_bounds__(256) void k_compact(Model M, DevState *__restrict__
     if (SPLAT) {
         if (lane == 0) s_vis[wave] = vis;
         __syncthreads();
-        if (threadIdx.x == 0) {
-            const uint32_t t = s_vis[0] + s_vis[1] + s_vis[2] + s_vis[3];
-            if (t) atomicAdd(&st->visible_count, t);
-            if (skipped) atomicAdd(&st->n_splat_skipped, skipped);
-        }
+        if (threadIdx.x == 0)      // per-workgroup partials, summed by the append kernel (no same-address atomics)
+            blk_part[blockIdx.x] = make_uint2(s_vis[0] + s_vis[1] + s_vis[2] + s_vis[3], skipped);
     }
 }
 
@@ -977,7 +970,8 @@ __global__ __launch_bounds__(PIX_BLOCK) void k_associate_append(Model M, DevStat
                                                                 const uint64_t *__restrict__ keyT,
                                                                 const float *__restrict__ xs, const float *__restrict__ ys,
                                                                 unsigned long long *__restrict__ desc, uint32_t epoch, int nblocks,
-                                                                FrameLog *__restrict__ log, uint32_t *__restrict__ tb)
+                                                                FrameLog *__restrict__ log, uint32_t *__restrict__ tb,
+                                                                const uint2 *__restrict__ compact_part, uint32_t n_compact_part)
 {
     __shared__ uint64_t s_nw[4];
     __shared__ uint32_t s_f[4];
@@ -1045,6 +1039,11 @@ __global__ __launch_bounds__(PIX_BLOCK) void k_associate_append(Model M, DevStat
         if (b == nblocks - 1 && threadIdx.x == 0) {
             // this block's inclusive prefix is the frame total (GlobalModel::concatenate src/GlobalModel.cpp:629)
             const uint32_t ntot = excl_n + own_new, ftot = s_excl[1] + own_f;
+            if (n_compact_part) {
+                uint32_t cv = 0, cs = 0;
+                for (uint32_t i = 0; i < n_compact_part; ++i) { cv += compact_part[i].x; cs += compact_part[i].y; }
+                st->visible_count = cv; st->n_splat_skipped = cs;
+            }
             st->unstable_count = ntot;
             st->fused_count = ftot;
             st->data_count = ntot + ftot;
@@ -1077,9 +1076,15 @@ __global__ __launch_bounds__(PIX_BLOCK) void k_associate_append(Model M, DevStat
 __global__ __launch_bounds__(1024) void k_scan_new(DevState *__restrict__ st, FrameParams fp, int nblocks,
                                                    const uint64_t *__restrict__ validmask,
                                                    const uint64_t *__restrict__ fusedmask,
-                                                   uint32_t *__restrict__ blk_prefix, FrameLog *__restrict__ log)
+                                                   uint32_t *__restrict__ blk_prefix, FrameLog *__restrict__ log,
+                                                   const uint2 *__restrict__ compact_part, uint32_t n_compact_part)
 {
     __shared__ uint32_t s_scan[17];
+    uint32_t pv = 0, ps = 0, vis_tot, skip_tot;
+    for (uint32_t b = threadIdx.x; b < n_compact_part; b += 1024u) { const uint2 c = compact_part[b]; pv += c.x; ps += c.y; }
+    block_scan_1024(pv, &vis_tot, s_scan);
+    block_scan_1024(ps, &skip_tot, s_scan);
+    if (threadIdx.x == 0 && n_compact_part) { st->visible_count = vis_tot; st->n_splat_skipped = skip_tot; }
     const uint32_t nb = (uint32_t)nblocks;
     const uint32_t nwords = ((uint32_t)fp.P + 63u) >> 6;
     uint32_t ncarry = 0, fcarry = 0;
@@ -1172,9 +1177,11 @@ __global__ __launch_bounds__(PIX_BLOCK) void k_append_scan(Model M, DevState *__
                                                            const uint64_t *__restrict__ validmask,
                                                            const uint64_t *__restrict__ fusedmask,
                                                            const uint2 *__restrict__ blk_cnt, FrameLog *__restrict__ log,
-                                                           uint32_t *__restrict__ tb)
+                                                           uint32_t *__restrict__ tb, const uint2 *__restrict__ compact_part,
+                                                           uint32_t n_compact_part)
 {
     __shared__ uint32_t s_red[2][4];
+    __shared__ uint32_t s_cp[2][4];
     const SurfelSet cur = M.s[st->cur];
     const uint32_t offset = st->offset;
     const int q = blockIdx.x * PIX_BLOCK + threadIdx.x;
@@ -1187,6 +1194,13 @@ __global__ __launch_bounds__(PIX_BLOCK) void k_append_scan(Model M, DevState *__
         if (b < (int)blockIdx.x) pn += c.x;
         if (last) { pf += c.y; tn += c.x; }
     }
+    uint32_t cv = 0, cs = 0;                                      // visible / splat-skipped partials of k_compact
+    if (last) {
+        for (uint32_t b = threadIdx.x; b < n_compact_part; b += PIX_BLOCK) { const uint2 c = compact_part[b]; cv += c.x; cs += c.y; }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { cv += __shfl_xor(cv, o); cs += __shfl_xor(cs, o); }
+        if (lane == 0) { s_cp[0][wave] = cv; s_cp[1][wave] = cs; }
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { pn += __shfl_xor(pn, o); pf += __shfl_xor(pf, o); tn += __shfl_xor(tn, o); }
     if (lane == 0) { s_red[0][wave] = pn; s_red[1][wave] = pf; }
@@ -1197,6 +1211,10 @@ __global__ __launch_bounds__(PIX_BLOCK) void k_append_scan(Model M, DevState *__
     if (last && threadIdx.x == 0) {
         const uint32_t ntot = s_tn[0] + s_tn[1] + s_tn[2] + s_tn[3];
         const uint32_t ftot = s_red[1][0] + s_red[1][1] + s_red[1][2] + s_red[1][3];
+        if (n_compact_part) {
+            st->visible_count = s_cp[0][0] + s_cp[0][1] + s_cp[0][2] + s_cp[0][3];
+            st->n_splat_skipped = s_cp[1][0] + s_cp[1][1] + s_cp[1][2] + s_cp[1][3];
+        }
         st->unstable_count = ntot;
         st->fused_count = ftot;
         st->data_count = ntot + ftot;
