@@ -20,15 +20,37 @@ __device__ __forceinline__ void tile_flags_one(uint32_t t, const FrameParams &fp
                                                uint8_t *__restrict__ tile_flags)
 {
     uint32_t f = 0;
-    if (fp.use_bounds) {
-        const uint32_t *b = tb + (size_t)t * 8;
-        if (box_outside_view(b, fp.t_inv, fp.fx, fp.fy, fp.cx, fp.cy, fp.min_depth, fp.max_depth, fp.stereo_border, fp.cols, 0.0f,
-                             fp.rows))
-            f |= 1u;
-        if (b[3] == 0u && ((b[0] == 0u && b[4] == 0u) || (float)fp.time - ord2f(b[7]) > (float)fp.time_delta ||
-                           box_outside_view(b, fp.t_inv, fp.fx, fp.fy, fp.cx, fp.cy, 0.0f, fp.depth_cutoff, 0.0f, fp.cols, 0.0f,
-                                            fp.rows)))
-            f |= 2u;
+    const uint32_t *b = tb + (size_t)t * 8;
+    if (fp.use_bounds && b[3] == 0u) {
+        if (b[0] == 0u && b[4] == 0u) {
+            f = 3u;                                        // no surfel recorded at all
+        } else {
+            // one transform of the 8 box corners serves both view volumes (they share three of the four side planes)
+            const float lx = ord2f(~b[0]), ly = ord2f(~b[1]), lz = ord2f(~b[2]), hx = ord2f(b[4]), hy = ord2f(b[5]), hz = ord2f(b[6]);
+            float zmin = 3.0e38f, zmax = -3.0e38f;
+            bool right = true, left_c = true, left_s = true, below = true, above = true, finite = true;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const float3 p = xform3(fp.t_inv, (c & 1) ? hx : lx, (c & 2) ? hy : ly, (c & 4) ? hz : lz);
+                finite = finite && (p.x - p.x == 0.0f) && (p.y - p.y == 0.0f) && (p.z - p.z == 0.0f);
+                zmin = fminf(zmin, p.z); zmax = fmaxf(zmax, p.z);
+                right = right && (fp.fx * p.x + (fp.cx - fp.cols - 2.0f) * p.z > 0.0f);
+                left_c = left_c && (fp.fx * p.x + (fp.cx - fp.stereo_border + 2.0f) * p.z < 0.0f);
+                left_s = left_s && (fp.fx * p.x + (fp.cx + 2.0f) * p.z < 0.0f);
+                below = below && (fp.fy * p.y + (fp.cy - fp.rows - 2.0f) * p.z > 0.0f);
+                above = above && (fp.fy * p.y + (fp.cy + 2.0f) * p.z < 0.0f);
+            }
+            if (finite) {
+                const bool front = zmin > 1.0e-3f;
+                // bit 0: conflict.vert:35  (min < Z < max, border <= u <= cols, 0 <= v <= rows)
+                if (zmax < fp.min_depth - 0.01f || zmin > fp.max_depth + 0.01f || (front && (right || left_c || below || above)))
+                    f |= 1u;
+                // bit 1: index_map.vert:45-55  (0 < Z < far, inside the image, updated within timeDelta frames)
+                if (zmax < -0.01f || zmin > fp.depth_cutoff + 0.01f || (front && (right || left_s || below || above)) ||
+                    (float)fp.time - ord2f(b[7]) > (float)fp.time_delta)
+                    f |= 2u;
+            }
+        }
     }
     tile_flags[t] = (uint8_t)f;
 }
@@ -52,9 +74,10 @@ __global__ __launch_bounds__(1024) void k_prep(const uint8_t *__restrict__ rgb,
                                                const uint32_t *__restrict__ tb, uint8_t *__restrict__ tile_flags)
 {
     __shared__ float s_d[32][33];
-    if (tile_flags) {       // tile t = block + thread * grid: a handful of lanes of wave 0 in every workgroup
-        const uint64_t t = (uint64_t)blockIdx.x + (uint64_t)threadIdx.x * gridDim.x;
-        if (t < fp.n_flag_tiles) tile_flags_one((uint32_t)t, fp, tb, tile_flags);
+    if (tile_flags && (threadIdx.x & 63) == 0) {       // lane 0 of every wave of the launch takes tiles in turn
+        const uint32_t nwaves = gridDim.x * 16u;
+        for (uint32_t t = blockIdx.x * 16u + (threadIdx.x >> 6); t < fp.n_flag_tiles; t += nwaves)
+            tile_flags_one(t, fp, tb, tile_flags);
     }
     __shared__ uint32_t s_c[32][33];
     const int W = fp.W, H = fp.H;
@@ -567,16 +590,24 @@ __global__ __launch_bounds__(256) void k_compact(Model M, DevState *__restrict__
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t vis = 0, skipped = 0, iter = 0;
     uint64_t skipmask = 0;
+    uint32_t m_nconf = 0, m_nkill = 0, m_allow = 0, m_base = 0;
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x, ++iter) {
         if ((iter & 63u) == 0u) {
+            // metadata of this workgroup's next 64 tiles in one round of loads (lane i <-> i-th tile), so that the
+            // per-tile critical path holds a single memory latency (the surfel loads themselves)
             const uint64_t tl = (uint64_t)tile + (uint64_t)lane * gridDim.x;
-            skipmask = __ballot(tl < ntiles && (tile_flags[tl < ntiles ? tl : 0] & 2u));
+            const bool in = tl < ntiles;
+            const uint32_t tt = in ? (uint32_t)tl : 0u;
+            skipmask = __ballot(in && (tile_flags[tt] & 2u));
+            m_nconf = tile_cnt[tt * 3]; m_nkill = tile_cnt[tt * 3 + 1]; m_allow = tile_allow[tt];
+            m_base = tile_keep_prefix[tt] + group_keep_base[tt / GROUP];
         }
-        const uint32_t allow = tile_allow[tile], nconf = tile_cnt[tile * 3];
+        const int sl = (int)(iter & 63u);
+        const uint32_t allow = (uint32_t)__shfl((int)m_allow, sl), nconf = (uint32_t)__shfl((int)m_nconf, sl);
+        const uint32_t nkill_full = (uint32_t)__shfl((int)m_nkill, sl), base_id = (uint32_t)__shfl((int)m_base, sl);
         // fast path (workgroup-uniform): nothing of this tile conflicts, dies or moves -- the bulk of the map
         // once the camera has passed.  No masks, no LDS, no barriers: read pos+time, splat.
-        if (nconf == 0 && tile_cnt[tile * 3 + 1] == 0 &&
-            tile_keep_prefix[tile] + group_keep_base[tile / GROUP] == tile * (uint32_t)TILE) {
+        if (nconf == 0 && nkill_full == 0 && base_id == tile * (uint32_t)TILE) {
             // ... and if its box cannot reach the index map (index_map.vert:45-55: 0 < z < far inside the image,
             // updated within timeDelta frames) it is not even read
             if (SPLAT && ((skipmask >> (iter & 63u)) & 1ull)) {
@@ -603,6 +634,23 @@ __global__ __launch_bounds__(256) void k_compact(Model M, DevState *__restrict__
                 }
             }
             continue;
+        }
+        // conservative: a tile classified "moving" that turns out static is handled correctly (it rewrites itself)
+        const bool moving = (base_id != tile * (uint32_t)TILE) || (nkill_full != 0u);   // workgroup-uniform
+        // ---- issue every surfel load of the tile first (unconditional, clamped: a per-lane branch would serialise
+        // them behind s_waitcnt); the mask bookkeeping below overlaps their latency
+        float4 v[4], nr[4];
+        uint32_t col[4], nid[4];
+        float it[4], tl[4];
+        bool kept[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const uint32_t k = (tile * TILE_WORDS + r * 4 + wave) * 64u + lane;
+            const uint32_t kc = min(k, N - 1u);
+            v[r] = set.pos_conf[kc];
+            tl[r] = set.time[kc];
+            nr[r] = make_float4(0.f, 0.f, 0.f, 0.f); col[r] = 0; it[r] = 0.f;
+            if (moving) { nr[r] = set.norm_rad[kc]; col[r] = set.color[kc]; it[r] = set.init_time[kc]; }
         }
         uint64_t c = 0, d = 0, z = 0, valid = 0;
         if (threadIdx.x < TILE_WORDS) {
@@ -634,33 +682,13 @@ __global__ __launch_bounds__(256) void k_compact(Model M, DevState *__restrict__
             s_kpre[threadIdx.x] = before;                 // s_kpre[TILE_WORDS] = survivors of the tile
         }
         __syncthreads();
-        const uint32_t base_id = tile_keep_prefix[tile] + group_keep_base[tile / GROUP];
         const uint32_t kcount = s_kpre[TILE_WORDS];
-        const uint32_t nvalid = min((uint32_t)TILE, N - tile * TILE);
-        const bool moving = (base_id != tile * TILE) || (kcount != nvalid);   // block-uniform
-
-        // ---- load phase: every survivor of the tile into registers
-        float4 v[4], nr[4];
-        uint32_t col[4], nid[4];
-        float it[4], tl[4];
-        bool kept[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int w = r * 4 + wave;
             const uint64_t keepw = s_keep[w];
-            const uint32_t k = (tile * TILE_WORDS + w) * 64u + lane;
             kept[r] = (keepw >> lane) & 1ull;
             nid[r] = base_id + s_kpre[w] + (uint32_t)__popcll(keepw & ((1ull << lane) - 1ull));
-            // unconditional, clamped loads: a per-lane branch would serialise them behind s_waitcnt
-            const uint32_t kc = min(k, N - 1u);
-            v[r] = set.pos_conf[kc];
-            tl[r] = set.time[kc];
-            nr[r] = make_float4(0.f, 0.f, 0.f, 0.f); col[r] = 0; it[r] = 0.f;
-            if (moving) { nr[r] = set.norm_rad[kc]; col[r] = set.color[kc]; it[r] = set.init_time[kc]; }
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int w = r * 4 + wave;
             if (kept[r] && ((s_ceff[w] >> lane) & 1ull)) {
                 v[r].w -= 1.0f;                           // conflict.vert:72
                 if (!moving) set.pos_conf[(tile * TILE_WORDS + w) * 64u + lane].w = v[r].w;
