@@ -284,33 +284,12 @@ int take_error(sm_ctx *s)
 
 // ---- launches ----
 
-uint32_t flag_tiles(const sm_ctx *s)
-{
-    return (uint32_t)std::min<uint64_t>(((uint64_t)s->count_bound + TILE - 1) / TILE, s->tb_tiles);
-}
-
-// skip flags when no k_prep precedes the cull (per-pass entry points)
-int launch_tile_flags(sm_ctx *s, FrameParams fp)
-{
-    fp.n_flag_tiles = flag_tiles(s);
-    if (fp.n_flag_tiles == 0) return SM_OK;
-    hipLaunchKernelGGL(k_tile_flags, dim3((fp.n_flag_tiles + 255) / 256), dim3(256), 0, s->stream, fp, s->d_tb, s->d_tile_flags);
-    HIPCK(hipGetLastError());
-    return SM_OK;
-}
-
 int launch_prep(sm_ctx *s, const uint8_t *rgb, const uint16_t *raw, const uint8_t *sem, const float *dm,
-                FrameParams fp, bool clear_keys, bool with_flags = true)
+                const FrameParams &fp, bool clear_keys)
 {
     const int tiles = ((s->W + 31) / 32) * ((s->H + 31) / 32);
-    fp.n_flag_tiles = with_flags ? flag_tiles(s) : 0;
-    if (fp.n_flag_tiles > (uint32_t)tiles * 1024u) {           // more tiles than k_prep has threads (> 470 M surfels at KITTI size)
-        int rc = launch_tile_flags(s, fp);
-        if (rc) return rc;
-        fp.n_flag_tiles = 0;
-    }
     hipLaunchKernelGGL(k_prep, dim3(tiles), dim3(1024), 0, s->stream, rgb, raw, sem, dm, s->d_depthT, s->d_rgbsT,
-                       clear_keys ? s->d_keyT : nullptr, fp, s->d_tb, fp.n_flag_tiles ? s->d_tile_flags : (uint8_t *)nullptr);
+                       clear_keys ? s->d_keyT : nullptr, fp);
     HIPCK(hipGetLastError());
     return SM_OK;
 }
@@ -325,7 +304,7 @@ int launch_conflict(sm_ctx *s, const FrameParams &fp, bool timed = false)
 {
     s->n_conf_part = (uint32_t)grid_surfels(s);
     hipLaunchKernelGGL(k_conflict, dim3(s->n_conf_part), dim3(256), 0, s->stream, s->M, s->d_state, fp, s->d_depthT,
-                       s->d_rgbsT, s->d_cm, s->d_dm, s->d_zm, s->d_tile_cnt, s->d_tile_flags, s->d_conf_part);
+                       s->d_rgbsT, s->d_cm, s->d_dm, s->d_zm, s->d_tile_cnt, s->d_tb, s->d_tile_flags, s->d_conf_part);
     HIPCK(hipGetLastError());
     if (mark(s, 2, timed)) return SM_E_HIP;
     const int ngroups = std::max<int>(1, (int)((((uint64_t)s->count_bound + TILE - 1) / TILE + GROUP - 1) / GROUP));
@@ -786,11 +765,10 @@ int sm_clean_points(sm_ctx *s, const uint16_t *depth_mm, const uint8_t *semantic
     if (rc) return rc;
     memcpy(s->curr_pose, pose16, 64);
     FrameParams fp = make_params(s, pose16);
-    if ((rc = launch_prep(s, s->d_rgb, s->d_depth_raw, s->d_sem, nullptr, fp, false, false))) return rc;   // metriciseDepth only
+    if ((rc = launch_prep(s, s->d_rgb, s->d_depth_raw, s->d_sem, nullptr, fp, false))) return rc;   // metriciseDepth only
     fp.max_depth = s->cfg.far_clip - 15.0f;     // src/SurfelMapping.cpp:515
     fp.conflict_thresh = 0.1f;                  // :516
     fp.is_clean = 1;                            // :517
-    if ((rc = launch_tile_flags(s, fp))) return rc;
     if ((rc = launch_conflict(s, fp))) return rc;
     if ((rc = launch_compact(s, fp, false, false))) return rc;
     return sm_sync(s);
@@ -956,7 +934,7 @@ int sm_set_frame(sm_ctx *s, const uint8_t *rgb, const float *depth_metric, const
     const int tiles = ((s->W + 31) / 32) * ((s->H + 31) / 32);
     hipLaunchKernelGGL(k_prep, dim3(tiles), dim3(1024), 0, s->stream, s->d_rgb, (const uint16_t *)nullptr, s->d_sem,
                        depth_metric ? s->d_depth_f32 : nullptr, depth_metric ? s->d_depthT : nullptr, s->d_rgbsT,
-                       (uint64_t *)nullptr, fp, s->d_tb, (uint8_t *)nullptr);
+                       (uint64_t *)nullptr, fp);
     HIPCK(hipGetLastError());
     HIPCK(hipStreamSynchronize(s->stream));
     return SM_OK;
@@ -991,7 +969,6 @@ int sm_stage_conflict(sm_ctx *s, const float *pose16, float min_depth, float max
     fp.min_depth = min_depth; fp.max_depth = max_depth; fp.conflict_thresh = fuse_thresh; fp.is_clean = is_clean;
     s->count_before_cull = s->h_state->count;
     s->offset_before_cull = s->h_state->offset;
-    if ((rc = launch_tile_flags(s, fp))) return rc;
     if ((rc = launch_conflict(s, fp))) return rc;
     s->pending_cull = true;
     return sm_sync(s);

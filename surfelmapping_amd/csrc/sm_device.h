@@ -86,7 +86,6 @@ struct FrameParams {
     int init_mode;            // 1: every checkerboard pixel with 0 < z < far becomes a surfel, no association
     float inv_fx_fb, inv_fy_fb;   // 1.0f/fx as float division (src/FeedbackBuffer.cpp:93-96)
     int use_bounds;           // 1: whole 1024-surfel tiles are skipped when their bounding box is outside the view
-    uint32_t n_flag_tiles;    // tiles whose skip flags k_prep computes (host upper bound of the tile count)
 };
 
 // local index -> global id through the per-segment tables (segments = surfels created by one frame,

@@ -14,10 +14,10 @@ namespace sm {
 // ---------------------------------------------------------------------------------------------
 // Per-tile skip flags of the frame (bit 0: outside the conflict view volume, conflict.vert:35; bit 1:
 // cannot reach the index map, index_map.vert:45-55 incl. the timeDelta gate), from the tile bounds as they
-// stand at frame start.  One thread per tile; folded into k_prep so that it costs no launch.
+// stand at frame start.  Evaluated inside k_conflict, 64 tiles at a time (one per lane), which keeps bit 0 in a ballot
+// mask and stores bit 1 for the splat in k_compact: no extra launch, no extra pass.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void tile_flags_one(uint32_t t, const FrameParams &fp, const uint32_t *__restrict__ tb,
-                                               uint8_t *__restrict__ tile_flags)
+__device__ __forceinline__ uint32_t tile_flags_one(uint32_t t, const FrameParams &fp, const uint32_t *__restrict__ tb)
 {
     uint32_t f = 0;
     const uint32_t *b = tb + (size_t)t * 8;
@@ -52,13 +52,7 @@ __device__ __forceinline__ void tile_flags_one(uint32_t t, const FrameParams &fp
             }
         }
     }
-    tile_flags[t] = (uint8_t)f;
-}
-
-__global__ void k_tile_flags(FrameParams fp, const uint32_t *__restrict__ tb, uint8_t *__restrict__ tile_flags)
-{
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < fp.n_flag_tiles) tile_flags_one(t, fp, tb, tile_flags);
+    return f;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -70,15 +64,9 @@ __global__ __launch_bounds__(1024) void k_prep(const uint8_t *__restrict__ rgb,
                                                const uint8_t *__restrict__ sem,
                                                const float *__restrict__ depth_f32,  // optional: metric depth given directly
                                                float *__restrict__ depthT, uint32_t *__restrict__ rgbsT,
-                                               uint64_t *__restrict__ keyT, FrameParams fp,
-                                               const uint32_t *__restrict__ tb, uint8_t *__restrict__ tile_flags)
+                                               uint64_t *__restrict__ keyT, FrameParams fp)
 {
     __shared__ float s_d[32][33];
-    if (tile_flags && (threadIdx.x & 63) == 0) {       // lane 0 of every wave of the launch takes tiles in turn
-        const uint32_t nwaves = gridDim.x * 16u;
-        for (uint32_t t = blockIdx.x * 16u + (threadIdx.x >> 6); t < fp.n_flag_tiles; t += nwaves)
-            tile_flags_one(t, fp, tb, tile_flags);
-    }
     __shared__ uint32_t s_c[32][33];
     const int W = fp.W, H = fp.H;
     const int tiles_x = (W + 31) >> 5;
@@ -273,7 +261,8 @@ __global__ __launch_bounds__(256) void k_conflict(Model M, const DevState *__res
                                                   const uint32_t *__restrict__ rgbsT,
                                                   uint64_t *__restrict__ cm, uint64_t *__restrict__ dm,
                                                   uint64_t *__restrict__ zm, uint32_t *__restrict__ tile_cnt,
-                                                  const uint8_t *__restrict__ tile_flags, uint32_t *__restrict__ blk_part /* [grid] skipped */)
+                                                  const uint32_t *__restrict__ tb, uint8_t *__restrict__ tile_flags,
+                                                  uint32_t *__restrict__ blk_part /* [grid] skipped */)
 {
     __shared__ uint32_t s_red[4][3];
     __shared__ uint64_t s_m[3][TILE_WORDS];
@@ -287,9 +276,15 @@ __global__ __launch_bounds__(256) void k_conflict(Model M, const DevState *__res
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x, ++iter) {
         uint32_t nconf = 0, nkill = 0, nzero = 0;
         if ((iter & 63u) == 0u) {
-            // the skip flags of this workgroup's next 64 tiles in one load (lane i <-> i-th tile)
+            // the skip flags of this workgroup's next 64 tiles, one tile per lane: bit 0 stays in the ballot mask,
+            // bit 1 (splat) is stored for k_compact
             const uint64_t tl = (uint64_t)tile + (uint64_t)lane * gridDim.x;
-            skipmask = __ballot(tl < ntiles && (tile_flags[tl < ntiles ? tl : 0] & 1u));
+            uint32_t f = 0;
+            if (tl < ntiles) {
+                f = tile_flags_one((uint32_t)tl, fp, tb);
+                if (wave == 0) tile_flags[tl] = (uint8_t)f;
+            }
+            skipmask = __ballot((f & 1u) != 0u);
         }
         // whole tile outside the conflict view volume (conflict.vert:35)?  Then nothing conflicts, and a tile
         // without "bad" surfels has nothing dead either: zero masks, zero counts, no surfel read.
