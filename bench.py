@@ -328,6 +328,7 @@ def main():
         "cpu_baseline": cpu,
         "kernels": kern,
         "frame_ms_gpu_events": tim["run"],
+        "event_overhead_ms": tim.get("event_overhead", 0.0),
         "gen_seconds": t_gen,
     }
     print(json.dumps(out))

@@ -77,6 +77,7 @@ typedef struct sm_timings {
     /* per kernel */
     float k_prep, k_conflict, k_scan_cull, k_compact, k_associate, k_scan_new, k_append;
     uint32_t frames;          /* frames averaged */
+    float event_overhead;     /* measured cost of one event record, already subtracted from the k_* fields */
 } sm_timings;
 
 /* Per-frame counters written by the device at the end of every fusing frame (ring of

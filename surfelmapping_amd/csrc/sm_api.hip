@@ -38,7 +38,7 @@ void set_err(const char *what, hipError_t e, const char *file, int line)
     } while (0)
 
 constexpr int EV_RING = 256;
-constexpr int N_EV = 8;           // start, prep, conflict, scan_cull, compact, associate, scan_new, append
+constexpr int N_EV = 9;           // start, prep, conflict, scan_cull, compact, associate, scan_new, append, + calibration
 constexpr int MAX_GRID = 2048;   // 256 CUs x 8 workgroups
 constexpr int COMPACT_GRID = 1024;  // k_compact: 256 CUs x 4 workgroups, must be fully co-resident (in-place hand-off)
 
@@ -415,6 +415,7 @@ int begin_frame(sm_ctx *s, const uint8_t *d_rgb, const uint16_t *d_raw, const ui
     FrameParams fp = make_params(s, pose);
     const bool fusing = s->ref_set && s->tick != 0;
     int rc;
+    if ((rc = mark(s, 8, fusing))) return rc;    // back-to-back pair 8 -> 0: the cost of an event record itself
     if ((rc = mark(s, 0, fusing))) return rc;
     // metriciseDepth (+ filterDepth when preprocess=1)   src/SurfelMapping.cpp:136-139
     if ((rc = launch_prep(s, d_rgb, d_raw, d_sem, nullptr, fp, true))) return rc;
@@ -1028,27 +1029,35 @@ int sm_stage_timings(sm_ctx *s, sm_timings *out)
     HIPCK(hipStreamSynchronize(s->stream));
     uint64_t first = s->ev_read;
     if (s->ev_frames - first > EV_RING) first = s->ev_frames - EV_RING;
-    double seg[N_EV - 1] = {0}, run = 0;
+    double seg[7] = {0}, run = 0, ovh = 0;
     uint32_t nfr = 0;
     for (uint64_t f = first; f < s->ev_frames; ++f) {
         const int slot = (int)(f % EV_RING);
         float ms = 0;
         bool ok = true;
-        double loc[N_EV - 1];
-        for (int k = 0; k < N_EV - 1 && ok; ++k) {
+        double loc[7];
+        for (int k = 0; k < 7 && ok; ++k) {
             ok = hipEventElapsedTime(&ms, s->ev[k][slot], s->ev[k + 1][slot]) == hipSuccess;
             loc[k] = ms;
         }
-        ok = ok && hipEventElapsedTime(&ms, s->ev[0][slot], s->ev[N_EV - 1][slot]) == hipSuccess;
+        ok = ok && hipEventElapsedTime(&ms, s->ev[0][slot], s->ev[7][slot]) == hipSuccess;
+        float o = 0;
+        ok = ok && hipEventElapsedTime(&o, s->ev[8][slot], s->ev[0][slot]) == hipSuccess;
         if (!ok) continue;
-        for (int k = 0; k < N_EV - 1; ++k) seg[k] += loc[k];
+        for (int k = 0; k < 7; ++k) seg[k] += loc[k];
         run += ms;
+        ovh += o;
         nfr++;
     }
     s->ev_read = s->ev_frames;
     out->frames = nfr;
     if (nfr) {
         const double inv = 1.0 / nfr;
+        // every segment contains one event record; subtract its measured cost (the back-to-back pair) so that the
+        // per-kernel figures are launch durations, comparable with rocprofv3's
+        const double oh = ovh * inv;
+        out->event_overhead = (float)oh;
+        for (double &x : seg) x = std::max(0.0, x - oh * nfr);
         out->k_prep = (float)(seg[0] * inv); out->k_conflict = (float)(seg[1] * inv); out->k_scan_cull = (float)(seg[2] * inv);
         out->k_compact = (float)(seg[3] * inv); out->k_associate = (float)(seg[4] * inv); out->k_scan_new = (float)(seg[5] * inv);
         out->k_append = (float)(seg[6] * inv);
