@@ -146,6 +146,12 @@ int sm_download_index_map(sm_ctx *s, int32_t *id, float *vert_conf4, float *colo
 /* SurfelMapping::getTexture(DEPTH_METRIC / DEPTH_FILTERED / "LAST") read-back, row-major */
 int sm_download_depth(sm_ctx *s, int which, float *dst);
 
+/* GlobalModel::setImageSize + renderImage + the two texture downloads of SurfelMapping::acquireImages
+ * (src/GlobalModel.cpp:772-833, src/SurfelMapping.cpp:378-434): novel view of the model from camera->world
+ * pose `view16`; bgr_out h*w*3 u8 (B,G,R as FragColor = srgb.wzy), sem_out h*w u8 = class + 1, 0 = empty. */
+int sm_render_image(sm_ctx *s, const float *view16, int w, int h, float fx, float fy, float cx, float cy,
+                    uint8_t *bgr_out, uint8_t *sem_out);
+
 /* ---- per-pass entry points (GlobalModel / IndexMap methods), synchronous ---- */
 /* Upload RGB / metric depth / semantic textures directly (bypasses p0). */
 int sm_set_frame(sm_ctx *s, const uint8_t *rgb, const float *depth_metric,

@@ -1131,3 +1131,125 @@ int smo_filter_data(smo_ctx *s, const uint8_t *keep)
     s->fused_count = nf;
     return SMO_OK;
 }
+
+/* ------------------------------------------------------------------ novel-view renderer */
+
+typedef struct { int64_t X, Y; float zw, tx, ty; } rv_t;
+
+static inline int64_t edge64(const rv_t *a, const rv_t *b, int64_t px, int64_t py)
+{
+    return (b->X - a->X) * (py - a->Y) - (b->Y - a->Y) * (px - a->X);
+}
+
+static inline int top_left(const rv_t *a, const rv_t *b)
+{
+    int64_t dx = b->X - a->X, dy = b->Y - a->Y;
+    return (dy == 0 && dx > 0) || (dy < 0);
+}
+
+static void raster_tri(const rv_t *v0, const rv_t *v1, const rv_t *v2, int w, int h, uint32_t id, uint64_t *key)
+{
+    int64_t area = edge64(v0, v1, v2->X, v2->Y);
+    if (area == 0) return;
+    if (area < 0) { const rv_t *t = v1; v1 = v2; v2 = t; area = -area; }
+    int64_t minX = v0->X, maxX = v0->X, minY = v0->Y, maxY = v0->Y;
+    const rv_t *vs[2] = {v1, v2};
+    for (int q = 0; q < 2; ++q) {
+        if (vs[q]->X < minX) minX = vs[q]->X;
+        if (vs[q]->X > maxX) maxX = vs[q]->X;
+        if (vs[q]->Y < minY) minY = vs[q]->Y;
+        if (vs[q]->Y > maxY) maxY = vs[q]->Y;
+    }
+    int64_t x0 = (minX - 128) >> 8, x1 = (maxX - 128) >> 8, y0 = (minY - 128) >> 8, y1 = (maxY - 128) >> 8;
+    if (x0 < 0) x0 = 0;
+    if (y0 < 0) y0 = 0;
+    if (x1 > w - 1) x1 = w - 1;
+    if (y1 > h - 1) y1 = h - 1;
+    const int b0 = top_left(v1, v2) ? 0 : -1, b1 = top_left(v2, v0) ? 0 : -1, b2 = top_left(v0, v1) ? 0 : -1;
+    for (int64_t py = y0; py <= y1; ++py)
+        for (int64_t px = x0; px <= x1; ++px) {
+            const int64_t cx = px * 256 + 128, cy = py * 256 + 128;
+            const int64_t e0 = edge64(v1, v2, cx, cy), e1 = edge64(v2, v0, cx, cy), e2 = edge64(v0, v1, cx, cy);
+            if (e0 + b0 < 0 || e1 + b1 < 0 || e2 + b2 < 0) continue;
+            const float l0 = (float)((double)e0 / (double)area), l1 = (float)((double)e1 / (double)area),
+                        l2 = (float)((double)e2 / (double)area);
+            const float tx = (l0 * v0->tx + l1 * v1->tx) + l2 * v2->tx;
+            const float ty = (l0 * v0->ty + l1 * v1->ty) + l2 * v2->ty;
+            if (tx * tx + ty * ty > 1.0f) continue;                         /* draw_image.frag:13-14 */
+            const float zw = (l0 * v0->zw + l1 * v1->zw) + l2 * v2->zw;
+            if (!(zw >= 0.0f && zw <= 1.0f)) continue;                      /* depth clip */
+            const uint32_t d24 = (uint32_t)floor((double)zw * 16777215.0 + 0.5);
+            if (d24 >= 16777215u) continue;                                 /* GL_LESS against the clear value */
+            const uint64_t kk = ((uint64_t)d24 << 32) | id;
+            uint64_t *dst = key + (size_t)py * w + px;
+            if (kk < *dst) *dst = kk;
+        }
+}
+
+int smo_render_image(const smo_ctx *s, const float *view, int w, int h, float fx, float fy, float cx, float cy,
+                     uint8_t *bgr, uint8_t *sem)
+{
+    if (!s || !view || w <= 0 || h <= 0 || !bgr || !sem) return SMO_E_ARG;
+    const float maxDepth = 200.0f;                                          /* src/GlobalModel.cpp:797 */
+    const float cols = (float)w, rows = (float)h;
+    float t_inv[16];
+    smo_invert4(view, t_inv);
+    uint64_t *key = malloc((size_t)w * h * 8);
+    if (!key) return SMO_E_ARG;
+    for (size_t p = 0; p < (size_t)w * h; ++p) key[p] = 0x7FFFFFFFFFFFFFFFull;
+    for (uint32_t k = 0; k < s->count; ++k) {
+        const float *v = s->model + (size_t)k * SURFEL_F;
+        float ph[4], n[3];
+        xform(t_inv, v[0], v[1], v[2], ph);                                /* draw_image.vert:20-27 */
+        rot3(t_inv, v[8], v[9], v[10], n);
+        normalize3(n);
+        const float r = v[11];
+        if (ph[2] >= maxDepth || ph[2] <= 1.0f) continue;                   /* draw_image_adaptive.geom:41 */
+        float x[3], y[3];
+        if (ph[2] > 5.0f) {                                                 /* :47-52 */
+            const float tn[3] = {0.0f, 0.0f, 1.0f};
+            float a[3] = {tn[1] - tn[2], -tn[0], tn[0]};
+            normalize3(a);
+            for (int q = 0; q < 3; ++q) x[q] = a[q] * r * 1.41421356f;
+            cross3(tn, x, y);
+        } else {                                                            /* :53-63 */
+            const float cosAngle = dot3(ph, n) / (sqrtf(dot3(ph, ph)) * sqrtf(dot3(n, n)));
+            const float radius = r / (1.0f + 0.5f * fabsf(cosAngle));
+            float a[3] = {n[1] - n[2], -n[0], n[0]};
+            normalize3(a);
+            for (int q = 0; q < 3; ++q) x[q] = a[q] * radius * 1.41421356f;
+            cross3(n, x, y);
+        }
+        const float sx[4] = {x[0], y[0], -y[0], -x[0]}, sy[4] = {x[1], y[1], -y[1], -x[1]}, sz[4] = {x[2], y[2], -y[2], -x[2]};
+        const float tcx[4] = {-1.0f, 1.0f, -1.0f, 1.0f}, tcy[4] = {-1.0f, -1.0f, 1.0f, 1.0f};
+        rv_t rv[4];
+        int ok = 1;
+        for (int q = 0; q < 4 && ok; ++q) {
+            const float X = ph[0] + sx[q], Y = ph[1] + sy[q], Z = ph[2] + sz[q];
+            if (!(Z > 0.0f)) { ok = 0; break; }                             /* would need polygon clipping: not drawn */
+            const float xn = ((((fx * X) / Z) + cx) - (cols * 0.5f)) / (cols * 0.5f);   /* projectPoint :31-36 */
+            const float yn = ((((fy * Y) / Z) + cy) - (rows * 0.5f)) / (rows * 0.5f);
+            const float zn = (2.0f * Z / maxDepth) - 1.0f;
+            const float xw = (cols * 0.5f) * xn + (cols * 0.5f), yw = (rows * 0.5f) * yn + (rows * 0.5f);
+            if (!(fabsf(xw) < 1.0e6f && fabsf(yw) < 1.0e6f)) { ok = 0; break; }
+            rv[q].X = (int64_t)floor((double)xw * 256.0 + 0.5);
+            rv[q].Y = (int64_t)floor((double)yw * 256.0 + 0.5);
+            rv[q].zw = 0.5f * zn + 0.5f;
+            rv[q].tx = tcx[q]; rv[q].ty = tcy[q];
+        }
+        if (!ok) continue;
+        raster_tri(&rv[0], &rv[1], &rv[2], w, h, k, key);                   /* triangle strip */
+        raster_tri(&rv[2], &rv[1], &rv[3], w, h, k, key);
+    }
+    for (size_t p = 0; p < (size_t)w * h; ++p) {
+        if (key[p] == 0x7FFFFFFFFFFFFFFFull) { bgr[p * 3] = bgr[p * 3 + 1] = bgr[p * 3 + 2] = 0; sem[p] = 0; continue; }
+        const uint32_t id = (uint32_t)(key[p] & 0xFFFFFFFFu);
+        const uint32_t sc = f2u(s->model[(size_t)id * SURFEL_F + 4]);
+        bgr[p * 3 + 0] = (uint8_t)(sc & 0xFFu);                             /* vBGR = srgb.wzy :38 */
+        bgr[p * 3 + 1] = (uint8_t)((sc >> 8) & 0xFFu);
+        bgr[p * 3 + 2] = (uint8_t)((sc >> 16) & 0xFFu);
+        sem[p] = (uint8_t)(((sc >> 24) & 0xFFu) + 1u);                      /* :39 */
+    }
+    free(key);
+    return SMO_OK;
+}

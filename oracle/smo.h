@@ -100,6 +100,13 @@ int smo_stage_concatenate(smo_ctx *s);                               /* p11 */
 /* computeFeedbackBuffers + GlobalModel::initialize, the tick==0 branch after reset() */
 int smo_stage_initialize(smo_ctx *s, const float *pose, int time, float max_depth);
 
+/* GlobalModel::renderImage (src/GlobalModel.cpp:772-833) with draw_image.vert / draw_image_adaptive.geom /
+ * draw_image.frag: every surfel as a screen-space disc (two triangles + per-fragment circle test), z-buffered.
+ * Outputs: bgr u8[h][w][3] (FragColor = srgb.wzy) and semantic u8[h][w] = class + 1 (0 = nothing drawn).
+ * Rasterisation rules fixed by DESIGN.md "Renderer": 24.8 fixed-point vertices, top-left fill rule. */
+int smo_render_image(const smo_ctx *s, const float *view, int w, int h, float fx, float fy, float cx, float cy,
+                     uint8_t *bgr, uint8_t *sem);
+
 /* ---- helpers for the multi-GPU shard tests: one oracle instance plays one rank ---- */
 int smo_set_exempt_id(smo_ctx *s, int32_t id);
 int smo_download_zbuf(const smo_ctx *s, uint32_t *dst);

@@ -21,7 +21,7 @@ SYMBOLS = (
     "sm_api_version", "sm_last_error", "sm_default_config", "sm_create", "sm_destroy",
     "sm_process_frame", "sm_process_frame_device", "sm_sync", "sm_clean_points", "sm_reset",
     "sm_get_counts", "sm_download_model_aos", "sm_upload_model_aos", "sm_save_map", "sm_load_map",
-    "sm_download_index_map", "sm_download_depth", "sm_set_frame", "sm_set_tick",
+    "sm_download_index_map", "sm_download_depth", "sm_render_image", "sm_set_frame", "sm_set_tick",
     "sm_stage_conflict", "sm_stage_cull", "sm_stage_splat", "sm_stage_associate_fuse",
     "sm_stage_timings", "sm_read_frame_log", "sm_device_alloc", "sm_device_free", "sm_device_upload",
     "sm_export_model_device", "sm_append_model_aos_device", "sm_key_map_device_ptr",
@@ -107,6 +107,7 @@ def load():
     L.sm_load_map.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.sm_download_index_map.argtypes = [vp, vp, vp, vp, vp]
     L.sm_download_depth.argtypes = [vp, C.c_int, vp]
+    L.sm_render_image.argtypes = [vp, vp, C.c_int, C.c_int] + [C.c_float] * 4 + [vp, vp]
     L.sm_set_frame.argtypes = [vp, vp, vp, vp]
     L.sm_set_tick.argtypes = [vp, C.c_int32]
     L.sm_stage_conflict.argtypes = [vp, vp, C.c_float, C.c_float, C.c_float, C.c_int]
@@ -247,6 +248,14 @@ class SurfelMap:
         out = np.zeros((self.H, self.W), np.float32)
         self._chk(self._L.sm_download_depth(self._h, which, _ptr(out)), "sm_download_depth")
         return out
+
+    def render_image(self, view, w, h, fx, fy, cx, cy):
+        """Novel view (GlobalModel::renderImage): (bgr uint8[h][w][3], semantic uint8[h][w] = class + 1)."""
+        view = np.ascontiguousarray(view, np.float32)
+        bgr = np.zeros((h, w, 3), np.uint8)
+        sem = np.zeros((h, w), np.uint8)
+        self._chk(self._L.sm_render_image(self._h, _ptr(view), w, h, fx, fy, cx, cy, _ptr(bgr), _ptr(sem)), "sm_render_image")
+        return bgr, sem
 
     # -- per-pass entry points
     def set_frame(self, rgb=None, depth_metric=None, sem=None):

@@ -77,7 +77,28 @@ public:
         return v;
     }
 
-    // GL presentation (src/GlobalModel.cpp:683-833) is out of scope of the compute core
+    // novel views for SPADE (src/GlobalModel.cpp:772-833): rendered by the HIP core, kept on the host
+    void setImageSize(int w, int h, float fx, float fy, float cx, float cy)
+    {
+        iw_ = w; ih_ = h; ifx_ = fx; ify_ = fy; icx_ = cx; icy_ = cy;
+        imageBgr_.assign((size_t)w * h * 3, 0);
+        imageSem_.assign((size_t)w * h, 0);
+        imageTex_.texture->width = semTex_.texture->width = w;
+        imageTex_.texture->height = semTex_.texture->height = h;
+    }
+    void renderImage(const Eigen::Matrix4f &view)
+    {
+        if (sm_render_image(ctx_, view.data(), iw_, ih_, ifx_, ify_, icx_, icy_, imageBgr_.data(), imageSem_.data()) != SM_OK)
+            std::printf("renderImage: %s\n", sm_last_error());
+    }
+    pangolin::GlTexture *getImageTex() { return imageTex_.texture; }
+    pangolin::GlTexture *getSemanticTex() { return semTex_.texture; }
+    const std::vector<unsigned char> &imageBGR() const { return imageBgr_; }      // h*w*3, B,G,R (FragColor = srgb.wzy)
+    const std::vector<unsigned char> &imageSemantic() const { return imageSem_; } // h*w, class + 1, 0 = empty
+    int imageWidth() const { return iw_; }
+    int imageHeight() const { return ih_; }
+
+    // interactive GL presentation (renderModel, src/GlobalModel.cpp:683-758) is out of scope of the compute core
     pangolin::GlTexture *getModelMapVC() { return mapVC_.texture; }
     pangolin::GlTexture *getModelMapCT() { return mapCT_.texture; }
     pangolin::GlTexture *getModelMapNR() { return mapNR_.texture; }
@@ -86,5 +107,8 @@ private:
     sm_counts counts() { sm_counts c{}; sm_get_counts(ctx_, &c); return c; }
     sm_ctx *ctx_;
     bool pending_ = false;
-    GPUTexture mapVC_, mapCT_, mapNR_;
+    GPUTexture mapVC_, mapCT_, mapNR_, imageTex_, semTex_;
+    int iw_ = 0, ih_ = 0;
+    float ifx_ = 0, ify_ = 0, icx_ = 0, icy_ = 0;
+    std::vector<unsigned char> imageBgr_, imageSem_;
 };

@@ -13,6 +13,8 @@
 #include "GlobalModel.h"
 #include "IndexMap.h"
 #include "sm_compat.h"
+#include "sm_png.h"
+#include <sys/stat.h>
 
 class Checker;          // debug aid of the reference (src/Utils/Checker.h); never constructed here
 class FeedbackBuffer;   // raw per-frame cloud (GUI "Draw raw"); not produced by the compute core
@@ -86,10 +88,28 @@ public:
     }
     FeedbackBuffer *getFeedbackBuffer(const std::string &) { return nullptr; }
 
-    // novel-view dump for SPADE (src/SurfelMapping.cpp:378-434): SURVEY 8f rank 3, not built
-    void acquireImages(std::string, const std::vector<Eigen::Matrix4f> &, int, int, float, float, float, float, int = 0)
+    // novel-view dump for SPADE (src/SurfelMapping.cpp:378-434): <path>/image/%06d.png (the bytes of the
+    // reference's BGR cv::Mat, i.e. a correct-colour picture) and <path>/semantic/%06d.png (class + 1)
+    void acquireImages(std::string path, const std::vector<Eigen::Matrix4f> &views, int w, int h, float fx, float fy, float cx,
+                       float cy, int startId = 0)
     {
-        std::printf("acquireImages: novel-view renderer is not part of the compute core yet\n");
+        if (path.empty() || path.back() != '/') path += "/";
+        const std::string image_path = path + "image/", semantic_path = path + "semantic/";
+        ::mkdir(image_path.c_str(), 0755);
+        ::mkdir(semantic_path.c_str(), 0755);
+        globalModel.setImageSize(w, h, fx, fy, cx, cy);
+        std::vector<unsigned char> rgb((size_t)w * h * 3);
+        for (const auto &v : views) {
+            char name[32];
+            std::snprintf(name, sizeof name, "%06d.png", startId);
+            globalModel.renderImage(v);
+            const std::vector<unsigned char> &bgr = globalModel.imageBGR();
+            for (size_t p = 0; p < (size_t)w * h; ++p) { rgb[p * 3] = bgr[p * 3 + 2]; rgb[p * 3 + 1] = bgr[p * 3 + 1]; rgb[p * 3 + 2] = bgr[p * 3]; }
+            const bool r1 = sm_png::write((image_path + name).c_str(), rgb.data(), w, h, 3);
+            const bool r2 = sm_png::write((semantic_path + name).c_str(), globalModel.imageSemantic().data(), w, h, 1);
+            if (!(r1 && r2)) std::printf("%s is NOT saved!\n", name);
+            startId++;
+        }
     }
 
     // extras of the HIP core

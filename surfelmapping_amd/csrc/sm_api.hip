@@ -921,6 +921,33 @@ int sm_download_depth(sm_ctx *s, int which, float *dst)
     return SM_OK;
 }
 
+int sm_render_image(sm_ctx *s, const float *view16, int w, int h, float fx, float fy, float cx, float cy, uint8_t *bgr_out,
+                    uint8_t *sem_out)
+{
+    if (!s || !view16 || w <= 0 || h <= 0 || (uint64_t)w * h > (1u << 28) || !bgr_out || !sem_out) return SM_E_ARG;
+    HIPCK(hipSetDevice(s->cfg.device));
+    if (s->pending_cull) { g_err = "sm_render_image between sm_stage_conflict and sm_stage_cull"; return SM_E_ARG; }
+    int rc = pull_state(s);
+    if (rc) return rc;
+    const size_t npix = (size_t)w * h;
+    if ((rc = ensure_export(s, npix * 12))) return rc;            // [keys u64 | bgr | sem]
+    uint64_t *d_key = (uint64_t *)s->d_export;
+    uint8_t *d_bgr = (uint8_t *)s->d_export + npix * 8, *d_sem = d_bgr + npix * 3;
+    RenderParams rp;
+    invert4(view16, rp.t_inv);
+    rp.fx = fx; rp.fy = fy; rp.cx = cx; rp.cy = cy; rp.cols = (float)w; rp.rows = (float)h; rp.w = w; rp.h = h;
+    hipLaunchKernelGGL(k_fill_keys, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s->stream, d_key, (int)npix);
+    const uint32_t cnt = s->h_state->count;
+    if (cnt) hipLaunchKernelGGL(k_render_splat, dim3((cnt + 255) / 256), dim3(256), 0, s->stream, s->M, s->d_state, rp, d_key);
+    hipLaunchKernelGGL(k_render_resolve, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s->stream, s->M, s->d_state, d_key,
+                       (int)npix, d_bgr, d_sem);
+    HIPCK(hipGetLastError());
+    HIPCK(hipMemcpyAsync(bgr_out, d_bgr, npix * 3, hipMemcpyDeviceToHost, s->stream));
+    HIPCK(hipMemcpyAsync(sem_out, d_sem, npix, hipMemcpyDeviceToHost, s->stream));
+    HIPCK(hipStreamSynchronize(s->stream));
+    return SM_OK;
+}
+
 // ---- per-pass entry points ----
 
 int sm_set_frame(sm_ctx *s, const uint8_t *rgb, const float *depth_metric, const uint8_t *semantic)

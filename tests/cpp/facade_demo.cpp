@@ -31,5 +31,9 @@ int main(int argc, char **argv)
                     core.getGlobalModel().getConflict().second, core.getGlobalModel().getUnstable().second);
     }
     std::fclose(f);
+    if (argc > 3) {                                                        // load_map.cpp-style novel-view dump
+        std::vector<Eigen::Matrix4f> views = {core.getCurrPose()};
+        core.acquireImages(argv[3], views, W, H, intr[0], intr[1], intr[2], intr[3], 7);
+    }
     return core.getGlobalModel().downloadMap(argv[2], 0, n - 1) ? 0 : 1;  // build_map.cpp:254
 }

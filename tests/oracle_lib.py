@@ -97,6 +97,8 @@ def lib():
         L.smo_acosf.argtypes = [C.c_float]
         L.smo_expf.restype = C.c_float
         L.smo_expf.argtypes = [C.c_float]
+        L.smo_render_image.restype = C.c_int
+        L.smo_render_image.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_float] * 4 + [C.c_void_p] * 2
         L.smo_invert4.argtypes = [fp, fp]
         L.smo_mul4.argtypes = [fp, fp, fp]
         _lib = L
@@ -200,6 +202,13 @@ class Oracle:
         out = np.zeros((n.value, 12), np.float32)
         _chk(lib().smo_download_data(self._h, _ptr(out), n.value, C.byref(n)), "download_data")
         return out
+
+    def render_image(self, view, w, h, fx, fy, cx, cy):
+        view = np.ascontiguousarray(view, np.float32)
+        bgr = np.zeros((h, w, 3), np.uint8)
+        sem = np.zeros((h, w), np.uint8)
+        _chk(lib().smo_render_image(self._h, _ptr(view), w, h, fx, fy, cx, cy, _ptr(bgr), _ptr(sem)), "render_image")
+        return bgr, sem
 
     # -- stage level
     def set_frame(self, rgb=None, depth_metric=None, sem=None):

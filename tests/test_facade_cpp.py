@@ -39,7 +39,9 @@ def test_facade_demo_matches_oracle(tmp_path):
             f.write(rgb.tobytes()); f.write(d.tobytes()); f.write(s.tobytes()); f.write(p.astype(np.float32).tobytes())
     exe = build_demo(tmp_path)
     out = tmp_path / "map.bin"
-    r = subprocess.run([exe, str(frames), str(out)], capture_output=True, text=True)
+    views = tmp_path / "views"
+    views.mkdir()
+    r = subprocess.run([exe, str(frames), str(out), str(views)], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     o = ol.Oracle(ol.make_config(**cam, preprocess=0, max_sqrt_vertices=1000))
     for fr in seq:
@@ -50,5 +52,32 @@ def test_facade_demo_matches_oracle(tmp_path):
     ref = o.download_model()
     assert n == ref.shape[0] > 0
     assert np.array_equal(m.view(np.uint32), ref.view(np.uint32))
+    # acquireImages wrote image/000007.png + semantic/000007.png: decode the stored-deflate PNGs and compare
+    import struct
+    import zlib
+
+    def read_png(path):
+        b = open(path, "rb").read()
+        assert b[:8] == b"\x89PNG\r\n\x1a\n"
+        pos, idat, hdr = 8, b"", None
+        while pos < len(b):
+            n, typ = struct.unpack(">I4s", b[pos:pos + 8])
+            body = b[pos + 8:pos + 8 + n]
+            assert zlib.crc32(typ + body) == struct.unpack(">I", b[pos + 8 + n:pos + 12 + n])[0]
+            if typ == b"IHDR":
+                hdr = struct.unpack(">IIBBBBB", body)
+            if typ == b"IDAT":
+                idat += body
+            pos += 12 + n
+        w, h, depth, ctype = hdr[:4]
+        ch = 3 if ctype == 2 else 1
+        raw = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(h, w * ch + 1)
+        assert depth == 8 and np.all(raw[:, 0] == 0)
+        return raw[:, 1:].reshape(h, w, ch)
+
+    bgr, sem = o.render_image(seq[-1][3], cam["width"], cam["height"], cam["fx"], cam["fy"], cam["cx"], cam["cy"])
+    img = read_png(str(views / "image" / "000007.png"))
+    lab = read_png(str(views / "semantic" / "000007.png"))
+    assert np.array_equal(img, bgr[..., ::-1]) and np.array_equal(lab[..., 0], sem) and (sem > 0).mean() > 0.3
     c = o.counts()
     assert f"frame 4: model {c['count']} offset {c['offset']} data {c['data_count']} conflict {c['conflict_count']}" in r.stdout
