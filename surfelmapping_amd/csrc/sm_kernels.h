@@ -273,8 +273,6 @@ __global__ __launch_bounds__(256) void k_conflict(Model M, const DevState *__res
     uint32_t skipped = 0;
     uint64_t skipmask = 0;
     uint32_t iter = 0;
-    float4 vnext[4];
-    bool have_next = false;                     // workgroup-uniform
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x, ++iter) {
         uint32_t nconf = 0, nkill = 0, nzero = 0;
         if ((iter & 63u) == 0u) {
@@ -298,27 +296,16 @@ __global__ __launch_bounds__(256) void k_conflict(Model M, const DevState *__res
                 if ((uint64_t)word * 64u < N) { uint64_t *dst = m == 0 ? cm : (m == 1 ? dm : zm); dst[word] = 0ull; }
             }
             skipped += min((uint32_t)TILE, N - tile * TILE);
-            have_next = false;                  // a prefetch issued before this tile's flag was known is dropped
             continue;
         }
-        // phase 1: all four 16-byte loads of the lane in flight together (unconditional, clamped: a per-lane branch
-        // would serialise them) -- normally already issued by the previous iteration (software prefetch)
+        // phase 1: all four 16-byte loads of the lane in flight together
         float4 v[4];
         bool valid[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const uint32_t k = (tile * TILE_WORDS + r * 4 + wave) * 64u + lane;
             valid[r] = k < N;
-            v[r] = have_next ? vnext[r] : pc[min(k, N - 1u)];
-        }
-        {   // prefetch the next tile of this workgroup unless it is known to be skipped
-            const uint32_t nt = tile + gridDim.x;
-            const uint32_t ni = iter + 1u;
-            have_next = nt < ntiles && ((ni & 63u) == 0u || !((skipmask >> (ni & 63u)) & 1ull));
-            if (have_next) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) vnext[r] = pc[min((nt * TILE_WORDS + r * 4 + wave) * 64u + lane, N - 1u)];
-            }
+            v[r] = pc[min(k, N - 1u)];          // unconditional (clamped): a branch here would serialise the loads
         }
         // phase 2: projection + view test; phase 3: the dependent depth/class gathers, again together
         float zc[4], lam[4], dep[4];
