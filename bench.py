@@ -63,16 +63,17 @@ def kernel_bytes(log):
     """Algorithmic HBM bytes per launch of each kernel from the per-frame counters
     (DESIGN.md "Measurement"; SoA surfel = 44 B, key = 8 B)."""
     P = log["P"]
-    N, Np, V, F, U, Ns, Cs, Ss = (log[k].astype(np.float64) for k in
-                                  ("n_before", "n_after_cull", "visible_count", "fused_count", "unstable_count", "n_static",
-                                   "n_conf_skipped", "n_splat_skipped"))
-    # in-place cull: static tiles are only read for the splat (pos_conf 16 + time 4) unless their bounding box
-    # is out of view (then not at all), the rest is read and rewritten in full (44 + 44); every drawn surfel
-    # costs one 8-byte key atomic
-    compact = 20.0 * np.maximum(Ns - Ss, 0.0) + 88.0 * np.maximum(Np - Ns, 0.0) + 8.0 * V
+    N, Np, V, F, U, Ns, Cs, Ss, Sl = (log[k].astype(np.float64) for k in
+                                      ("n_before", "n_after_cull", "visible_count", "fused_count", "unstable_count", "n_static",
+                                       "n_conf_skipped", "n_splat_skipped", "n_slots"))
+    # Sl = slots the cull scans (live surfels + slots of surfels killed since the last physical compaction).
+    # Slots that stay in place (n_static; on a deferred-compaction frame that is all of them) are only read for the
+    # splat (pos_conf 16 + time 4) unless their tile's bounding box is out of view (then not at all); on a compacting
+    # frame the rest is read in full (44) and its survivors rewritten (44); every drawn surfel costs one 8-byte key atomic
+    compact = 20.0 * np.maximum(Ns - Ss, 0.0) + 44.0 * np.maximum(Sl - Ns, 0.0) + 44.0 * np.maximum(Np - Ns, 0.0) + 8.0 * V
     return {
         "k_prep": np.full_like(N, 6.0 * P + 16.0 * P),          # u8x3+u16+u8 in, f32+u32+u64 out
-        "k_conflict": 16.0 * np.maximum(N - Cs, 0.0),             # tiles skipped by their bounds are not read
+        "k_conflict": 16.0 * np.maximum(Sl - Cs, 0.0),            # tiles skipped by their bounds are not read
         "k_compact": compact,
         "k_associate": 16.0 * P + 84.0 * F,                       # depth+rgbs+key per pixel, gather 44 + scatter 40 per fuse
         "k_append": 8.0 * (P / 64.0) + 44.0 * U,
@@ -135,6 +136,8 @@ def main():
                     help="N>1: 'rig' = one camera stream per GPU + all-gather into one GlobalModel (weak scaling); "
                          "'sharded' = ONE stream split over the GPUs, bit-identical to 1 GPU (strong scaling)")
     ap.add_argument("--force-dist", action="store_true", help="rehearse the multi-GPU code path with WORLD_SIZE=1")
+    ap.add_argument("--compact-pct", type=int, default=12,
+                    help="deferred compaction: culled surfels keep their slots until this %% of the slots is dead (0: compact every frame)")
     ap.add_argument("--sync-every-frame", action="store_true",
                     help="reference semantics: host waits for the counters after every frame")
     args = ap.parse_args()
@@ -173,7 +176,8 @@ def main():
     # hd20m: the conflict cap is off for the stress benchmark (SURVEY.md A13 says to state which)
     mk = lambda timing: capi.SurfelMap(capi.make_config(**cam, preprocess=args.preprocess, device=local_rank,
                                                         enable_timing=timing, conflict_cap=0 if hd else 1,
-                                                        max_sqrt_vertices=10000 if hd else 5000))
+                                                        max_sqrt_vertices=10000 if hd else 5000,
+                                                        compact_garbage_pct=args.compact_pct))
     sm = mk(0)                                    # raises without a GPU: no CPU fallback
     # second context: the same frames again with HIP events between the kernels (the events cost
     # ~25 us per frame, so they stay out of the run that produces `value`)
@@ -327,6 +331,9 @@ def main():
                    "frames": f"{Wm}..{Wm + K - 1}", "multi_gpu": (f"{world}-camera rig, one stream per GPU, RCCL all-gather into a single GlobalModel of "
                                  f"{global_count} surfels after the timed frames ({gather_ms:.1f} ms, not in `value`)") if dist else "single stream",
                    "host_sync": "per frame" if args.sync_every_frame else "none inside the timed region",
+                   "compaction": (f"deferred: dead slots squeezed out once they exceed {args.compact_pct}% "
+                                  f"({int((log['n_static'] < log['n_slots']).sum()) if len(log) else 0} of {K} timed frames compacted)")
+                                 if args.compact_pct else "every frame",
                    "surfels_start": int(log["n_before"][0]) if len(log) else 0, "surfels_end": int(counts["count"])},
         "surfels_fused_per_sec": fused_total / elapsed,
         "roofline": roofline,

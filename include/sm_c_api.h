@@ -50,6 +50,9 @@ typedef struct sm_config {
     int32_t device;                /* HIP device ordinal */
     int32_t enable_timing;         /* 1: record hipEvents per stage (sm_stage_timings) */
     int32_t disable_tile_bounds;   /* 1: never skip tiles by their bounding box (A/B switch; results are identical) */
+    int32_t compact_garbage_pct;   /* 12: culled surfels keep their slots (marked dead) until more than this % of the slots
+                                      are dead, then one in-place compaction squeezes them out; 0: compact at every cull
+                                      like the reference (results are identical either way) */
 } sm_config;
 
 /* GlobalModel counters (src/GlobalModel.cpp:860-888) + tick (src/SurfelMapping.h:100) */
@@ -95,7 +98,7 @@ typedef struct sm_frame_log {
     uint32_t n_static;        /* surfels the in-place cull did not have to move */
     uint32_t n_conf_skipped;  /* surfels in tiles the conflict pass skipped by their bounding box */
     uint32_t n_splat_skipped; /* surfels in static tiles the index-map splat skipped by their bounding box */
-    uint32_t reserved;
+    uint32_t n_slots;         /* model slots scanned by the cull = n_before + slots of surfels killed since the last compaction */
 } sm_frame_log;
 
 enum { SM_TEX_DEPTH_METRIC = 0, SM_TEX_DEPTH_FILTERED = 1, SM_TEX_LAST = 2 };

@@ -38,6 +38,7 @@ class SmConfig(C.Structure):
         ("max_sqrt_vertices", C.c_int32), ("time_delta", C.c_int32),
         ("stereo_border", C.c_float), ("preprocess", C.c_int32), ("conflict_cap", C.c_int32),
         ("device", C.c_int32), ("enable_timing", C.c_int32), ("disable_tile_bounds", C.c_int32),
+        ("compact_garbage_pct", C.c_int32),
     ]
 
 
@@ -65,7 +66,7 @@ class SmTimings(C.Structure):
 FRAME_LOG_LEN = 1024
 FRAME_LOG_DTYPE = np.dtype([(n, np.uint32) for n in (
     "tick", "n_before", "n_after_cull", "n_kill", "conflict_count", "visible_count",
-    "fused_count", "unstable_count", "n_static", "n_conf_skipped", "n_splat_skipped", "reserved")])
+    "fused_count", "unstable_count", "n_static", "n_conf_skipped", "n_splat_skipped", "n_slots")])
 
 
 class SurfelMapError(RuntimeError):

@@ -135,6 +135,10 @@ struct sm_ctx {
     uint64_t *d_cm = nullptr, *d_dm = nullptr, *d_zm = nullptr;
     uint32_t *d_tile_cnt = nullptr, *d_tile_allow = nullptr, *d_tile_keep = nullptr, *d_tile_flag = nullptr;
     uint32_t *d_group_tot = nullptr, *d_group_base = nullptr;
+    uint64_t *d_alive = nullptr;       // 1 bit per slot: 0 = killed since the last physical compaction (free slots are 1)
+    uint32_t *d_tile_dead = nullptr;   // dead slots per tile
+    size_t alive_words = 0, dead_tiles = 0;
+    bool maybe_garbage = false;        // a deferred-compaction cull ran since the last physical compaction
     uint32_t *d_tb = nullptr;          // per-tile bounds (8 words per tile)
     uint8_t *d_tile_flags = nullptr;   // per-tile skip flags of the current frame
     uint32_t *d_conf_part = nullptr;   // per-workgroup partial counters (instead of same-address atomics)
@@ -236,6 +240,8 @@ FrameParams make_params(const sm_ctx *s, const float *pose)
     fp.inv_fx_fb = 1.0f / c.fx;
     fp.inv_fy_fb = 1.0f / c.fy;
     fp.use_bounds = c.disable_tile_bounds ? 0 : 1;
+    fp.compact_pct = 0;                     // per-pass entry points and sharded frames compact at every cull
+    fp.maintenance = 0;
     return fp;
 }
 
@@ -257,8 +263,8 @@ int pull_state(sm_ctx *s)
     HIPCK(hipMemcpyAsync(s->h_state, s->d_state, sizeof(DevState), hipMemcpyDeviceToHost, s->stream));
     HIPCK(hipStreamSynchronize(s->stream));
     const DevState &d = *s->h_state;
-    s->counts.count = s->pending_cull ? s->count_before_cull : d.count;
-    s->counts.offset = d.offset;
+    s->counts.count = s->pending_cull ? s->count_before_cull : d.count - d.garbage;   // dead slots are not surfels
+    s->counts.offset = d.offset - d.garbage;
     s->counts.data_count = d.data_count;
     s->counts.conflict_count = d.conflict_count;
     s->counts.unstable_count = d.unstable_count;
@@ -304,15 +310,21 @@ int launch_conflict(sm_ctx *s, const FrameParams &fp, bool timed = false)
 {
     s->n_conf_part = (uint32_t)grid_surfels(s);
     hipLaunchKernelGGL(k_conflict, dim3(s->n_conf_part), dim3(256), 0, s->stream, s->M, s->d_state, fp, s->d_depthT,
-                       s->d_rgbsT, s->d_cm, s->d_dm, s->d_zm, s->d_tile_cnt, s->d_tb, s->d_tile_flags, s->d_conf_part);
+                       s->d_rgbsT, s->d_cm, s->d_dm, s->d_zm, s->d_tile_cnt, s->d_tb, s->d_tile_flags, s->d_conf_part, s->d_alive);
     HIPCK(hipGetLastError());
     if (mark(s, 2, timed)) return SM_E_HIP;
-    const int ngroups = std::max<int>(1, (int)((((uint64_t)s->count_bound + TILE - 1) / TILE + GROUP - 1) / GROUP));
-    hipLaunchKernelGGL(k_scan_cull, dim3(ngroups), dim3(1024), 0, s->stream, s->d_state, s->d_tile_cnt, s->d_tile_allow,
-                       s->d_tile_keep, s->d_group_tot);
-    HIPCK(hipGetLastError());
+    if (fp.compact_pct == 0u) {
+        // every cull compacts: the survivor prefixes are always needed, scan them with one workgroup per 1024 tiles.
+        // With deferred compaction the finalize kernel gets its totals from k_conflict's partial sums and scans
+        // the tiles itself on the (few) frames that compact.
+        const int ngroups = std::max<int>(1, (int)((((uint64_t)s->count_bound + TILE - 1) / TILE + GROUP - 1) / GROUP));
+        hipLaunchKernelGGL(k_scan_cull, dim3(ngroups), dim3(1024), 0, s->stream, s->d_state, s->d_tile_cnt, s->d_tile_allow,
+                           s->d_tile_keep, s->d_group_tot, s->d_tile_dead);
+        HIPCK(hipGetLastError());
+    }
     hipLaunchKernelGGL(k_cull_finalize, dim3(1), dim3(1024), 0, s->stream, s->d_state, fp, s->d_cm, s->d_dm, s->d_zm,
-                       s->d_tile_cnt, s->d_tile_allow, s->d_tile_keep, s->d_group_tot, s->d_group_base, s->d_conf_part, s->n_conf_part);
+                       s->d_tile_cnt, s->d_tile_allow, s->d_tile_keep, s->d_group_tot, s->d_group_base, s->d_conf_part, s->n_conf_part,
+                       s->d_alive, s->d_tile_dead);
     HIPCK(hipGetLastError());
     if (mark(s, 3, timed)) return SM_E_HIP;
     return SM_OK;
@@ -326,13 +338,58 @@ int launch_compact(sm_ctx *s, const FrameParams &fp, bool splat, bool timed)
     if (splat)
         hipLaunchKernelGGL(k_compact<true>, dim3(grid), dim3(256), 0, s->stream, s->M, s->d_state, fp, s->d_cm,
                            s->d_dm, s->d_zm, s->d_tile_cnt, s->d_tile_allow, s->d_tile_keep, s->d_keyT, s->d_tile_flag, epoch,
-                           s->d_seg_lstart, s->d_seg_gbase, s->d_group_base, s->d_tb, s->d_tile_flags, s->d_compact_part);
+                           s->d_seg_lstart, s->d_seg_gbase, s->d_group_base, s->d_tb, s->d_tile_flags, s->d_compact_part, s->d_alive,
+                           s->d_tile_dead);
     else
         hipLaunchKernelGGL(k_compact<false>, dim3(grid), dim3(256), 0, s->stream, s->M, s->d_state, fp, s->d_cm,
                            s->d_dm, s->d_zm, s->d_tile_cnt, s->d_tile_allow, s->d_tile_keep, s->d_keyT, s->d_tile_flag, epoch,
-                           s->d_seg_lstart, s->d_seg_gbase, s->d_group_base, s->d_tb, s->d_tile_flags, s->d_compact_part);
+                           s->d_seg_lstart, s->d_seg_gbase, s->d_group_base, s->d_tb, s->d_tile_flags, s->d_compact_part, s->d_alive,
+                           s->d_tile_dead);
     HIPCK(hipGetLastError());
     if (mark(s, 4, timed)) return SM_E_HIP;
+    return SM_OK;
+}
+
+// after a cull that is not followed by the append kernel (which does this itself): restore the alive mask
+int launch_post_fill(sm_ctx *s)
+{
+    hipLaunchKernelGGL(k_post_fill, dim3(1024), dim3(256), 0, s->stream, s->d_state, s->d_alive, s->d_tile_dead);
+    HIPCK(hipGetLastError());
+    return SM_OK;
+}
+
+// Physical compaction outside a frame: every entry point that exposes slots as surfel ids (downloads, the per-pass
+// API, rendering, sharding, uploads) first squeezes out the slots that deferred culls left dead.  Nothing is killed:
+// empty conflict masks, then the regular scan + in-place compaction, with the key map's ids translated on the way.
+int ensure_compact(sm_ctx *s)
+{
+    if (!s->maybe_garbage) return SM_OK;
+    if (s->pending_cull) { g_err = "internal: deferred compaction with a pending per-pass cull"; return SM_E_ARG; }
+    FrameParams fp = make_params(s, s->curr_pose);
+    fp.maintenance = 1;
+    fp.conflict_cap = 0xFFFFFFFFu;
+    const uint64_t tiles = ((uint64_t)s->count_bound + TILE - 1) / TILE + 1;
+    const size_t words = std::min<size_t>(tiles * TILE_WORDS, s->alive_words);
+    HIPCK(hipMemsetAsync(s->d_cm, 0, words * 8, s->stream));
+    HIPCK(hipMemsetAsync(s->d_dm, 0, words * 8, s->stream));
+    HIPCK(hipMemsetAsync(s->d_zm, 0, words * 8, s->stream));
+    HIPCK(hipMemsetAsync(s->d_tile_cnt, 0, std::min<size_t>(tiles, s->dead_tiles) * 12, s->stream));
+    const int ngroups = std::max<int>(1, (int)((tiles + GROUP - 1) / GROUP));
+    hipLaunchKernelGGL(k_scan_cull, dim3(ngroups), dim3(1024), 0, s->stream, s->d_state, s->d_tile_cnt, s->d_tile_allow,
+                       s->d_tile_keep, s->d_group_tot, s->d_tile_dead);
+    hipLaunchKernelGGL(k_cull_finalize, dim3(1), dim3(1024), 0, s->stream, s->d_state, fp, s->d_cm, s->d_dm, s->d_zm,
+                       s->d_tile_cnt, s->d_tile_allow, s->d_tile_keep, s->d_group_tot, s->d_group_base, s->d_conf_part, 0u,
+                       s->d_alive, s->d_tile_dead);
+    hipLaunchKernelGGL(k_remap_keys, dim3((s->P + 255) / 256), dim3(256), 0, s->stream, s->d_state, s->d_keyT, s->P, s->d_alive,
+                       s->d_tile_keep, s->d_group_base);
+    HIPCK(hipGetLastError());
+    const uint32_t keep_part = s->n_compact_part;
+    int rc = launch_compact(s, fp, false, false);
+    s->n_compact_part = keep_part;
+    if (rc) return rc;
+    if ((rc = launch_post_fill(s))) return rc;
+    s->maybe_garbage = false;
+    HIPCK(hipStreamSynchronize(s->stream));
     return SM_OK;
 }
 
@@ -368,7 +425,7 @@ int launch_associate_fused(sm_ctx *s, const FrameParams &fp, bool timed)
     const int grid = std::min(s->n_pix_blocks, s->assoc_grid);
     hipLaunchKernelGGL(k_associate_append, dim3(grid), dim3(PIX_BLOCK), 0, s->stream, s->M, s->d_state, fp, s->d_depthT,
                        s->d_rgbsT, s->d_keyT, s->d_xs, s->d_ys, s->d_desc, s->assoc_epoch, s->n_pix_blocks, s->d_log, s->d_tb,
-                       s->d_compact_part, s->n_compact_part);
+                       s->d_compact_part, s->n_compact_part, s->d_alive, s->d_tile_dead);
     HIPCK(hipGetLastError());
     if (mark(s, 5, timed) || mark(s, 6, timed) || mark(s, 7, timed)) return SM_E_HIP;
     return SM_OK;
@@ -389,7 +446,7 @@ int launch_associate(sm_ctx *s, const FrameParams &fp, bool timed)
         if (mark(s, 6, timed)) return SM_E_HIP;
         hipLaunchKernelGGL(k_append_scan, dim3(s->n_pix_blocks), dim3(PIX_BLOCK), 0, s->stream, s->M, s->d_state, fp, s->d_depthT,
                            s->d_rgbsT, s->d_xs, s->d_ys, s->d_validmask, s->d_fusedmask, s->d_blk_cnt, s->d_log, s->d_tb, s->d_compact_part,
-                           s->n_compact_part);
+                           s->n_compact_part, s->d_alive, s->d_tile_dead);
         HIPCK(hipGetLastError());
         if (mark(s, 7, timed)) return SM_E_HIP;
         return SM_OK;
@@ -453,6 +510,7 @@ int begin_frame(sm_ctx *s, const uint8_t *d_rgb, const uint16_t *d_raw, const ui
         if (s->sh_world > 1) { g_err = "reset() is not supported in sharded mode"; return SM_E_UNSUPPORTED; }
         fp.init_mode = 1;
         fp.log_frame = 0;
+        s->n_compact_part = 0;                            // no cull / splat ran: nothing to fold into visible_count
         if ((rc = launch_associate(s, fp, false))) return rc;
         bump_bound(s);
         end_frame(s, false);
@@ -480,6 +538,8 @@ int enqueue_frame(sm_ctx *s, const uint8_t *d_rgb, const uint16_t *d_raw, const 
     FrameParams fp;
     int rc = begin_frame(s, d_rgb, d_raw, d_sem, pose, &fp);
     if (rc <= 0) return rc;
+    fp.compact_pct = (uint32_t)s->cfg.compact_garbage_pct;
+    if (fp.compact_pct) s->maybe_garbage = true;
     if ((rc = launch_conflict(s, fp, true))) return rc;    // :178-187
     if ((rc = launch_compact(s, fp, true, true))) return rc;   // :189-197 (cull + mirror + index map)
     if ((rc = launch_associate(s, fp, true))) return rc;   // :212-239
@@ -573,12 +633,13 @@ int sm_default_config(sm_config *c, int width, int height, float fx, float fy, f
     c->conflict_cap = 1;
     c->device = 0;
     c->enable_timing = 0;
+    c->compact_garbage_pct = 12;
     return SM_OK;
 }
 
 sm_ctx *sm_create(const sm_config *c)
 {
-    if (!c || c->width <= 0 || c->height <= 0 || c->max_sqrt_vertices <= 0 ||
+    if (!c || c->width <= 0 || c->height <= 0 || c->max_sqrt_vertices <= 0 || c->compact_garbage_pct < 0 || c->compact_garbage_pct > 90 ||
         (uint64_t)c->width * c->height > (1u << 30) || (uint64_t)c->max_sqrt_vertices * c->max_sqrt_vertices > 0x7FFFFFFFull) {
         g_err = "sm_create: bad config";
         return nullptr;
@@ -607,12 +668,15 @@ sm_ctx *sm_create(const sm_config *c)
     ok = ok && dalloc(&s->d_depth_f32, P) == SM_OK;
     ok = ok && dalloc(&s->d_xs, (size_t)s->W * 2) == SM_OK && dalloc(&s->d_ys, (size_t)s->H * 2) == SM_OK && dalloc(&s->d_wtab, (size_t)169) == SM_OK;
     ok = ok && dalloc(&s->d_cm, nwords) == SM_OK && dalloc(&s->d_dm, nwords) == SM_OK && dalloc(&s->d_zm, nwords) == SM_OK;
+    s->alive_words = nwords; s->dead_tiles = ntiles;
+    ok = ok && dalloc(&s->d_alive, nwords) == SM_OK && hipMemset(s->d_alive, 0xFF, nwords * 8) == hipSuccess &&
+         dalloc(&s->d_tile_dead, ntiles) == SM_OK && hipMemset(s->d_tile_dead, 0, ntiles * 4) == hipSuccess;
     ok = ok && dalloc(&s->d_tile_cnt, ntiles * 3) == SM_OK && dalloc(&s->d_tile_allow, ntiles) == SM_OK &&
          dalloc(&s->d_tile_keep, ntiles) == SM_OK && dalloc(&s->d_tile_flag, ntiles) == SM_OK &&
          hipMemset(s->d_tile_flag, 0, ntiles * 4) == hipSuccess &&
          dalloc(&s->d_group_tot, (ntiles / GROUP + 2) * 4) == SM_OK && dalloc(&s->d_group_base, ntiles / GROUP + 2) == SM_OK;
     s->tb_tiles = (uint32_t)(ntiles + P / 2 / TILE + 8);
-    ok = ok && dalloc(&s->d_conf_part, (size_t)MAX_GRID) == SM_OK && dalloc(&s->d_compact_part, (size_t)MAX_GRID) == SM_OK;
+    ok = ok && dalloc(&s->d_conf_part, (size_t)MAX_GRID * 4) == SM_OK && dalloc(&s->d_compact_part, (size_t)MAX_GRID) == SM_OK;
     ok = ok && dalloc(&s->d_tb, (size_t)s->tb_tiles * 8) == SM_OK && dalloc(&s->d_tile_flags, (size_t)s->tb_tiles) == SM_OK &&
          hipMemset(s->d_tile_flags, 0, s->tb_tiles) == hipSuccess;
     ok = ok && dalloc(&s->d_validmask, (P + 63) / 64 + 4) == SM_OK && dalloc(&s->d_fusedmask, (P + 63) / 64 + 4) == SM_OK;
@@ -715,7 +779,7 @@ void sm_destroy(sm_ctx *s)
     (void)hipFree(s->d_rgbsT); (void)hipFree(s->d_keyT);
     (void)hipFree(s->d_rgb); (void)hipFree(s->d_sem); (void)hipFree(s->d_depth_raw); (void)hipFree(s->d_depth_f32);
     (void)hipFree(s->d_xs); (void)hipFree(s->d_ys); (void)hipFree(s->d_wtab);
-    (void)hipFree(s->d_cm); (void)hipFree(s->d_dm); (void)hipFree(s->d_zm);
+    (void)hipFree(s->d_cm); (void)hipFree(s->d_dm); (void)hipFree(s->d_zm); (void)hipFree(s->d_alive); (void)hipFree(s->d_tile_dead);
     (void)hipFree(s->d_tile_cnt); (void)hipFree(s->d_tile_allow); (void)hipFree(s->d_tile_keep); (void)hipFree(s->d_tile_flag); (void)hipFree(s->d_group_tot); (void)hipFree(s->d_group_base); (void)hipFree(s->d_tb); (void)hipFree(s->d_tile_flags); (void)hipFree(s->d_conf_part); (void)hipFree(s->d_compact_part);
     (void)hipFree(s->d_validmask); (void)hipFree(s->d_fusedmask); (void)hipFree(s->d_blk_prefix); (void)hipFree(s->d_desc); (void)hipFree(s->d_blk_cnt);
     (void)hipFree(s->d_seg_lstart); (void)hipFree(s->d_seg_gbase); (void)hipFree(s->d_gseg_base); (void)hipFree(s->d_seg_keep);
@@ -770,8 +834,11 @@ int sm_clean_points(sm_ctx *s, const uint16_t *depth_mm, const uint8_t *semantic
     fp.max_depth = s->cfg.far_clip - 15.0f;     // src/SurfelMapping.cpp:515
     fp.conflict_thresh = 0.1f;                  // :516
     fp.is_clean = 1;                            // :517
+    fp.compact_pct = s->sh_world > 1 ? 0u : (uint32_t)s->cfg.compact_garbage_pct;
+    if (fp.compact_pct) s->maybe_garbage = true;
     if ((rc = launch_conflict(s, fp))) return rc;
     if ((rc = launch_compact(s, fp, false, false))) return rc;
+    if ((rc = launch_post_fill(s))) return rc;
     return sm_sync(s);
 }
 
@@ -781,6 +848,11 @@ int sm_reset(sm_ctx *s)
     HIPCK(hipSetDevice(s->cfg.device));
     int rc = pull_state(s);
     if (rc) return rc;
+    if (s->maybe_garbage) {
+        HIPCK(hipMemsetAsync(s->d_alive, 0xFF, s->alive_words * 8, s->stream));
+        HIPCK(hipMemsetAsync(s->d_tile_dead, 0, s->dead_tiles * 4, s->stream));
+        s->maybe_garbage = false;
+    }
     const uint32_t cur = s->h_state->cur;
     memset(s->h_state, 0, sizeof(DevState));
     s->h_state->cur = cur;
@@ -803,8 +875,9 @@ int sm_download_model_aos(sm_ctx *s, float *dst12, uint32_t cap, uint32_t *n)
 {
     if (!s || !n) return SM_E_ARG;
     HIPCK(hipSetDevice(s->cfg.device));
-    int rc = pull_state(s);
+    int rc = ensure_compact(s);
     if (rc) return rc;
+    if ((rc = pull_state(s))) return rc;
     const uint32_t cnt = s->pending_cull ? s->count_before_cull : s->h_state->count;
     *n = cnt;
     if (!dst12) return SM_OK;
@@ -827,8 +900,9 @@ int sm_upload_model_aos(sm_ctx *s, const float *src12, uint32_t n)
     if (!s || (!src12 && n)) return SM_E_ARG;
     HIPCK(hipSetDevice(s->cfg.device));
     if (n > s->cap) { g_err = "sm_upload_model_aos: exceeds MAX_VERTICES"; return SM_E_CAPACITY; }
-    int rc = pull_state(s);
+    int rc = ensure_compact(s);
     if (rc) return rc;
+    if ((rc = pull_state(s))) return rc;
     const uint32_t CH = 1u << 22;
     if (n && (rc = ensure_export(s, (size_t)std::min(n, CH) * 48))) return rc;
     for (uint32_t first = 0; first < n; first += CH) {
@@ -840,6 +914,7 @@ int sm_upload_model_aos(sm_ctx *s, const float *src12, uint32_t n)
     }
     s->h_state->count = n;                       // src/GlobalModel.cpp:995
     s->h_state->offset = n;
+    s->h_state->garbage = 0; s->h_state->garbage_prev = 0; s->h_state->first_live = 0; s->h_state->do_compact = 0;
     s->pending_cull = false;
     if ((rc = push_state(s))) return rc;
     if ((rc = rebuild_bounds(s, 0, n))) return rc;
@@ -886,8 +961,9 @@ int sm_download_index_map(sm_ctx *s, int32_t *id, float *vert_conf4, float *colo
     if (!s) return SM_E_ARG;
     HIPCK(hipSetDevice(s->cfg.device));
     const size_t P = (size_t)s->P;
-    int rc = ensure_export(s, P * 52);
+    int rc = ensure_compact(s);
     if (rc) return rc;
+    if ((rc = ensure_export(s, P * 52))) return rc;
     char *base = (char *)s->d_export;
     int32_t *d_id = (int32_t *)(base + P * 48);
     float4 *d_vc = (float4 *)base, *d_ct = (float4 *)(base + P * 16), *d_nr = (float4 *)(base + P * 32);
@@ -927,8 +1003,9 @@ int sm_render_image(sm_ctx *s, const float *view16, int w, int h, float fx, floa
     if (!s || !view16 || w <= 0 || h <= 0 || (uint64_t)w * h > (1u << 28) || !bgr_out || !sem_out) return SM_E_ARG;
     HIPCK(hipSetDevice(s->cfg.device));
     if (s->pending_cull) { g_err = "sm_render_image between sm_stage_conflict and sm_stage_cull"; return SM_E_ARG; }
-    int rc = pull_state(s);
+    int rc = ensure_compact(s);
     if (rc) return rc;
+    if ((rc = pull_state(s))) return rc;
     const size_t npix = (size_t)w * h;
     if ((rc = ensure_export(s, npix * 12))) return rc;            // [keys u64 | bgr | sem]
     uint64_t *d_key = (uint64_t *)s->d_export;
@@ -980,8 +1057,9 @@ int sm_stage_conflict(sm_ctx *s, const float *pose16, float min_depth, float max
 {
     if (!s || !pose16) return SM_E_ARG;
     HIPCK(hipSetDevice(s->cfg.device));
-    int rc = pull_state(s);
+    int rc = s->pending_cull ? SM_OK : ensure_compact(s);
     if (rc) return rc;
+    if ((rc = pull_state(s))) return rc;
     if (s->pending_cull) {
         // processConflict may be called again before backMapping (it only rewrites conflictVbo,
         // src/GlobalModel.cpp:449-454): re-arm the not yet applied cull.
@@ -1019,8 +1097,9 @@ int sm_stage_splat(sm_ctx *s, const float *pose16, int32_t time, float depth_cut
     if (!s || !pose16) return SM_E_ARG;
     HIPCK(hipSetDevice(s->cfg.device));
     if (s->pending_cull) { g_err = "sm_stage_splat between sm_stage_conflict and sm_stage_cull"; return SM_E_ARG; }
-    int rc = pull_state(s);
+    int rc = ensure_compact(s);
     if (rc) return rc;
+    if ((rc = pull_state(s))) return rc;
     memcpy(s->curr_pose, pose16, 64);
     FrameParams fp = make_params(s, pose16);
     fp.time = time; fp.depth_cutoff = depth_cutoff; fp.time_delta = time_delta;
@@ -1042,8 +1121,9 @@ int sm_stage_associate_fuse(sm_ctx *s, const float *pose16, int32_t time, float 
     memcpy(s->curr_pose, pose16, 64);
     FrameParams fp = make_params(s, pose16);
     fp.time = time; fp.min_depth = depth_min; fp.max_depth = depth_max;
-    int rc = launch_associate(s, fp, false);
+    int rc = ensure_compact(s);
     if (rc) return rc;
+    if ((rc = launch_associate(s, fp, false))) return rc;
     return sm_sync(s);
 }
 
@@ -1154,8 +1234,9 @@ int sm_export_model_device(sm_ctx *s, void **d_aos, uint32_t *n)
     if (!s || !d_aos || !n) return SM_E_ARG;
     HIPCK(hipSetDevice(s->cfg.device));
     if (s->pending_cull) { g_err = "sm_export_model_device between sm_stage_conflict and sm_stage_cull"; return SM_E_ARG; }
-    int rc = pull_state(s);
+    int rc = ensure_compact(s);
     if (rc) return rc;
+    if ((rc = pull_state(s))) return rc;
     const uint32_t cnt = s->h_state->count;
     if ((rc = ensure_export(s, (size_t)std::max(cnt, 1u) * 48))) return rc;
     if (cnt) {
@@ -1173,8 +1254,9 @@ int sm_append_model_aos_device(sm_ctx *s, const float *d_src12, uint32_t n)
     if (!s || (!d_src12 && n)) return SM_E_ARG;
     HIPCK(hipSetDevice(s->cfg.device));
     if (s->pending_cull) { g_err = "sm_append_model_aos_device between sm_stage_conflict and sm_stage_cull"; return SM_E_ARG; }
-    int rc = pull_state(s);
+    int rc = ensure_compact(s);
     if (rc) return rc;
+    if ((rc = pull_state(s))) return rc;
     const uint32_t cnt = s->h_state->count;
     if ((uint64_t)cnt + n > s->cap) { g_err = "sm_append_model_aos_device: exceeds MAX_VERTICES"; return SM_E_CAPACITY; }
     if (n) {
@@ -1212,6 +1294,9 @@ int sm_device_download(sm_ctx *s, void *dst_host, const void *src_device, size_t
 int sm_shard_configure(sm_ctx *s, int rank, int world)
 {
     if (!s || world < 1 || rank < 0 || rank >= world) return SM_E_ARG;
+    HIPCK(hipSetDevice(s->cfg.device));
+    int rcc = ensure_compact(s);
+    if (rcc) return rcc;
     s->sh_rank = rank; s->sh_world = world;
     s->sh_nseg = 0; s->sh_ngseg = 0; s->sh_exempt = 0; s->sh_in_frame = false;
     return ensure_seg(s, 64);

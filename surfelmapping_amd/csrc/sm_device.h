@@ -36,8 +36,8 @@ struct Model {
 // Device-resident frame state: every kernel reads its sizes from here so that a frame needs
 // no host read-back (the reference blocks on 6 glGetQueryObjectuiv per frame).
 struct DevState {
-    uint32_t count;           // live surfels
-    uint32_t offset;          // survivors of the last cull
+    uint32_t count;           // occupied slots [0, count): live surfels + `garbage` dead ones (deferred compaction)
+    uint32_t offset;          // slots occupied after the last cull (where the frame's new surfels are appended)
     uint32_t cur;             // which SurfelSet holds the model
     uint32_t cull_n;          // count before the pending cull
     uint32_t cull_src, cull_dst;
@@ -51,10 +51,15 @@ struct DevState {
     uint32_t n_static;        // surfels in tiles the last cull left in place
     uint32_t n_conf_skipped;  // surfels in tiles the conflict pass skipped by their bounds
     uint32_t n_splat_skipped; // surfels in static tiles the splat skipped by their bounds
-    uint32_t pad2[2];
+    // ---- deferred compaction (DESIGN.md "Deferred compaction") ----
+    uint32_t garbage;         // dead slots below `offset`; live surfels = count - garbage
+    uint32_t garbage_prev;    // its value before the last cull
+    uint32_t do_compact;      // the last cull compacts physically (otherwise it only marks the dead in `alive`)
+    uint32_t cap_binds;       // the last cull had more conflicts than the conflict cap (tile_allow is in force)
+    uint32_t first_live;      // slot of the first live surfel = the reference's surfel id 0 (conflict.geom:15, data.vert:142)
 };
 
-struct FrameLog { uint32_t tick, n_before, n_after_cull, n_kill, conflict_count, visible_count, fused_count, unstable_count, n_static, n_conf_skipped, n_splat_skipped, pad; };
+struct FrameLog { uint32_t tick, n_before, n_after_cull, n_kill, conflict_count, visible_count, fused_count, unstable_count, n_static, n_conf_skipped, n_splat_skipped, n_slots; };
 constexpr uint32_t FRAME_LOG_LEN = 1024;
 
 struct FrameParams {
@@ -86,6 +91,9 @@ struct FrameParams {
     int init_mode;            // 1: every checkerboard pixel with 0 < z < far becomes a surfel, no association
     float inv_fx_fb, inv_fy_fb;   // 1.0f/fx as float division (src/FeedbackBuffer.cpp:93-96)
     int use_bounds;           // 1: whole 1024-surfel tiles are skipped when their bounding box is outside the view
+    // ---- deferred compaction ----
+    uint32_t compact_pct;     // 0: every cull compacts (the reference's behaviour); else compact once dead slots exceed this % of the slots
+    int maintenance;          // 1: compaction outside a frame (no kills): frame statistics are left alone
 };
 
 // local index -> global id through the per-segment tables (segments = surfels created by one frame,

@@ -262,15 +262,19 @@ __global__ __launch_bounds__(256) void k_conflict(Model M, const DevState *__res
                                                   uint64_t *__restrict__ cm, uint64_t *__restrict__ dm,
                                                   uint64_t *__restrict__ zm, uint32_t *__restrict__ tile_cnt,
                                                   const uint32_t *__restrict__ tb, uint8_t *__restrict__ tile_flags,
-                                                  uint32_t *__restrict__ blk_part /* [grid] skipped */)
+                                                  uint32_t *__restrict__ blk_part /* [grid][4]: skipped, nconf, nkill, - */,
+                                                  const uint64_t *__restrict__ alive)
 {
     __shared__ uint32_t s_red[4][3];
     __shared__ uint64_t s_m[3][TILE_WORDS];
     const uint32_t N = st->count;
+    const bool has_dead = st->garbage != 0u;          // slots of surfels killed since the last physical compaction
+    const uint32_t exempt = fp.world > 1 ? fp.exempt_local : st->first_live;   // the surfel with (global) id 0
     const float4 *__restrict__ pc = M.s[st->cur].pos_conf;
     const uint32_t ntiles = (N + TILE - 1) / TILE;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t skipped = 0;
+    uint32_t acc = 0;                 // thread 0: conflicts, thread 1: kills of this workgroup's tiles
     uint64_t skipmask = 0;
     uint32_t iter = 0;
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x, ++iter) {
@@ -306,6 +310,10 @@ __global__ __launch_bounds__(256) void k_conflict(Model M, const DevState *__res
             const uint32_t k = (tile * TILE_WORDS + r * 4 + wave) * 64u + lane;
             valid[r] = k < N;
             v[r] = pc[min(k, N - 1u)];          // unconditional (clamped): a branch here would serialise the loads
+        }
+        if (has_dead) {                         // workgroup-uniform
+#pragma unroll
+            for (int r = 0; r < 4; ++r) valid[r] = valid[r] && ((alive[tile * TILE_WORDS + r * 4 + wave] >> lane) & 1ull);
         }
         // phase 2: projection + view test; phase 3: the dependent depth/class gathers, again together
         float zc[4], lam[4], dep[4];
@@ -347,7 +355,7 @@ __global__ __launch_bounds__(256) void k_conflict(Model M, const DevState *__res
                 float depth = dep[r];
                 if (cls[r] == 10u) depth = fp.max_depth + 1.0f;
                 if (fp.is_clean == 0 && depth == 0.0f) depth = fp.max_depth + 20.0f;
-                conflict = (depth * lam[r] - zc[r] * lam[r] > fp.conflict_thresh * zc[r]) && (k != fp.exempt_local);
+                conflict = (depth * lam[r] - zc[r] * lam[r] > fp.conflict_thresh * zc[r]) && (k != exempt);
             }
             const bool dies = valid[r] && !(v[r].w - 1.0f > 0.0f);
             const bool dead = valid[r] && !(v[r].w > 0.0f);
@@ -360,8 +368,9 @@ __global__ __launch_bounds__(256) void k_conflict(Model M, const DevState *__res
         if (lane == 0) { s_red[wave][0] = nconf; s_red[wave][1] = nkill; s_red[wave][2] = nzero; }
         __syncthreads();
         if (threadIdx.x < 3) {
-            tile_cnt[tile * 3 + threadIdx.x] = s_red[0][threadIdx.x] + s_red[1][threadIdx.x] +
-                                               s_red[2][threadIdx.x] + s_red[3][threadIdx.x];
+            const uint32_t tsum = s_red[0][threadIdx.x] + s_red[1][threadIdx.x] + s_red[2][threadIdx.x] + s_red[3][threadIdx.x];
+            tile_cnt[tile * 3 + threadIdx.x] = tsum;
+            acc += tsum;
         }
         if (threadIdx.x >= 64 && threadIdx.x < 64 + 3 * TILE_WORDS) {
             // one store instruction for the tile's 3 x 16 ballot words (48 lanes, three 128-byte runs)
@@ -374,7 +383,9 @@ __global__ __launch_bounds__(256) void k_conflict(Model M, const DevState *__res
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0) blk_part[blockIdx.x] = skipped;      // summed by k_cull_finalize (no same-address atomics)
+    // per-workgroup partials, summed by k_cull_finalize (no same-address atomics)
+    if (threadIdx.x < 2) blk_part[blockIdx.x * 4 + 1 + threadIdx.x] = acc;
+    if (threadIdx.x == 0) blk_part[blockIdx.x * 4] = skipped;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -393,7 +404,8 @@ __global__ __launch_bounds__(1024) void k_scan_cull(const DevState *__restrict__
                                                     const uint32_t *__restrict__ tile_cnt,
                                                     uint32_t *__restrict__ tile_allow,
                                                     uint32_t *__restrict__ tile_keep_prefix,
-                                                    uint32_t *__restrict__ group_tot /* [g][4]: conf, keep, first killing tile, - */)
+                                                    uint32_t *__restrict__ group_tot /* [g][4]: conf, keep, first killing tile, - */,
+                                                    const uint32_t *__restrict__ tile_dead)
 {
     __shared__ uint32_t s_scan[17];
     __shared__ uint32_t s_first;
@@ -406,8 +418,8 @@ __global__ __launch_bounds__(1024) void k_scan_cull(const DevState *__restrict__
     if (t < ntiles) {
         nconf = tile_cnt[t * 3];
         const uint32_t nkill = tile_cnt[t * 3 + 1];
-        keep = min((uint32_t)TILE, N - t * TILE) - nkill;
-        kills = nkill != 0;
+        keep = min((uint32_t)TILE, N - t * TILE) - tile_dead[t] - nkill;
+        kills = nkill != 0 || tile_dead[t] != 0;
         tile_allow[t] = nconf;                  // every conflict takes effect unless the cap binds
     }
     uint32_t ctot, ktot;
@@ -423,6 +435,25 @@ __global__ __launch_bounds__(1024) void k_scan_cull(const DevState *__restrict__
     }
 }
 
+// survivors of one 64-surfel word of tile `t` under the effective conflict set (the first `allow` conflicts of the tile)
+__device__ __forceinline__ uint64_t keep_word(uint32_t t, int w, uint32_t N, const uint64_t *__restrict__ cm,
+                                              const uint64_t *__restrict__ dm, const uint64_t *__restrict__ zm,
+                                              const uint64_t *__restrict__ alive, uint32_t allow, uint32_t nconf)
+{
+    const uint32_t word = t * TILE_WORDS + (uint32_t)w;
+    const uint64_t base = (uint64_t)word * 64u;
+    if (base >= N) return 0ull;
+    const uint64_t rem = (uint64_t)N - base;
+    const uint64_t valid = (rem >= 64 ? ~0ull : ((1ull << rem) - 1ull)) & alive[word];
+    uint64_t ce = cm[word];
+    if (allow != nconf) {
+        uint32_t before = 0;
+        for (int x = 0; x < w; ++x) before += (uint32_t)__popcll(cm[t * TILE_WORDS + x]);
+        ce = before >= allow ? 0ull : first_n_bits(ce, allow - before);
+    }
+    return ~(zm[word] | (ce & dm[word])) & valid;
+}
+
 __global__ __launch_bounds__(1024) void k_cull_finalize(DevState *__restrict__ st, FrameParams fp,
                                                         const uint64_t *__restrict__ cm,
                                                         const uint64_t *__restrict__ dm,
@@ -432,29 +463,57 @@ __global__ __launch_bounds__(1024) void k_cull_finalize(DevState *__restrict__ s
                                                         uint32_t *__restrict__ tile_keep_prefix,
                                                         const uint32_t *__restrict__ group_tot,
                                                         uint32_t *__restrict__ group_keep_base,
-                                                        const uint32_t *__restrict__ conf_part, uint32_t n_conf_part)
+                                                        const uint32_t *__restrict__ conf_part, uint32_t n_conf_part,
+                                                        const uint64_t *__restrict__ alive,
+                                                        const uint32_t *__restrict__ tile_dead)
 {
     __shared__ uint32_t s_scan[17];
-    __shared__ uint32_t s_first;
-    const uint32_t N = st->count;
+    __shared__ uint32_t s_first, s_ft, s_fl, s_keep_first;
+    const uint32_t N = st->count;                     // occupied slots
+    const uint32_t g0 = st->garbage;                  // dead ones among them
+    const uint32_t old_first = st->first_live, old_offset = st->offset;
     const uint32_t ntiles = (N + TILE - 1) / TILE;
     const uint32_t ngroups = (ntiles + GROUP - 1) / GROUP;
     const uint32_t cap = fp.conflict_cap;
-    if (threadIdx.x == 0) s_first = 0xFFFFFFFFu;
-    __syncthreads();
-    // ---- fast path: scan the group totals (ngroups <= 1024 covers 1 G surfels)
-    uint32_t gc = 0, gk = 0;
-    if (threadIdx.x < ngroups) {
-        gc = group_tot[threadIdx.x * 4 + 0];
-        gk = group_tot[threadIdx.x * 4 + 1];
-        atomicMin(&s_first, group_tot[threadIdx.x * 4 + 2]);
+    // k_scan_cull ran before this kernel only where every cull compacts; otherwise the per-tile prefixes are
+    // produced here, and only on the frames that do compact
+    const bool have_scan = fp.compact_pct == 0u || fp.maintenance != 0;
+    if (threadIdx.x == 0) { s_first = 0xFFFFFFFFu; s_ft = 0xFFFFFFFFu; s_fl = 0xFFFFFFFFu; }
+    if (threadIdx.x == 1023) {
+        // does the surfel that is id 0 today survive this cull?  (almost always: then its slot stays "id 0")
+        uint32_t survive = 0;
+        if (old_first < N) {
+            const uint32_t w = old_first / 64u, bit = old_first % 64u;
+            survive = (((zm[w] | (cm[w] & dm[w])) >> bit) & 1ull) ? 0u : 1u;     // all conflicts counted: conservative under the cap
+        }
+        s_keep_first = survive;
     }
-    uint32_t ctotal, ktotal;
-    block_scan_1024(gc, &ctotal, s_scan);
-    const uint32_t gkpre = block_scan_1024(gk, &ktotal, s_scan);
-    uint32_t nstatic = (s_first == 0xFFFFFFFFu) ? N : min(N, s_first * (uint32_t)TILE);
-    if (ctotal <= cap) {
-        if (threadIdx.x < ngroups) group_keep_base[threadIdx.x] = gkpre;
+    // totals of the conflict pass (per-workgroup partials instead of same-address atomics)
+    uint32_t cskip = 0, cconf = 0, ckill = 0, cskip_tot, cconf_tot, ckill_tot;
+    for (uint32_t b = threadIdx.x; b < n_conf_part; b += 1024u) {
+        cskip += conf_part[b * 4]; cconf += conf_part[b * 4 + 1]; ckill += conf_part[b * 4 + 2];
+    }
+    __syncthreads();
+    block_scan_1024(cskip, &cskip_tot, s_scan);
+    block_scan_1024(cconf, &cconf_tot, s_scan);
+    block_scan_1024(ckill, &ckill_tot, s_scan);
+    uint32_t ctotal = cconf_tot, ktotal = (N - g0) - ckill_tot, gkpre = 0;
+    uint32_t nstatic = N;
+    if (have_scan) {
+        // scan the group totals of k_scan_cull (ngroups <= 1024 covers 1 G surfels)
+        uint32_t gc = 0, gk = 0;
+        if (threadIdx.x < ngroups) {
+            gc = group_tot[threadIdx.x * 4 + 0];
+            gk = group_tot[threadIdx.x * 4 + 1];
+            atomicMin(&s_first, group_tot[threadIdx.x * 4 + 2]);
+        }
+        block_scan_1024(gc, &ctotal, s_scan);
+        gkpre = block_scan_1024(gk, &ktotal, s_scan);
+        nstatic = (s_first == 0xFFFFFFFFu) ? N : min(N, s_first * (uint32_t)TILE);
+    }
+    const bool cap_binds = ctotal > cap;
+    if (!cap_binds) {
+        if (have_scan && threadIdx.x < ngroups) group_keep_base[threadIdx.x] = gkpre;
     } else {
         // ---- slow path: the cap binds; exact sequential-order scan with absolute prefixes
         if (threadIdx.x < ngroups) group_keep_base[threadIdx.x] = 0;
@@ -487,36 +546,137 @@ __global__ __launch_bounds__(1024) void k_cull_finalize(DevState *__restrict__ s
                 }
             }
             tile_keep_prefix[t] = kills;          // parked: rewritten with the prefix below
-            ksum += min((uint32_t)TILE, N - t * TILE) - kills;
+            ksum += min((uint32_t)TILE, N - t * TILE) - tile_dead[t] - kills;
             cpre += nconf;
         }
         uint32_t kpre = block_scan_1024(ksum, &ktotal, s_scan);
         uint32_t ns = 0;
         for (uint32_t t = t0; t < t1; ++t) {
             const uint32_t kills = tile_keep_prefix[t];
-            const uint32_t nv = min((uint32_t)TILE, N - t * TILE);
+            const uint32_t nv = min((uint32_t)TILE, N - t * TILE) - tile_dead[t];
             if (kpre == t * TILE && kills == 0) ns += nv;
             tile_keep_prefix[t] = kpre;
             kpre += nv - kills;
         }
         block_scan_1024(ns, &nstatic, s_scan);
     }
-    uint32_t cskip = 0, cskip_tot;
-    for (uint32_t b = threadIdx.x; b < n_conf_part; b += 1024u) cskip += conf_part[b];
-    block_scan_1024(cskip, &cskip_tot, s_scan);
+    // ---- deferred compaction: mark the dead now, move the survivors only once enough slots are dead
+    const uint32_t kept = ktotal;                     // live surfels after this cull
+    const uint32_t g1 = N - kept;                     // dead slots if nothing moves
+    const bool compact = fp.compact_pct == 0u || fp.maintenance != 0 ||
+                         (uint64_t)g1 * 100u > (uint64_t)N * fp.compact_pct ||
+                         (g1 != 0u && (uint64_t)N + (uint64_t)fp.P > (uint64_t)fp.max_vertices);
+    if (compact && !have_scan && !cap_binds) {
+        // survivor prefixes for the compaction, 1024 tiles per round (only on the frames that compact)
+        if (threadIdx.x < ngroups) group_keep_base[threadIdx.x] = 0;
+        uint32_t carry = 0;
+        for (uint32_t base = 0; base < ntiles; base += 1024u) {
+            const uint32_t t = base + threadIdx.x;
+            uint32_t keep = 0;
+            if (t < ntiles) {
+                const uint32_t nk = tile_cnt[t * 3 + 1], td = tile_dead[t];
+                keep = min((uint32_t)TILE, N - t * TILE) - td - nk;
+                if (nk != 0u || td != 0u) atomicMin(&s_first, t);
+            }
+            uint32_t tot;
+            const uint32_t excl = block_scan_1024(keep, &tot, s_scan);
+            if (t < ntiles) tile_keep_prefix[t] = carry + excl;
+            carry += tot;
+        }
+        __syncthreads();
+        nstatic = (s_first == 0xFFFFFFFFu) ? N : min(N, s_first * (uint32_t)TILE);
+    }
+    // slot of the first survivor (the surfel the reference addresses as id 0)
+    uint32_t first_live = compact ? 0u : N;
+    if (!compact && kept != 0u) {
+        __syncthreads();                              // s_keep_first; tile_keep_prefix of the slow path
+        if (s_keep_first) {
+            first_live = old_first;
+        } else {
+            for (uint32_t base = min(old_first, N - 1u) / TILE; base < ntiles; base += 1024u) {
+                const uint32_t t = base + threadIdx.x;
+                if (t < ntiles) {
+                    uint32_t keep_t;
+                    if (cap_binds) keep_t = ((t + 1 < ntiles) ? tile_keep_prefix[t + 1] : kept) - tile_keep_prefix[t];
+                    else keep_t = min((uint32_t)TILE, N - t * TILE) - tile_dead[t] - tile_cnt[t * 3 + 1];
+                    if (keep_t != 0u) atomicMin(&s_ft, t);
+                }
+                __syncthreads();
+                const uint32_t found = s_ft;
+                __syncthreads();
+                if (found != 0xFFFFFFFFu) break;
+            }
+            const uint32_t ft = s_ft;
+            if (ft != 0xFFFFFFFFu && threadIdx.x < TILE_WORDS) {
+                const uint32_t nconf = tile_cnt[ft * 3];
+                const uint64_t k = keep_word(ft, (int)threadIdx.x, N, cm, dm, zm, alive, cap_binds ? tile_allow[ft] : nconf, nconf);
+                if (k) atomicMin(&s_fl, (ft * TILE_WORDS + threadIdx.x) * 64u + (uint32_t)(__ffsll((long long)k) - 1));
+            }
+            __syncthreads();
+            first_live = s_fl;
+        }
+    }
     if (threadIdx.x == 0) {
-        const uint32_t kept = ktotal;
-        st->n_conf_skipped = cskip_tot;
-        st->n_static = nstatic;
+        if (!fp.maintenance) {
+            st->n_conf_skipped = cskip_tot;
+            st->n_static = compact ? nstatic : N;
+            st->n_kill = (N - g0) - kept;
+            st->conflict_count = min(ctotal, cap);
+            if (fp.splat_follows) st->visible_count = 0;
+        }
         st->cull_n = N;
-        st->n_kill = N - kept;
-        st->conflict_count = min(ctotal, cap);
         st->cull_src = st->cur;
         st->cull_dst = st->cur;                           // compaction is in place
-        st->count = kept;                                 // src/GlobalModel.cpp:575
-        st->offset = kept;
-        if (fp.splat_follows) st->visible_count = 0;
+        st->garbage_prev = g0;
+        st->cap_binds = cap_binds ? 1u : 0u;
+        st->do_compact = compact ? 1u : 0u;
+        st->first_live = first_live;
+        if (compact) {
+            st->count = kept;                             // src/GlobalModel.cpp:575
+            st->offset = fp.maintenance ? old_offset - g0 : kept;
+            st->garbage = 0;
+        } else {
+            st->count = N;                                // the dead keep their slots until the next compaction
+            st->offset = N;
+            st->garbage = g1;
+        }
     }
+}
+
+// after a physical compaction every slot below the new count is live again: refill the alive mask and clear
+// the per-tile dead counts over the range the model occupied before (grid-stride, called by the frame's last
+// kernel or by k_post_fill)
+__device__ __forceinline__ void post_compact_fill(const DevState *__restrict__ st, uint64_t *__restrict__ alive,
+                                                  uint32_t *__restrict__ tile_dead, uint32_t tid, uint32_t nthreads)
+{
+    if (st->do_compact == 0u || st->garbage_prev == 0u) return;
+    const uint32_t n = st->cull_n;
+    const uint32_t nwords = (n + 63u) / 64u, ntiles = (n + TILE - 1) / TILE;
+    for (uint32_t w = tid; w < nwords; w += nthreads) alive[w] = ~0ull;
+    for (uint32_t t = tid; t < ntiles; t += nthreads) tile_dead[t] = 0u;
+}
+
+__global__ void k_post_fill(const DevState *__restrict__ st, uint64_t *__restrict__ alive, uint32_t *__restrict__ tile_dead)
+{
+    post_compact_fill(st, alive, tile_dead, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
+}
+
+// ids of the key map: slot -> position among the live surfels (before a compaction outside a frame moves them)
+__global__ void k_remap_keys(const DevState *__restrict__ st, uint64_t *__restrict__ keyT, int P,
+                             const uint64_t *__restrict__ alive, const uint32_t *__restrict__ tile_keep_prefix,
+                             const uint32_t *__restrict__ group_keep_base)
+{
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= P || st->garbage_prev == 0u) return;
+    const uint64_t key = keyT[q];
+    if (key == KEY_EMPTY) return;
+    const uint32_t id = (uint32_t)(key & 0xFFFFFFFFull);
+    if (id >= st->cull_n) return;
+    const uint32_t tile = id / TILE, w = (id % TILE) / 64u, bit = id % 64u;
+    uint32_t nid = tile_keep_prefix[tile] + group_keep_base[tile / GROUP];
+    for (uint32_t x = 0; x < w; ++x) nid += (uint32_t)__popcll(alive[tile * TILE_WORDS + x]);
+    nid += (uint32_t)__popcll(alive[tile * TILE_WORDS + w] & ((1ull << bit) - 1ull));
+    keyT[q] = (key & 0xFFFFFFFF00000000ull) | (uint64_t)nid;
 }
 
 // z-buffered 1-px splat of one surfel (index_map.vert:38-64, index_map.frag:31-37;
@@ -574,7 +734,8 @@ __global__ __launch_bounds__(256) void k_compact(Model M, DevState *__restrict__
                                                  const uint32_t *__restrict__ seg_gbase,
                                                  const uint32_t *__restrict__ group_keep_base,
                                                  uint32_t *__restrict__ tb, const uint8_t *__restrict__ tile_flags,
-                                                 uint2 *__restrict__ blk_part /* [grid] (visible, splat-skipped) */)
+                                                 uint2 *__restrict__ blk_part /* [grid] (visible, splat-skipped) */,
+                                                 uint64_t *__restrict__ alive, uint32_t *__restrict__ tile_dead)
 {
     __shared__ uint64_t s_keep[TILE_WORDS], s_ceff[TILE_WORDS];
     __shared__ uint32_t s_cpop[TILE_WORDS], s_kpre[TILE_WORDS + 1];
@@ -585,7 +746,12 @@ __global__ __launch_bounds__(256) void k_compact(Model M, DevState *__restrict__
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t vis = 0, skipped = 0, iter = 0;
     uint64_t skipmask = 0;
-    uint32_t m_nconf = 0, m_nkill = 0, m_allow = 0, m_base = 0;
+    uint32_t m_nconf = 0, m_nkill = 0, m_allow = 0, m_base = 0, m_dead = 0;
+    // Deferred compaction: unless this cull compacts, survivors stay in their slots (slot = id for the key map: the
+    // order of slots is the order of ids) and the dead are only cleared from the alive mask.
+    const bool compacting = st->do_compact != 0u;
+    const bool had_dead = st->garbage_prev != 0u;
+    const bool cap_binds = st->cap_binds != 0u;
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x, ++iter) {
         if ((iter & 63u) == 0u) {
             // metadata of this workgroup's next 64 tiles in one round of loads (lane i <-> i-th tile), so that the
@@ -594,15 +760,18 @@ __global__ __launch_bounds__(256) void k_compact(Model M, DevState *__restrict__
             const bool in = tl < ntiles;
             const uint32_t tt = in ? (uint32_t)tl : 0u;
             skipmask = __ballot(in && (tile_flags[tt] & 2u));
-            m_nconf = tile_cnt[tt * 3]; m_nkill = tile_cnt[tt * 3 + 1]; m_allow = tile_allow[tt];
-            m_base = tile_keep_prefix[tt] + group_keep_base[tt / GROUP];
+            m_nconf = tile_cnt[tt * 3]; m_nkill = tile_cnt[tt * 3 + 1];
+            m_allow = cap_binds ? tile_allow[tt] : m_nconf;         // every conflict takes effect unless the cap binds
+            m_base = compacting ? tile_keep_prefix[tt] + group_keep_base[tt / GROUP] : tt * (uint32_t)TILE;
+            m_dead = had_dead ? tile_dead[tt] : 0u;
         }
         const int sl = (int)(iter & 63u);
         const uint32_t allow = (uint32_t)__shfl((int)m_allow, sl), nconf = (uint32_t)__shfl((int)m_nconf, sl);
         const uint32_t nkill_full = (uint32_t)__shfl((int)m_nkill, sl), base_id = (uint32_t)__shfl((int)m_base, sl);
+        const uint32_t tdead = (uint32_t)__shfl((int)m_dead, sl);
         // fast path (workgroup-uniform): nothing of this tile conflicts, dies or moves -- the bulk of the map
         // once the camera has passed.  No masks, no LDS, no barriers: read pos+time, splat.
-        if (nconf == 0 && nkill_full == 0 && base_id == tile * (uint32_t)TILE) {
+        if (nconf == 0 && nkill_full == 0 && base_id == tile * (uint32_t)TILE && (tdead == 0u || !compacting)) {
             // ... and if its box cannot reach the index map (index_map.vert:45-55: 0 < z < far inside the image,
             // updated within timeDelta frames) it is not even read
             if (SPLAT && ((skipmask >> (iter & 63u)) & 1ull)) {
@@ -622,8 +791,9 @@ __global__ __launch_bounds__(256) void k_compact(Model M, DevState *__restrict__
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const uint32_t k = (tile * TILE_WORDS + r * 4 + wave) * 64u + lane;
-                    bool drew = false;
-                    if (k < N)
+                    bool drew = false, live = k < N;
+                    if (tdead) live = live && ((alive[tile * TILE_WORDS + r * 4 + wave] >> lane) & 1ull);   // workgroup-uniform branch
+                    if (live)
                         drew = splat_one(fp, pv[r].x, pv[r].y, pv[r].z, pt[r], local_to_global(k, seg_lstart, seg_gbase, fp.nseg), keyT);
                     vis += (uint32_t)__popcll(__ballot(drew));
                 }
@@ -631,7 +801,7 @@ __global__ __launch_bounds__(256) void k_compact(Model M, DevState *__restrict__
             continue;
         }
         // conservative: a tile classified "moving" that turns out static is handled correctly (it rewrites itself)
-        const bool moving = (base_id != tile * (uint32_t)TILE) || (nkill_full != 0u);   // workgroup-uniform
+        const bool moving = compacting && ((base_id != tile * (uint32_t)TILE) || nkill_full != 0u || tdead != 0u);   // workgroup-uniform
         // ---- issue every surfel load of the tile first (unconditional, clamped: a per-lane branch would serialise
         // them behind s_waitcnt); the mask bookkeeping below overlaps their latency
         float4 v[4], nr[4];
@@ -647,7 +817,7 @@ __global__ __launch_bounds__(256) void k_compact(Model M, DevState *__restrict__
             nr[r] = make_float4(0.f, 0.f, 0.f, 0.f); col[r] = 0; it[r] = 0.f;
             if (moving) { nr[r] = set.norm_rad[kc]; col[r] = set.color[kc]; it[r] = set.init_time[kc]; }
         }
-        uint64_t c = 0, d = 0, z = 0, valid = 0;
+        uint64_t c = 0, d = 0, z = 0, valid = 0, beyond = 0;   // beyond: bits of slots >= N (free slots count as alive)
         if (threadIdx.x < TILE_WORDS) {
             const uint32_t word = tile * TILE_WORDS + threadIdx.x;
             const uint64_t base = (uint64_t)word * 64u;
@@ -655,6 +825,8 @@ __global__ __launch_bounds__(256) void k_compact(Model M, DevState *__restrict__
                 c = cm[word]; d = dm[word]; z = zm[word];
                 const uint64_t rem = (uint64_t)N - base;
                 valid = rem >= 64 ? ~0ull : ((1ull << rem) - 1ull);
+                beyond = ~valid;
+                if (had_dead) valid &= alive[word];
             }
             s_cpop[threadIdx.x] = (uint32_t)__popcll(c);
         }
@@ -669,6 +841,7 @@ __global__ __launch_bounds__(256) void k_compact(Model M, DevState *__restrict__
             const uint64_t keep = ~(z | (ce & d)) & valid;
             s_ceff[threadIdx.x] = ce;
             s_keep[threadIdx.x] = keep;
+            if (!compacting && keep != valid) alive[tile * TILE_WORDS + threadIdx.x] = keep | beyond;   // the dead keep their slots
         }
         __syncthreads();
         if (threadIdx.x <= TILE_WORDS) {
@@ -678,12 +851,14 @@ __global__ __launch_bounds__(256) void k_compact(Model M, DevState *__restrict__
         }
         __syncthreads();
         const uint32_t kcount = s_kpre[TILE_WORDS];
+        if (!compacting && threadIdx.x == 0) tile_dead[tile] = min((uint32_t)TILE, N - tile * TILE) - kcount;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int w = r * 4 + wave;
             const uint64_t keepw = s_keep[w];
             kept[r] = (keepw >> lane) & 1ull;
-            nid[r] = base_id + s_kpre[w] + (uint32_t)__popcll(keepw & ((1ull << lane) - 1ull));
+            nid[r] = compacting ? base_id + s_kpre[w] + (uint32_t)__popcll(keepw & ((1ull << lane) - 1ull))
+                                : (tile * TILE_WORDS + w) * 64u + lane;
             if (kept[r] && ((s_ceff[w] >> lane) & 1ull)) {
                 v[r].w -= 1.0f;                           // conflict.vert:72
                 if (!moving) set.pos_conf[(tile * TILE_WORDS + w) * 64u + lane].w = v[r].w;
@@ -848,7 +1023,7 @@ __device__ __forceinline__ void associate_pixel(int q, const SurfelSet &cur, con
                                                 const uint64_t *__restrict__ keyT, const float *__restrict__ xs,
                                                 const float *__restrict__ ys, const uint32_t *__restrict__ gseg_base,
                                                 const uint32_t *__restrict__ seg_lstart, LocalSurfel &L, bool &is_valid,
-                                                bool &is_fused, uint32_t *__restrict__ tb)
+                                                bool &is_fused, uint32_t *__restrict__ tb, uint32_t first_live)
 {
     is_valid = false;
     is_fused = false;
@@ -857,8 +1032,9 @@ __device__ __forceinline__ void associate_pixel(int q, const SurfelSet &cur, con
         const uint64_t key = keyT[q];
         const int32_t gid = (int32_t)(uint32_t)(key & 0xFFFFFFFFull);
         uint32_t id = 0;
-        // data.vert:142 on the GLOBAL id; only the rank that owns the winner tries to fuse it
-        if (!fp.init_mode && key != KEY_EMPTY && gid > 0 &&
+        // data.vert:142 "id > 0" on the GLOBAL id (single GPU: the slot of the first live surfel is id 0);
+        // only the rank that owns the winner tries to fuse it
+        if (!fp.init_mode && key != KEY_EMPTY && (fp.world > 1 ? gid > 0 : (uint32_t)gid != first_live) &&
             global_to_local((uint32_t)gid, gseg_base, fp.n_gseg, seg_lstart, fp.rank, fp.world, &id)) {
             const float4 pc = cur.pos_conf[id];
             const uint32_t col = cur.color[id];
@@ -955,7 +1131,7 @@ __global__ __launch_bounds__(PIX_BLOCK) void k_associate(Model M, const DevState
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     bool is_valid, is_fused;
     LocalSurfel L;
-    associate_pixel(q, cur, fp, depthT, rgbsT, keyT, xs, ys, gseg_base, seg_lstart, L, is_valid, is_fused, tb);
+    associate_pixel(q, cur, fp, depthT, rgbsT, keyT, xs, ys, gseg_base, seg_lstart, L, is_valid, is_fused, tb, st->first_live);
     // two ballot words per wave: candidate pixels, and pixels fused by THIS rank (disjoint across ranks,
     // so a sum-reduction of the words over the ranks is their union)
     const uint64_t vw = __ballot(is_valid), fw = __ballot(is_fused);
@@ -994,19 +1170,22 @@ __global__ __launch_bounds__(PIX_BLOCK) void k_associate_append(Model M, DevStat
                                                                 const float *__restrict__ xs, const float *__restrict__ ys,
                                                                 unsigned long long *__restrict__ desc, uint32_t epoch, int nblocks,
                                                                 FrameLog *__restrict__ log, uint32_t *__restrict__ tb,
-                                                                const uint2 *__restrict__ compact_part, uint32_t n_compact_part)
+                                                                const uint2 *__restrict__ compact_part, uint32_t n_compact_part,
+                                                                uint64_t *__restrict__ alive, uint32_t *__restrict__ tile_dead)
 {
     __shared__ uint64_t s_nw[4];
     __shared__ uint32_t s_f[4];
     __shared__ uint32_t s_excl[2];
     const SurfelSet cur = M.s[st->cur];
-    const uint32_t offset = st->offset;
+    const uint32_t offset = st->offset, first_live = st->first_live;
+    const uint32_t garbage = st->garbage, garbage_prev = st->garbage_prev, n_slots = st->cull_n;
+    post_compact_fill(st, alive, tile_dead, blockIdx.x * PIX_BLOCK + threadIdx.x, gridDim.x * PIX_BLOCK);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int b = blockIdx.x; b < nblocks; b += gridDim.x) {
         const int q = b * PIX_BLOCK + threadIdx.x;
         bool is_valid, is_fused;
         LocalSurfel L;
-        associate_pixel(q, cur, fp, depthT, rgbsT, keyT, xs, ys, nullptr, nullptr, L, is_valid, is_fused, tb);
+        associate_pixel(q, cur, fp, depthT, rgbsT, keyT, xs, ys, nullptr, nullptr, L, is_valid, is_fused, tb, first_live);
         const bool is_new = is_valid && !is_fused;
         const uint64_t nw = __ballot(is_new), fw = __ballot(is_fused);
         if (lane == 0) { s_nw[wave] = nw; s_f[wave] = (uint32_t)__popcll(fw); }
@@ -1080,10 +1259,10 @@ __global__ __launch_bounds__(PIX_BLOCK) void k_associate_append(Model M, DevStat
             }
             if (fp.log_frame && log) {
                 FrameLog e;
-                e.tick = (uint32_t)fp.time; e.n_before = st->cull_n; e.n_after_cull = offset; e.n_kill = st->n_kill;
+                e.tick = (uint32_t)fp.time; e.n_before = n_slots - garbage_prev; e.n_after_cull = offset - garbage; e.n_kill = st->n_kill;
                 e.conflict_count = st->conflict_count; e.visible_count = st->visible_count;
                 e.fused_count = ftot; e.unstable_count = ntot; e.n_static = st->n_static;
-            e.n_conf_skipped = st->n_conf_skipped; e.n_splat_skipped = st->n_splat_skipped; e.pad = 0;
+            e.n_conf_skipped = st->n_conf_skipped; e.n_splat_skipped = st->n_splat_skipped; e.n_slots = n_slots;
             st->n_conf_skipped = 0;
                 log[st->frames_logged % FRAME_LOG_LEN] = e;
                 st->frames_logged = st->frames_logged + 1;
@@ -1155,7 +1334,7 @@ __global__ __launch_bounds__(1024) void k_scan_new(DevState *__restrict__ st, Fr
             e.tick = (uint32_t)fp.time; e.n_before = st->cull_n; e.n_after_cull = st->offset; e.n_kill = st->n_kill;
             e.conflict_count = st->conflict_count; e.visible_count = st->visible_count;
             e.fused_count = ftot; e.unstable_count = ntot; e.n_static = st->n_static;
-            e.n_conf_skipped = st->n_conf_skipped; e.n_splat_skipped = st->n_splat_skipped; e.pad = 0;
+            e.n_conf_skipped = st->n_conf_skipped; e.n_splat_skipped = st->n_splat_skipped; e.n_slots = st->cull_n;
             st->n_conf_skipped = 0;
             log[st->frames_logged % FRAME_LOG_LEN] = e;
             st->frames_logged = st->frames_logged + 1;
@@ -1201,12 +1380,15 @@ __global__ __launch_bounds__(PIX_BLOCK) void k_append_scan(Model M, DevState *__
                                                            const uint64_t *__restrict__ fusedmask,
                                                            const uint2 *__restrict__ blk_cnt, FrameLog *__restrict__ log,
                                                            uint32_t *__restrict__ tb, const uint2 *__restrict__ compact_part,
-                                                           uint32_t n_compact_part)
+                                                           uint32_t n_compact_part, uint64_t *__restrict__ alive,
+                                                           uint32_t *__restrict__ tile_dead)
 {
     __shared__ uint32_t s_red[2][4];
     __shared__ uint32_t s_cp[2][4];
     const SurfelSet cur = M.s[st->cur];
     const uint32_t offset = st->offset;
+    const uint32_t garbage = st->garbage, garbage_prev = st->garbage_prev, n_slots = st->cull_n;
+    post_compact_fill(st, alive, tile_dead, blockIdx.x * PIX_BLOCK + threadIdx.x, gridDim.x * PIX_BLOCK);
     const int q = blockIdx.x * PIX_BLOCK + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool last = blockIdx.x == gridDim.x - 1;
@@ -1251,10 +1433,10 @@ __global__ __launch_bounds__(PIX_BLOCK) void k_append_scan(Model M, DevState *__
         }
         if (fp.log_frame && log) {
             FrameLog e;
-            e.tick = (uint32_t)fp.time; e.n_before = st->cull_n; e.n_after_cull = offset; e.n_kill = st->n_kill;
+            e.tick = (uint32_t)fp.time; e.n_before = n_slots - garbage_prev; e.n_after_cull = offset - garbage; e.n_kill = st->n_kill;
             e.conflict_count = st->conflict_count; e.visible_count = st->visible_count;
             e.fused_count = ftot; e.unstable_count = ntot; e.n_static = st->n_static;
-            e.n_conf_skipped = st->n_conf_skipped; e.n_splat_skipped = st->n_splat_skipped; e.pad = 0;
+            e.n_conf_skipped = st->n_conf_skipped; e.n_splat_skipped = st->n_splat_skipped; e.n_slots = n_slots;
             st->n_conf_skipped = 0;
             log[st->frames_logged % FRAME_LOG_LEN] = e;
             st->frames_logged = st->frames_logged + 1;

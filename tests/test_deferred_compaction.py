@@ -1,0 +1,161 @@
+"""Deferred compaction (DESIGN.md "Deferred compaction"): culled surfels keep their slots, marked dead, until
+more than `compact_garbage_pct` % of the slots are dead; only then does a cull move the survivors.  The stored
+model, every counter and the index map must not depend on when the compaction happens: all variants are compared
+with the CPU oracle (which compacts at every cull like the reference, src/GlobalModel.cpp:517-579) bit for bit."""
+import math
+
+import numpy as np
+import pytest
+
+from backends import assert_models_equal, make
+from surfelmapping_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+
+SMALL = dict(width=320, height=120, fx=180.0, fy=180.0, cx=159.5, cy=59.5)
+IDENT = np.eye(4, dtype=np.float32).T.reshape(16).copy()
+COUNT_KEYS = ("count", "offset", "data_count", "conflict_count", "unstable_count", "fused_count", "visible_count", "tick")
+
+
+def pair(cam, **over):
+    args = (cam["width"], cam["height"], cam["fx"], cam["fy"], cam["cx"], cam["cy"])
+    over.setdefault("preprocess", 0)
+    return make("oracle", *args, **over), make("hip", *args, **over)
+
+
+def same_counts(o, h, what):
+    co, ch = o.counts(), h.counts()
+    assert {k: co[k] for k in COUNT_KEYS} == {k: ch[k] for k in COUNT_KEYS}, what
+
+
+def wavy(n):
+    return [synth.pose_matrix(0.15 * math.sin(0.7 * k), 0.0, 0.35 * k, 0.25 * math.sin(0.5 * k)) for k in range(n)]
+
+
+@pytest.mark.parametrize("pct", [0, 12, 25, 60])
+def test_any_compaction_schedule_gives_the_oracle_model(pct):
+    seq = synth.make_sequence(SMALL, wavy(36), seed=21, noise_mm=6.0)
+    o, h = pair(SMALL, stereo_border=20.0, max_sqrt_vertices=700, compact_garbage_pct=pct)
+    for k, fr in enumerate(seq):
+        o.process_frame(*fr); h.process_frame(*fr)
+        same_counts(o, h, f"pct={pct} frame {k}")          # counters never include dead slots
+    log = h.read_frame_log(64)
+    dead_carried = log["n_slots"].astype(np.int64) - log["n_before"].astype(np.int64)
+    assert log["n_kill"].sum() > 2000, "the sequence must actually cull"
+    if pct == 0:
+        assert dead_carried.max() == 0                     # compacts at every cull
+    else:
+        assert dead_carried.max() > 0                      # dead slots were carried over frames ...
+    if pct in (12, 25):
+        again = np.nonzero(dead_carried > 0)[0]
+        assert (dead_carried[again[0]:] == 0).any(), dead_carried      # ... and squeezed out by a later cull
+    if pct == 60:
+        assert dead_carried[-1] > 0                        # still dead slots in the model when it is downloaded
+    assert_models_equal(o.download_model(), h.download_model(), f"pct={pct}")
+    same_counts(o, h, "after the download's compaction")
+    # and the run continues on the compacted model
+    for fr in synth.make_sequence(SMALL, wavy(40)[36:], seed=22, noise_mm=6.0):
+        o.process_frame(*fr); h.process_frame(*fr)
+    assert_models_equal(o.download_model(), h.download_model(), f"pct={pct} continued")
+
+
+def test_index_map_ids_are_positions_among_live_surfels():
+    seq = synth.make_sequence(SMALL, wavy(14), seed=23, noise_mm=6.0)
+    o, h = pair(SMALL, stereo_border=20.0, max_sqrt_vertices=700, compact_garbage_pct=60)
+    for fr in seq:
+        o.process_frame(*fr); h.process_frame(*fr)
+    log = h.read_frame_log(4)
+    assert log["n_slots"][-1] > log["n_before"][-1]        # dead slots present: slot != id
+    io, ih = o.download_index_map(), h.download_index_map()
+    np.testing.assert_array_equal(io[0], ih[0])
+    # attributes: the product reads them from the model as it is now, the reference's textures date from the splat,
+    # so they agree wherever this frame's fusion did not touch the surfel
+    untouched = ih[2][..., 3] != float(h.counts()["tick"] - 1)
+    for a, b, name in zip(io[1:], ih[1:], ("vertConf", "colorTime", "normRad")):
+        np.testing.assert_array_equal(a.view(np.uint32)[untouched], b.view(np.uint32)[untouched], err_msg=name)
+    assert (io[0] > 0).sum() > 1000 and untouched.sum() > 1000
+    assert_models_equal(o.download_model(), h.download_model(), "after index-map download")
+
+
+def test_clean_points_and_reset_with_dead_slots():
+    seq = synth.make_sequence(SMALL, wavy(16), seed=24, noise_mm=6.0)
+    o, h = pair(SMALL, stereo_border=20.0, max_sqrt_vertices=700, compact_garbage_pct=60)
+    for fr in seq[:8]:
+        o.process_frame(*fr); h.process_frame(*fr)
+    rgb, d, s, p = seq[5]
+    o.clean_points(d, s, p); h.clean_points(d, s, p)
+    co, ch = o.counts(), h.counts()
+    assert co["count"] == ch["count"] and co["conflict_count"] == ch["conflict_count"]
+    for fr in seq[8:12]:
+        o.process_frame(*fr); h.process_frame(*fr)
+        same_counts(o, h, "after cleanPoints")
+    assert_models_equal(o.download_model(), h.download_model(), "cleanPoints")
+    for fr in seq[12:14]:
+        o.process_frame(*fr); h.process_frame(*fr)
+    o.reset(); h.reset()
+    for fr in seq[14:]:
+        o.process_frame(*fr); h.process_frame(*fr)
+        same_counts(o, h, "after reset")
+    a, b = o.download_model(), h.download_model()
+    assert a.shape == b.shape
+    ok = (a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))     # raw-cloud normals: NaN payloads differ
+    assert ok.all()
+
+
+def test_capacity_pressure_forces_compaction():
+    """Dead slots must never make a frame fail that fits once they are squeezed out (and vice versa)."""
+    seq = synth.make_sequence(SMALL, wavy(30), seed=25, noise_mm=6.0)
+    o, h = pair(SMALL, stereo_border=20.0, max_sqrt_vertices=260, compact_garbage_pct=60)    # 67600 slots, P = 38400
+    rcs = []
+    for k, fr in enumerate(seq):
+        ro = o.process_frame(*fr, allow=(0, -2)); rh = h.process_frame(*fr, allow=(0, -2))
+        assert ro == rh, f"frame {k}"
+        rcs.append(rh)
+        same_counts(o, h, f"frame {k}")
+    assert o.counts()["count"] + 38400 > 260 * 260          # the pressure rule was in force
+    assert_models_equal(o.download_model(), h.download_model(), "capacity pressure")
+
+
+def test_conflict_cap_and_id_zero_rule_with_dead_slots():
+    """More conflicts than pixels (only the first W*H in surfel order count) while slots are dead,
+    and the surfel the reference calls id 0 (never associated, never conflicting) is no longer in slot 0."""
+    cam = dict(width=48, height=32, fx=40.0, fy=40.0, cx=23.5, cy=15.5)
+    o, h = pair(cam, stereo_border=0.0, conflict_cap=1, max_sqrt_vertices=200, compact_garbage_pct=60)
+    rng = np.random.default_rng(7)
+    n = 20000
+    m = synth.seeded_model(n, tick=1, seed=9)
+    m[:, 0] = rng.uniform(-1.5, 1.5, n)
+    m[:, 1] = rng.uniform(-1.0, 1.0, n)
+    m[:, 2] = rng.uniform(3.0, 6.0, n)
+    m[:, 3] = rng.uniform(0.5, 3.5, n)
+    m[::7, 3] = 0.0                      # dead-already surfels, slot 0 among them
+    o.upload_model(m); h.upload_model(m)
+    rgb = np.zeros((32, 48, 3), np.uint8)
+    sem = np.zeros((32, 48), np.uint8)
+    far = np.full((32, 48), 20000, np.uint16)      # everything measured farther -> conflicts
+    near = np.full((32, 48), 4500, np.uint16)
+    o.process_frame(rgb, far, sem, IDENT); h.process_frame(rgb, far, sem, IDENT)      # reference frame only
+    for k, d in enumerate([far, near, far, near, far]):
+        o.process_frame(rgb, d, sem, IDENT); h.process_frame(rgb, d, sem, IDENT)
+        same_counts(o, h, f"frame {k}")
+    log = h.read_frame_log(8)
+    assert log["conflict_count"].max() == 48 * 32 and (log["n_slots"] > log["n_before"]).any()
+    assert_models_equal(o.download_model(), h.download_model(), "cap + dead slots")
+
+
+def test_async_frames_with_dead_slots_match_oracle():
+    seq = synth.make_sequence(SMALL, wavy(60), seed=26, noise_mm=6.0)
+    o, h = pair(SMALL, stereo_border=20.0, max_sqrt_vertices=900)          # default threshold
+    P = SMALL["width"] * SMALL["height"]
+    bufs = []
+    for rgb, d, s, p in seq:
+        dr, dd, ds = h.device_alloc(P * 3), h.device_alloc(P * 2), h.device_alloc(P)
+        h.device_upload(dr, rgb); h.device_upload(dd, d); h.device_upload(ds, s)
+        bufs.append((dr, dd, ds, p))
+    for fr in seq:
+        o.process_frame(*fr)
+    for dr, dd, ds, p in bufs:
+        h.process_frame_device(dr, dd, ds, p)
+    h.sync()
+    same_counts(o, h, "async")
+    assert_models_equal(o.download_model(), h.download_model(), "async")
