@@ -125,6 +125,7 @@ struct sm_ctx {
     // column-major frame images
     float *d_depthT = nullptr, *d_filteredT = nullptr, *d_lastT = nullptr;
     uint32_t *d_rgbsT = nullptr;
+    uint2 *d_dcT = nullptr;            // (depth bits, rgbs) of the frame the conflict test sees
     uint64_t *d_keyT = nullptr;
     // row-major staging of the caller's inputs
     uint8_t *d_rgb = nullptr, *d_sem = nullptr;
@@ -295,7 +296,7 @@ int launch_prep(sm_ctx *s, const uint8_t *rgb, const uint16_t *raw, const uint8_
 {
     const int tiles = ((s->W + 31) / 32) * ((s->H + 31) / 32);
     hipLaunchKernelGGL(k_prep, dim3(tiles), dim3(1024), 0, s->stream, rgb, raw, sem, dm, s->d_depthT, s->d_rgbsT,
-                       clear_keys ? s->d_keyT : nullptr, fp);
+                       clear_keys ? s->d_keyT : nullptr, fp, s->d_dcT);
     HIPCK(hipGetLastError());
     return SM_OK;
 }
@@ -309,8 +310,8 @@ int mark(sm_ctx *s, int which, bool timed)
 int launch_conflict(sm_ctx *s, const FrameParams &fp, bool timed = false)
 {
     s->n_conf_part = (uint32_t)grid_surfels(s);
-    hipLaunchKernelGGL(k_conflict, dim3(s->n_conf_part), dim3(256), 0, s->stream, s->M, s->d_state, fp, s->d_depthT,
-                       s->d_rgbsT, s->d_cm, s->d_dm, s->d_zm, s->d_tile_cnt, s->d_tb, s->d_tile_flags, s->d_conf_part, s->d_alive);
+    hipLaunchKernelGGL(k_conflict, dim3(s->n_conf_part), dim3(256), 0, s->stream, s->M, s->d_state, fp, s->d_dcT,
+                       s->d_cm, s->d_dm, s->d_zm, s->d_tile_cnt, s->d_tb, s->d_tile_flags, s->d_conf_part, s->d_alive);
     HIPCK(hipGetLastError());
     if (mark(s, 2, timed)) return SM_E_HIP;
     if (fp.compact_pct == 0u) {
@@ -500,7 +501,7 @@ int begin_frame(sm_ctx *s, const uint8_t *d_rgb, const uint16_t *d_raw, const ui
         invert4(s->last_pose, linv);
         mul4(linv, s->curr_pose, t_c2l.m);
         hipLaunchKernelGGL(k_remove_movings, dim3(pblocks), dim3(256), 0, s->stream, s->d_filteredT, s->d_rgbsT, s->d_lastT,
-                           s->d_depthT, fp, t_c2l);
+                           s->d_depthT, fp, t_c2l, s->d_dcT);
         HIPCK(hipGetLastError());
     }
     if ((rc = mark(s, 1, fusing))) return rc;
@@ -663,7 +664,8 @@ sm_ctx *sm_create(const sm_config *c)
     ok = ok && dalloc(&s->d_state, 1) == SM_OK && dalloc(&s->d_log, FRAME_LOG_LEN) == SM_OK;
     ok = ok && hipHostMalloc((void **)&s->h_state, sizeof(DevState), hipHostMallocDefault) == hipSuccess;
     ok = ok && dalloc(&s->d_depthT, P) == SM_OK && dalloc(&s->d_filteredT, P) == SM_OK && dalloc(&s->d_lastT, P) == SM_OK;
-    ok = ok && dalloc(&s->d_rgbsT, P) == SM_OK && dalloc(&s->d_keyT, P) == SM_OK;
+    ok = ok && dalloc(&s->d_rgbsT, P) == SM_OK && dalloc(&s->d_keyT, P) == SM_OK && dalloc(&s->d_dcT, P) == SM_OK &&
+         hipMemset(s->d_dcT, 0, P * 8) == hipSuccess;
     ok = ok && dalloc(&s->d_rgb, P * 3) == SM_OK && dalloc(&s->d_sem, P) == SM_OK && dalloc(&s->d_depth_raw, P) == SM_OK;
     ok = ok && dalloc(&s->d_depth_f32, P) == SM_OK;
     ok = ok && dalloc(&s->d_xs, (size_t)s->W * 2) == SM_OK && dalloc(&s->d_ys, (size_t)s->H * 2) == SM_OK && dalloc(&s->d_wtab, (size_t)169) == SM_OK;
@@ -776,7 +778,7 @@ void sm_destroy(sm_ctx *s)
     (void)hipFree(s->d_state); (void)hipFree(s->d_log);
     if (s->h_state) (void)hipHostFree(s->h_state);
     (void)hipFree(s->d_depthT); (void)hipFree(s->d_filteredT); (void)hipFree(s->d_lastT);
-    (void)hipFree(s->d_rgbsT); (void)hipFree(s->d_keyT);
+    (void)hipFree(s->d_rgbsT); (void)hipFree(s->d_keyT); (void)hipFree(s->d_dcT);
     (void)hipFree(s->d_rgb); (void)hipFree(s->d_sem); (void)hipFree(s->d_depth_raw); (void)hipFree(s->d_depth_f32);
     (void)hipFree(s->d_xs); (void)hipFree(s->d_ys); (void)hipFree(s->d_wtab);
     (void)hipFree(s->d_cm); (void)hipFree(s->d_dm); (void)hipFree(s->d_zm); (void)hipFree(s->d_alive); (void)hipFree(s->d_tile_dead);
@@ -1039,7 +1041,7 @@ int sm_set_frame(sm_ctx *s, const uint8_t *rgb, const float *depth_metric, const
     const int tiles = ((s->W + 31) / 32) * ((s->H + 31) / 32);
     hipLaunchKernelGGL(k_prep, dim3(tiles), dim3(1024), 0, s->stream, s->d_rgb, (const uint16_t *)nullptr, s->d_sem,
                        depth_metric ? s->d_depth_f32 : nullptr, depth_metric ? s->d_depthT : nullptr, s->d_rgbsT,
-                       (uint64_t *)nullptr, fp);
+                       (uint64_t *)nullptr, fp, s->d_dcT);
     HIPCK(hipGetLastError());
     HIPCK(hipStreamSynchronize(s->stream));
     return SM_OK;

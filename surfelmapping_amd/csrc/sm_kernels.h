@@ -64,7 +64,8 @@ __global__ __launch_bounds__(1024) void k_prep(const uint8_t *__restrict__ rgb,
                                                const uint8_t *__restrict__ sem,
                                                const float *__restrict__ depth_f32,  // optional: metric depth given directly
                                                float *__restrict__ depthT, uint32_t *__restrict__ rgbsT,
-                                               uint64_t *__restrict__ keyT, FrameParams fp)
+                                               uint64_t *__restrict__ keyT, FrameParams fp,
+                                               uint2 *__restrict__ dcT /* (depth bits, rgbs) per pixel: one 8-byte gather for the conflict test */)
 {
     __shared__ float s_d[32][33];
     __shared__ uint32_t s_c[32][33];
@@ -103,6 +104,8 @@ __global__ __launch_bounds__(1024) void k_prep(const uint8_t *__restrict__ rgb,
             const size_t q = (size_t)i * H + j;
             if (depthT) depthT[q] = s_d[tx][ty];
             if (rgbsT) rgbsT[q] = s_c[tx][ty];
+            if (depthT) dcT[q] = make_uint2(__float_as_uint(s_d[tx][ty]), s_c[tx][ty]);
+            else reinterpret_cast<uint32_t *>(dcT)[2 * q + 1] = s_c[tx][ty];       // depth plane kept
             if (keyT) keyT[q] = KEY_EMPTY;
         }
     }
@@ -209,7 +212,7 @@ struct Mat4 { float m[16]; };
 
 __global__ __launch_bounds__(256) void k_remove_movings(const float *__restrict__ inT, const uint32_t *__restrict__ rgbsT,
                                                         const float *__restrict__ lastT, float *__restrict__ outT,
-                                                        FrameParams fp, Mat4 t_c2l)
+                                                        FrameParams fp, Mat4 t_c2l, uint2 *__restrict__ dcT)
 {
     const int q = blockIdx.x * 256 + threadIdx.x;
     if (q >= fp.P) return;
@@ -232,6 +235,7 @@ __global__ __launch_bounds__(256) void k_remove_movings(const float *__restrict_
         }
     }
     outT[q] = r;
+    reinterpret_cast<uint32_t *>(dcT)[2 * (size_t)q] = __float_as_uint(r);     // the conflict test's packed copy
 }
 
 // column-major -> row-major read-back helper (tests / GUI textures)
@@ -256,9 +260,11 @@ __global__ void k_fill_keys(uint64_t *keyT, int P)
 //   zm  dead already: !(conf > 0)      (back_map.geom:17 culls on conf <= 0 / NaN)
 // plus per-tile counts (nconf, nkill = popc(zm | cm&dm), nzero).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_conflict(Model M, const DevState *__restrict__ st, FrameParams fp,
-                                                  const float *__restrict__ depthT,
-                                                  const uint32_t *__restrict__ rgbsT,
+#ifndef SM_CONFLICT_WAVES
+#define SM_CONFLICT_WAVES 5     // 96 VGPRs, no spills: 5 waves/SIMD measured best (6 and 8 spill and are slower)
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SM_CONFLICT_WAVES, 8))) void k_conflict(Model M, const DevState *__restrict__ st, FrameParams fp,
+                                                  const uint2 *__restrict__ dcT /* (depth bits, sem<<24|rgb) per pixel */,
                                                   uint64_t *__restrict__ cm, uint64_t *__restrict__ dm,
                                                   uint64_t *__restrict__ zm, uint32_t *__restrict__ tile_cnt,
                                                   const uint32_t *__restrict__ tb, uint8_t *__restrict__ tile_flags,
@@ -342,8 +348,9 @@ __global__ __launch_bounds__(256) void k_conflict(Model M, const DevState *__res
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {                 // gathers, unconditional (pixel 0 for out-of-view lanes)
-            dep[r] = depthT[qq[r]];
-            cls[r] = rgbsT[qq[r]] >> 24;
+            const uint2 g = dcT[qq[r]];               // depth and class in one 8-byte access
+            dep[r] = __uint_as_float(g.x);
+            cls[r] = g.y >> 24;
         }
         // phase 4: conflict rule + ballots
 #pragma unroll
