@@ -1399,6 +1399,7 @@ __global__ __launch_bounds__(PIX_BLOCK) void k_append_scan(Model M, DevState *__
     const int q = blockIdx.x * PIX_BLOCK + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool last = blockIdx.x == gridDim.x - 1;
+    if (!last && blk_cnt[blockIdx.x].x == 0u) return;             // no new surfel in this block's pixels (sky, border)
     const int upto = last ? (int)gridDim.x : (int)blockIdx.x;     // the last block needs the totals
     uint32_t pn = 0, pf = 0, tn = 0;                              // prefix of new; totals (last block only)
     for (int b = threadIdx.x; b < upto; b += PIX_BLOCK) {
