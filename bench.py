@@ -136,8 +136,8 @@ def main():
                     help="N>1: 'rig' = one camera stream per GPU + all-gather into one GlobalModel (weak scaling); "
                          "'sharded' = ONE stream split over the GPUs, bit-identical to 1 GPU (strong scaling)")
     ap.add_argument("--force-dist", action="store_true", help="rehearse the multi-GPU code path with WORLD_SIZE=1")
-    ap.add_argument("--compact-pct", type=int, default=12,
-                    help="deferred compaction: culled surfels keep their slots until this %% of the slots is dead (0: compact every frame)")
+    ap.add_argument("--compact-period", type=int, default=8,
+                    help="deferred compaction: culled surfels keep their slots, every Nth cull squeezes them out (1: every frame)")
     ap.add_argument("--sync-every-frame", action="store_true",
                     help="reference semantics: host waits for the counters after every frame")
     args = ap.parse_args()
@@ -177,7 +177,7 @@ def main():
     mk = lambda timing: capi.SurfelMap(capi.make_config(**cam, preprocess=args.preprocess, device=local_rank,
                                                         enable_timing=timing, conflict_cap=0 if hd else 1,
                                                         max_sqrt_vertices=10000 if hd else 5000,
-                                                        compact_garbage_pct=args.compact_pct))
+                                                        compact_period=args.compact_period))
     sm = mk(0)                                    # raises without a GPU: no CPU fallback
     # second context: the same frames again with HIP events between the kernels (the events cost
     # ~25 us per frame, so they stay out of the run that produces `value`)
@@ -331,9 +331,9 @@ def main():
                    "frames": f"{Wm}..{Wm + K - 1}", "multi_gpu": (f"{world}-camera rig, one stream per GPU, RCCL all-gather into a single GlobalModel of "
                                  f"{global_count} surfels after the timed frames ({gather_ms:.1f} ms, not in `value`)") if dist else "single stream",
                    "host_sync": "per frame" if args.sync_every_frame else "none inside the timed region",
-                   "compaction": (f"deferred: dead slots squeezed out once they exceed {args.compact_pct}% "
-                                  f"({int((log['n_static'] < log['n_slots']).sum()) if len(log) else 0} of {K} timed frames compacted)")
-                                 if args.compact_pct else "every frame",
+                   "compaction": (f"deferred: culled surfels keep their slots, every {args.compact_period}th cull compacts "
+                                  f"({int((log['n_static'] < log['n_slots']).sum()) if len(log) else 0} of {K} timed frames moved surfels)")
+                                 if args.compact_period > 1 else "every frame",
                    "surfels_start": int(log["n_before"][0]) if len(log) else 0, "surfels_end": int(counts["count"])},
         "surfels_fused_per_sec": fused_total / elapsed,
         "roofline": roofline,

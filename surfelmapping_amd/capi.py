@@ -38,7 +38,7 @@ class SmConfig(C.Structure):
         ("max_sqrt_vertices", C.c_int32), ("time_delta", C.c_int32),
         ("stereo_border", C.c_float), ("preprocess", C.c_int32), ("conflict_cap", C.c_int32),
         ("device", C.c_int32), ("enable_timing", C.c_int32), ("disable_tile_bounds", C.c_int32),
-        ("compact_garbage_pct", C.c_int32),
+        ("compact_period", C.c_int32),
     ]
 
 

@@ -140,6 +140,9 @@ struct sm_ctx {
     uint32_t *d_tile_dead = nullptr;   // dead slots per tile
     size_t alive_words = 0, dead_tiles = 0;
     bool maybe_garbage = false;        // a deferred-compaction cull ran since the last physical compaction
+    int culls_since_compact = 0;       // deferred-compaction schedule (host side: it picks the kernels)
+    uint32_t frames_enq = 0;           // appends enqueued so far (compared with the tag of *h_stat)
+    unsigned long long *h_stat = nullptr, *d_stat = nullptr;   // pinned, device-written: frames<<32 | occupied slots
     uint32_t *d_tb = nullptr;          // per-tile bounds (8 words per tile)
     uint8_t *d_tile_flags = nullptr;   // per-tile skip flags of the current frame
     uint32_t *d_conf_part = nullptr;   // per-workgroup partial counters (instead of same-address atomics)
@@ -241,7 +244,7 @@ FrameParams make_params(const sm_ctx *s, const float *pose)
     fp.inv_fx_fb = 1.0f / c.fx;
     fp.inv_fy_fb = 1.0f / c.fy;
     fp.use_bounds = c.disable_tile_bounds ? 0 : 1;
-    fp.compact_pct = 0;                     // per-pass entry points and sharded frames compact at every cull
+    fp.compact_now = 1;                     // per-pass entry points and sharded frames compact at every cull
     fp.maintenance = 0;
     return fp;
 }
@@ -252,10 +255,13 @@ int grid_surfels(const sm_ctx *s)
     return (int)std::min<uint64_t>(std::max<uint64_t>(tiles, 1), MAX_GRID);
 }
 
+void publish_stat(sm_ctx *s);
+
 int push_state(sm_ctx *s)
 {
     HIPCK(hipMemcpyAsync(s->d_state, s->h_state, sizeof(DevState), hipMemcpyHostToDevice, s->stream));
     HIPCK(hipStreamSynchronize(s->stream));
+    publish_stat(s);
     return SM_OK;
 }
 
@@ -314,10 +320,9 @@ int launch_conflict(sm_ctx *s, const FrameParams &fp, bool timed = false)
                        s->d_cm, s->d_dm, s->d_zm, s->d_tile_cnt, s->d_tb, s->d_tile_flags, s->d_conf_part, s->d_alive);
     HIPCK(hipGetLastError());
     if (mark(s, 2, timed)) return SM_E_HIP;
-    if (fp.compact_pct == 0u) {
-        // every cull compacts: the survivor prefixes are always needed, scan them with one workgroup per 1024 tiles.
-        // With deferred compaction the finalize kernel gets its totals from k_conflict's partial sums and scans
-        // the tiles itself on the (few) frames that compact.
+    if (fp.compact_now) {
+        // this cull compacts: the survivor prefixes are needed, scan them with one workgroup per 1024 tiles.
+        // A cull that only marks the dead gets its totals from k_conflict's partial sums in the finalize kernel.
         const int ngroups = std::max<int>(1, (int)((((uint64_t)s->count_bound + TILE - 1) / TILE + GROUP - 1) / GROUP));
         hipLaunchKernelGGL(k_scan_cull, dim3(ngroups), dim3(1024), 0, s->stream, s->d_state, s->d_tile_cnt, s->d_tile_allow,
                            s->d_tile_keep, s->d_group_tot, s->d_tile_dead);
@@ -325,7 +330,7 @@ int launch_conflict(sm_ctx *s, const FrameParams &fp, bool timed = false)
     }
     hipLaunchKernelGGL(k_cull_finalize, dim3(1), dim3(1024), 0, s->stream, s->d_state, fp, s->d_cm, s->d_dm, s->d_zm,
                        s->d_tile_cnt, s->d_tile_allow, s->d_tile_keep, s->d_group_tot, s->d_group_base, s->d_conf_part, s->n_conf_part,
-                       s->d_alive, s->d_tile_dead);
+                       s->d_alive, s->d_tile_dead, s->d_stat);
     HIPCK(hipGetLastError());
     if (mark(s, 3, timed)) return SM_E_HIP;
     return SM_OK;
@@ -333,6 +338,20 @@ int launch_conflict(sm_ctx *s, const FrameParams &fp, bool timed = false)
 
 int launch_compact(sm_ctx *s, const FrameParams &fp, bool splat, bool timed)
 {
+    if (!fp.compact_now) {
+        // deferred compaction: the cull only marks the dead -- lean kernel, no co-residency requirement
+        const int grid = grid_surfels(s);
+        s->n_compact_part = splat ? (uint32_t)grid : 0u;
+        if (splat)
+            hipLaunchKernelGGL(k_cull_lazy<true>, dim3(grid), dim3(256), 0, s->stream, s->M, s->d_state, fp, s->d_cm, s->d_dm, s->d_zm,
+                               s->d_tile_cnt, s->d_tile_allow, s->d_keyT, s->d_tile_flags, s->d_compact_part, s->d_alive, s->d_tile_dead);
+        else
+            hipLaunchKernelGGL(k_cull_lazy<false>, dim3(grid), dim3(256), 0, s->stream, s->M, s->d_state, fp, s->d_cm, s->d_dm, s->d_zm,
+                               s->d_tile_cnt, s->d_tile_allow, s->d_keyT, s->d_tile_flags, s->d_compact_part, s->d_alive, s->d_tile_dead);
+        HIPCK(hipGetLastError());
+        if (mark(s, 4, timed)) return SM_E_HIP;
+        return SM_OK;
+    }
     const int grid = std::min(grid_surfels(s), s->compact_grid);
     const uint32_t epoch = ++s->cull_epoch;
     s->n_compact_part = splat ? (uint32_t)grid : 0u;
@@ -349,6 +368,35 @@ int launch_compact(sm_ctx *s, const FrameParams &fp, bool splat, bool timed)
     HIPCK(hipGetLastError());
     if (mark(s, 4, timed)) return SM_E_HIP;
     return SM_OK;
+}
+
+// Deferred-compaction schedule.  The HOST decides whether a cull compacts (it must launch the matching kernels, and it
+// must do so without waiting for the device): every `compact_period`-th cull, and whenever dead slots could make the
+// frame overflow the capacity (then the result would differ from the reference's).  The bound on the occupied slots
+// comes from a pinned word the device updates after every cull and append: slots then + one frame's worth of new
+// surfels for every append enqueued since.
+bool decide_compact(sm_ctx *s)
+{
+    if (s->sh_world > 1 || s->cfg.compact_period <= 1) return true;
+    const unsigned long long v = __atomic_load_n(s->h_stat, __ATOMIC_RELAXED);
+    const uint32_t fr = (uint32_t)(v >> 32), slots = (uint32_t)v;
+    uint64_t bound = s->count_bound;
+    if (s->frames_enq >= fr) bound = std::min<uint64_t>(bound, (uint64_t)slots + (uint64_t)(s->frames_enq - fr) * s->n_odd_pixels);
+    if (bound + s->n_odd_pixels > s->cap) return true;
+    return s->culls_since_compact + 1 >= s->cfg.compact_period;
+}
+
+void note_cull(sm_ctx *s, bool compacted)
+{
+    if (compacted) { s->culls_since_compact = 0; }
+    else { s->culls_since_compact++; s->maybe_garbage = true; }
+}
+
+// refresh the pinned slot statistic after the host changed the model (device idle)
+void publish_stat(sm_ctx *s)
+{
+    __atomic_store_n(s->h_stat, ((unsigned long long)s->h_state->stat_frames << 32) | (unsigned long long)s->h_state->count, __ATOMIC_RELAXED);
+    s->frames_enq = s->h_state->stat_frames;
 }
 
 // after a cull that is not followed by the append kernel (which does this itself): restore the alive mask
@@ -368,6 +416,7 @@ int ensure_compact(sm_ctx *s)
     if (s->pending_cull) { g_err = "internal: deferred compaction with a pending per-pass cull"; return SM_E_ARG; }
     FrameParams fp = make_params(s, s->curr_pose);
     fp.maintenance = 1;
+    fp.compact_now = 1;
     fp.conflict_cap = 0xFFFFFFFFu;
     const uint64_t tiles = ((uint64_t)s->count_bound + TILE - 1) / TILE + 1;
     const size_t words = std::min<size_t>(tiles * TILE_WORDS, s->alive_words);
@@ -380,7 +429,7 @@ int ensure_compact(sm_ctx *s)
                        s->d_tile_keep, s->d_group_tot, s->d_tile_dead);
     hipLaunchKernelGGL(k_cull_finalize, dim3(1), dim3(1024), 0, s->stream, s->d_state, fp, s->d_cm, s->d_dm, s->d_zm,
                        s->d_tile_cnt, s->d_tile_allow, s->d_tile_keep, s->d_group_tot, s->d_group_base, s->d_conf_part, 0u,
-                       s->d_alive, s->d_tile_dead);
+                       s->d_alive, s->d_tile_dead, s->d_stat);
     hipLaunchKernelGGL(k_remap_keys, dim3((s->P + 255) / 256), dim3(256), 0, s->stream, s->d_state, s->d_keyT, s->P, s->d_alive,
                        s->d_tile_keep, s->d_group_base);
     HIPCK(hipGetLastError());
@@ -390,6 +439,7 @@ int ensure_compact(sm_ctx *s)
     if (rc) return rc;
     if ((rc = launch_post_fill(s))) return rc;
     s->maybe_garbage = false;
+    s->culls_since_compact = 0;
     HIPCK(hipStreamSynchronize(s->stream));
     return SM_OK;
 }
@@ -447,7 +497,8 @@ int launch_associate(sm_ctx *s, const FrameParams &fp, bool timed)
         if (mark(s, 6, timed)) return SM_E_HIP;
         hipLaunchKernelGGL(k_append_scan, dim3(s->n_pix_blocks), dim3(PIX_BLOCK), 0, s->stream, s->M, s->d_state, fp, s->d_depthT,
                            s->d_rgbsT, s->d_xs, s->d_ys, s->d_validmask, s->d_fusedmask, s->d_blk_cnt, s->d_log, s->d_tb, s->d_compact_part,
-                           s->n_compact_part, s->d_alive, s->d_tile_dead);
+                           s->n_compact_part, s->d_alive, s->d_tile_dead, s->d_stat);
+        s->frames_enq++;
         HIPCK(hipGetLastError());
         if (mark(s, 7, timed)) return SM_E_HIP;
         return SM_OK;
@@ -539,8 +590,8 @@ int enqueue_frame(sm_ctx *s, const uint8_t *d_rgb, const uint16_t *d_raw, const 
     FrameParams fp;
     int rc = begin_frame(s, d_rgb, d_raw, d_sem, pose, &fp);
     if (rc <= 0) return rc;
-    fp.compact_pct = (uint32_t)s->cfg.compact_garbage_pct;
-    if (fp.compact_pct) s->maybe_garbage = true;
+    fp.compact_now = decide_compact(s) ? 1u : 0u;
+    note_cull(s, fp.compact_now != 0u);
     if ((rc = launch_conflict(s, fp, true))) return rc;    // :178-187
     if ((rc = launch_compact(s, fp, true, true))) return rc;   // :189-197 (cull + mirror + index map)
     if ((rc = launch_associate(s, fp, true))) return rc;   // :212-239
@@ -634,13 +685,13 @@ int sm_default_config(sm_config *c, int width, int height, float fx, float fy, f
     c->conflict_cap = 1;
     c->device = 0;
     c->enable_timing = 0;
-    c->compact_garbage_pct = 12;
+    c->compact_period = 8;
     return SM_OK;
 }
 
 sm_ctx *sm_create(const sm_config *c)
 {
-    if (!c || c->width <= 0 || c->height <= 0 || c->max_sqrt_vertices <= 0 || c->compact_garbage_pct < 0 || c->compact_garbage_pct > 90 ||
+    if (!c || c->width <= 0 || c->height <= 0 || c->max_sqrt_vertices <= 0 || c->compact_period < 0 ||
         (uint64_t)c->width * c->height > (1u << 30) || (uint64_t)c->max_sqrt_vertices * c->max_sqrt_vertices > 0x7FFFFFFFull) {
         g_err = "sm_create: bad config";
         return nullptr;
@@ -663,6 +714,9 @@ sm_ctx *sm_create(const sm_config *c)
     ok = ok && alloc_set(s->M.s[0], cap) == SM_OK;      // one SoA set: the compaction is in place
     ok = ok && dalloc(&s->d_state, 1) == SM_OK && dalloc(&s->d_log, FRAME_LOG_LEN) == SM_OK;
     ok = ok && hipHostMalloc((void **)&s->h_state, sizeof(DevState), hipHostMallocDefault) == hipSuccess;
+    ok = ok && hipHostMalloc((void **)&s->h_stat, 8, hipHostMallocMapped) == hipSuccess &&
+         hipHostGetDevicePointer((void **)&s->d_stat, s->h_stat, 0) == hipSuccess;
+    if (ok) *s->h_stat = 0ull;
     ok = ok && dalloc(&s->d_depthT, P) == SM_OK && dalloc(&s->d_filteredT, P) == SM_OK && dalloc(&s->d_lastT, P) == SM_OK;
     ok = ok && dalloc(&s->d_rgbsT, P) == SM_OK && dalloc(&s->d_keyT, P) == SM_OK && dalloc(&s->d_dcT, P) == SM_OK &&
          hipMemset(s->d_dcT, 0, P * 8) == hipSuccess;
@@ -777,6 +831,7 @@ void sm_destroy(sm_ctx *s)
     free_set(s->M.s[0]); free_set(s->M.s[1]);
     (void)hipFree(s->d_state); (void)hipFree(s->d_log);
     if (s->h_state) (void)hipHostFree(s->h_state);
+    if (s->h_stat) (void)hipHostFree(s->h_stat);
     (void)hipFree(s->d_depthT); (void)hipFree(s->d_filteredT); (void)hipFree(s->d_lastT);
     (void)hipFree(s->d_rgbsT); (void)hipFree(s->d_keyT); (void)hipFree(s->d_dcT);
     (void)hipFree(s->d_rgb); (void)hipFree(s->d_sem); (void)hipFree(s->d_depth_raw); (void)hipFree(s->d_depth_f32);
@@ -836,8 +891,8 @@ int sm_clean_points(sm_ctx *s, const uint16_t *depth_mm, const uint8_t *semantic
     fp.max_depth = s->cfg.far_clip - 15.0f;     // src/SurfelMapping.cpp:515
     fp.conflict_thresh = 0.1f;                  // :516
     fp.is_clean = 1;                            // :517
-    fp.compact_pct = s->sh_world > 1 ? 0u : (uint32_t)s->cfg.compact_garbage_pct;
-    if (fp.compact_pct) s->maybe_garbage = true;
+    fp.compact_now = decide_compact(s) ? 1u : 0u;
+    note_cull(s, fp.compact_now != 0u);
     if ((rc = launch_conflict(s, fp))) return rc;
     if ((rc = launch_compact(s, fp, false, false))) return rc;
     if ((rc = launch_post_fill(s))) return rc;

@@ -56,6 +56,7 @@ struct DevState {
     uint32_t garbage_prev;    // its value before the last cull
     uint32_t do_compact;      // the last cull compacts physically (otherwise it only marks the dead in `alive`)
     uint32_t cap_binds;       // the last cull had more conflicts than the conflict cap (tile_allow is in force)
+    uint32_t stat_frames;     // frames whose append has completed (tag of the host-visible slot statistic)
     uint32_t first_live;      // slot of the first live surfel = the reference's surfel id 0 (conflict.geom:15, data.vert:142)
 };
 
@@ -92,7 +93,8 @@ struct FrameParams {
     float inv_fx_fb, inv_fy_fb;   // 1.0f/fx as float division (src/FeedbackBuffer.cpp:93-96)
     int use_bounds;           // 1: whole 1024-surfel tiles are skipped when their bounding box is outside the view
     // ---- deferred compaction ----
-    uint32_t compact_pct;     // 0: every cull compacts (the reference's behaviour); else compact once dead slots exceed this % of the slots
+    uint32_t compact_now;     // 1: this cull moves the survivors (k_scan_cull + k_compact); 0: it only marks the dead (k_cull_lazy).
+                              // Decided by the host (a fixed period + a capacity bound), so that it can launch the matching kernels
     int maintenance;          // 1: compaction outside a frame (no kills): frame statistics are left alone
 };
 

@@ -472,7 +472,8 @@ __global__ __launch_bounds__(1024) void k_cull_finalize(DevState *__restrict__ s
                                                         uint32_t *__restrict__ group_keep_base,
                                                         const uint32_t *__restrict__ conf_part, uint32_t n_conf_part,
                                                         const uint64_t *__restrict__ alive,
-                                                        const uint32_t *__restrict__ tile_dead)
+                                                        const uint32_t *__restrict__ tile_dead,
+                                                        unsigned long long *__restrict__ host_stat)
 {
     __shared__ uint32_t s_scan[17];
     __shared__ uint32_t s_first, s_ft, s_fl, s_keep_first;
@@ -482,9 +483,9 @@ __global__ __launch_bounds__(1024) void k_cull_finalize(DevState *__restrict__ s
     const uint32_t ntiles = (N + TILE - 1) / TILE;
     const uint32_t ngroups = (ntiles + GROUP - 1) / GROUP;
     const uint32_t cap = fp.conflict_cap;
-    // k_scan_cull ran before this kernel only where every cull compacts; otherwise the per-tile prefixes are
-    // produced here, and only on the frames that do compact
-    const bool have_scan = fp.compact_pct == 0u || fp.maintenance != 0;
+    // k_scan_cull ran before this kernel exactly when this cull compacts (the host decides and launches accordingly);
+    // a cull that only marks the dead needs no prefixes, its totals come from k_conflict's per-workgroup sums
+    const bool have_scan = fp.compact_now != 0u || fp.maintenance != 0;
     if (threadIdx.x == 0) { s_first = 0xFFFFFFFFu; s_ft = 0xFFFFFFFFu; s_fl = 0xFFFFFFFFu; }
     if (threadIdx.x == 1023) {
         // does the surfel that is id 0 today survive this cull?  (almost always: then its slot stays "id 0")
@@ -570,29 +571,7 @@ __global__ __launch_bounds__(1024) void k_cull_finalize(DevState *__restrict__ s
     // ---- deferred compaction: mark the dead now, move the survivors only once enough slots are dead
     const uint32_t kept = ktotal;                     // live surfels after this cull
     const uint32_t g1 = N - kept;                     // dead slots if nothing moves
-    const bool compact = fp.compact_pct == 0u || fp.maintenance != 0 ||
-                         (uint64_t)g1 * 100u > (uint64_t)N * fp.compact_pct ||
-                         (g1 != 0u && (uint64_t)N + (uint64_t)fp.P > (uint64_t)fp.max_vertices);
-    if (compact && !have_scan && !cap_binds) {
-        // survivor prefixes for the compaction, 1024 tiles per round (only on the frames that compact)
-        if (threadIdx.x < ngroups) group_keep_base[threadIdx.x] = 0;
-        uint32_t carry = 0;
-        for (uint32_t base = 0; base < ntiles; base += 1024u) {
-            const uint32_t t = base + threadIdx.x;
-            uint32_t keep = 0;
-            if (t < ntiles) {
-                const uint32_t nk = tile_cnt[t * 3 + 1], td = tile_dead[t];
-                keep = min((uint32_t)TILE, N - t * TILE) - td - nk;
-                if (nk != 0u || td != 0u) atomicMin(&s_first, t);
-            }
-            uint32_t tot;
-            const uint32_t excl = block_scan_1024(keep, &tot, s_scan);
-            if (t < ntiles) tile_keep_prefix[t] = carry + excl;
-            carry += tot;
-        }
-        __syncthreads();
-        nstatic = (s_first == 0xFFFFFFFFu) ? N : min(N, s_first * (uint32_t)TILE);
-    }
+    const bool compact = have_scan;
     // slot of the first survivor (the surfel the reference addresses as id 0)
     uint32_t first_live = compact ? 0u : N;
     if (!compact && kept != 0u) {
@@ -647,6 +626,11 @@ __global__ __launch_bounds__(1024) void k_cull_finalize(DevState *__restrict__ s
             st->offset = N;
             st->garbage = g1;
         }
+        // host-visible (pinned) statistic: occupied slots, tagged with the number of completed appends, so that the host
+        // can bound the slot count of a frame it enqueues without waiting for the device
+        if (host_stat)
+            __hip_atomic_store(host_stat, ((unsigned long long)st->stat_frames << 32) | (unsigned long long)(compact ? kept : N),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -922,6 +906,96 @@ __global__ __launch_bounds__(256) void k_compact(Model M, DevState *__restrict__
         __syncthreads();
         if (threadIdx.x == 0)      // per-workgroup partials, summed by the append kernel (no same-address atomics)
             blk_part[blockIdx.x] = make_uint2(s_vis[0] + s_vis[1] + s_vis[2] + s_vis[3], skipped);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The cull of a frame that does not compact (deferred compaction): survivors keep their slots, so nothing depends
+// on other tiles or even on the other words of a tile.  Each wave settles four 64-surfel words on its own -- apply
+// the confidence decrement, clear the dead from the alive mask, splat the survivors under their slot number -- with
+// no LDS, no barriers, no hand-off, and a quarter of k_compact's registers (twice its occupancy).  The grid needs no
+// co-residency.  (Slots are ids here: the order of slots is the order of ids, which is all the key map needs.)
+// ---------------------------------------------------------------------------------------------
+template <bool SPLAT>
+__global__ __launch_bounds__(256) void k_cull_lazy(Model M, const DevState *__restrict__ st, FrameParams fp,
+                                                   const uint64_t *__restrict__ cm, const uint64_t *__restrict__ dm,
+                                                   const uint64_t *__restrict__ zm, const uint32_t *__restrict__ tile_cnt,
+                                                   const uint32_t *__restrict__ tile_allow, uint64_t *__restrict__ keyT,
+                                                   const uint8_t *__restrict__ tile_flags,
+                                                   uint2 *__restrict__ blk_part /* [grid] (visible, splat-skipped) */,
+                                                   uint64_t *__restrict__ alive, uint32_t *__restrict__ tile_dead)
+{
+    __shared__ uint32_t s_vis[4];
+    const uint32_t N = st->cull_n;
+    const SurfelSet set = M.s[st->cull_src];
+    const uint32_t ntiles = (N + TILE - 1) / TILE;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool had_dead = st->garbage_prev != 0u, cap_binds = st->cap_binds != 0u;
+    uint32_t vis = 0, skipped = 0, iter = 0;
+    uint64_t skipmask = 0;
+    uint32_t m_nconf = 0, m_nkill = 0, m_dead = 0;
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x, ++iter) {
+        if ((iter & 63u) == 0u) {                    // metadata of this workgroup's next 64 tiles, one per lane
+            const uint64_t tl = (uint64_t)tile + (uint64_t)lane * gridDim.x;
+            const bool in = tl < ntiles;
+            const uint32_t tt = in ? (uint32_t)tl : 0u;
+            skipmask = __ballot(in && (tile_flags[tt] & 2u));
+            m_nconf = tile_cnt[tt * 3]; m_nkill = tile_cnt[tt * 3 + 1];
+            m_dead = had_dead ? tile_dead[tt] : 0u;
+        }
+        const int sl = (int)(iter & 63u);
+        const uint32_t nconf = (uint32_t)__shfl((int)m_nconf, sl), nkill = (uint32_t)__shfl((int)m_nkill, sl);
+        const uint32_t tdead = (uint32_t)__shfl((int)m_dead, sl);
+        const uint32_t tn = min((uint32_t)TILE, N - tile * TILE);
+        const bool touched = nconf != 0u || nkill != 0u;                                  // workgroup-uniform
+        const bool nosplat = !SPLAT || ((skipmask >> (iter & 63u)) & 1ull);              // box outside the index map's view
+        if (SPLAT && nosplat) skipped += tn;
+        if (!touched && nosplat) continue;                                                // the bulk of the map: not even read
+        float4 pv[4];
+        float pt[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {                // unconditional, clamped: all loads of the lane in flight together
+            const uint32_t kc = min((tile * TILE_WORDS + r * 4 + wave) * 64u + lane, N - 1u);
+            pv[r] = set.pos_conf[kc];
+            pt[r] = nosplat ? 0.0f : set.time[kc];
+        }
+        const uint32_t allow = (touched && cap_binds) ? tile_allow[tile] : nconf;
+        uint32_t killed = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int w = r * 4 + wave;
+            const uint32_t word = tile * TILE_WORDS + (uint32_t)w;
+            const uint32_t k = word * 64u + lane;
+            const uint64_t base = (uint64_t)word * 64u;
+            uint64_t range = 0ull;
+            if (base < N) { const uint64_t rem = (uint64_t)N - base; range = rem >= 64 ? ~0ull : ((1ull << rem) - 1ull); }
+            const uint64_t valid = range & ((tdead != 0u) ? alive[word] : ~0ull);
+            uint64_t keep = valid, ce = 0ull;
+            if (touched) {
+                ce = cm[word];
+                if (allow != nconf) {                // the conflict cap binds inside this tile: only its first `allow` conflicts count
+                    uint32_t before = 0;
+                    for (int x = 0; x < w; ++x) before += (uint32_t)__popcll(cm[tile * TILE_WORDS + x]);
+                    ce = before >= allow ? 0ull : first_n_bits(ce, allow - before);
+                }
+                keep = ~(zm[word] | (ce & dm[word])) & valid;
+                if (keep != valid && lane == 0) alive[word] = keep | ~range;            // the dead keep their slots
+                killed += (uint32_t)__popcll(valid ^ keep);
+            }
+            const bool kp = (keep >> lane) & 1ull;
+            if (kp && ((ce >> lane) & 1ull)) set.pos_conf[k].w = pv[r].w - 1.0f;       // conflict.vert:72
+            if (!nosplat) {                                                              // workgroup-uniform
+                bool drew = false;
+                if (kp) drew = splat_one(fp, pv[r].x, pv[r].y, pv[r].z, pt[r], k, keyT);
+                vis += (uint32_t)__popcll(__ballot(drew));
+            }
+        }
+        if (killed && lane == 0) atomicAdd(&tile_dead[tile], killed);
+    }
+    if (SPLAT) {
+        if (lane == 0) s_vis[wave] = vis;
+        __syncthreads();
+        if (threadIdx.x == 0) blk_part[blockIdx.x] = make_uint2(s_vis[0] + s_vis[1] + s_vis[2] + s_vis[3], skipped);
     }
 }
 
@@ -1388,7 +1462,8 @@ __global__ __launch_bounds__(PIX_BLOCK) void k_append_scan(Model M, DevState *__
                                                            const uint2 *__restrict__ blk_cnt, FrameLog *__restrict__ log,
                                                            uint32_t *__restrict__ tb, const uint2 *__restrict__ compact_part,
                                                            uint32_t n_compact_part, uint64_t *__restrict__ alive,
-                                                           uint32_t *__restrict__ tile_dead)
+                                                           uint32_t *__restrict__ tile_dead,
+                                                           unsigned long long *__restrict__ host_stat)
 {
     __shared__ uint32_t s_red[2][4];
     __shared__ uint32_t s_cp[2][4];
@@ -1438,6 +1513,13 @@ __global__ __launch_bounds__(PIX_BLOCK) void k_append_scan(Model M, DevState *__
         } else {
             st->append_n = ntot;
             st->count = offset + ntot;
+        }
+        {
+            const uint32_t fr = st->stat_frames + 1u;
+            st->stat_frames = fr;
+            if (host_stat)
+                __hip_atomic_store(host_stat, ((unsigned long long)fr << 32) | (unsigned long long)st->count, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_SYSTEM);
         }
         if (fp.log_frame && log) {
             FrameLog e;

@@ -66,7 +66,7 @@ class HipAsPasses:
 
 def make(backend: str, W, H, fx, fy, cx, cy, **over):
     if backend == "oracle":
-        over = {k: v for k, v in over.items() if k not in ("disable_tile_bounds", "device", "enable_timing", "compact_garbage_pct")}
+        over = {k: v for k, v in over.items() if k not in ("disable_tile_bounds", "device", "enable_timing", "compact_period")}
         return ol.Oracle(ol.make_config(W, H, fx, fy, cx, cy, **over))
     from surfelmapping_amd import capi
     over.setdefault("max_sqrt_vertices", 1000)

@@ -1,5 +1,5 @@
 """Deferred compaction (DESIGN.md "Deferred compaction"): culled surfels keep their slots, marked dead, until
-more than `compact_garbage_pct` % of the slots are dead; only then does a cull move the survivors.  The stored
+the next compacting cull (every `compact_period`-th one) moves the survivors.  The stored
 model, every counter and the index map must not depend on when the compaction happens: all variants are compared
 with the CPU oracle (which compacts at every cull like the reference, src/GlobalModel.cpp:517-579) bit for bit."""
 import math
@@ -32,36 +32,36 @@ def wavy(n):
     return [synth.pose_matrix(0.15 * math.sin(0.7 * k), 0.0, 0.35 * k, 0.25 * math.sin(0.5 * k)) for k in range(n)]
 
 
-@pytest.mark.parametrize("pct", [0, 12, 25, 60])
-def test_any_compaction_schedule_gives_the_oracle_model(pct):
+@pytest.mark.parametrize("period", [1, 2, 5, 1000])
+def test_any_compaction_schedule_gives_the_oracle_model(period):
     seq = synth.make_sequence(SMALL, wavy(36), seed=21, noise_mm=6.0)
-    o, h = pair(SMALL, stereo_border=20.0, max_sqrt_vertices=700, compact_garbage_pct=pct)
+    o, h = pair(SMALL, stereo_border=20.0, max_sqrt_vertices=700, compact_period=period)
     for k, fr in enumerate(seq):
         o.process_frame(*fr); h.process_frame(*fr)
-        same_counts(o, h, f"pct={pct} frame {k}")          # counters never include dead slots
+        same_counts(o, h, f"period={period} frame {k}")          # counters never include dead slots
     log = h.read_frame_log(64)
     dead_carried = log["n_slots"].astype(np.int64) - log["n_before"].astype(np.int64)
     assert log["n_kill"].sum() > 2000, "the sequence must actually cull"
-    if pct == 0:
+    if period == 1:
         assert dead_carried.max() == 0                     # compacts at every cull
     else:
         assert dead_carried.max() > 0                      # dead slots were carried over frames ...
-    if pct in (12, 25):
+    if period in (2, 5):
         again = np.nonzero(dead_carried > 0)[0]
         assert (dead_carried[again[0]:] == 0).any(), dead_carried      # ... and squeezed out by a later cull
-    if pct == 60:
+    if period == 1000:
         assert dead_carried[-1] > 0                        # still dead slots in the model when it is downloaded
-    assert_models_equal(o.download_model(), h.download_model(), f"pct={pct}")
+    assert_models_equal(o.download_model(), h.download_model(), f"period={period}")
     same_counts(o, h, "after the download's compaction")
     # and the run continues on the compacted model
     for fr in synth.make_sequence(SMALL, wavy(40)[36:], seed=22, noise_mm=6.0):
         o.process_frame(*fr); h.process_frame(*fr)
-    assert_models_equal(o.download_model(), h.download_model(), f"pct={pct} continued")
+    assert_models_equal(o.download_model(), h.download_model(), f"period={period} continued")
 
 
 def test_index_map_ids_are_positions_among_live_surfels():
     seq = synth.make_sequence(SMALL, wavy(14), seed=23, noise_mm=6.0)
-    o, h = pair(SMALL, stereo_border=20.0, max_sqrt_vertices=700, compact_garbage_pct=60)
+    o, h = pair(SMALL, stereo_border=20.0, max_sqrt_vertices=700, compact_period=1000)
     for fr in seq:
         o.process_frame(*fr); h.process_frame(*fr)
     log = h.read_frame_log(4)
@@ -79,7 +79,7 @@ def test_index_map_ids_are_positions_among_live_surfels():
 
 def test_clean_points_and_reset_with_dead_slots():
     seq = synth.make_sequence(SMALL, wavy(16), seed=24, noise_mm=6.0)
-    o, h = pair(SMALL, stereo_border=20.0, max_sqrt_vertices=700, compact_garbage_pct=60)
+    o, h = pair(SMALL, stereo_border=20.0, max_sqrt_vertices=700, compact_period=1000)
     for fr in seq[:8]:
         o.process_frame(*fr); h.process_frame(*fr)
     rgb, d, s, p = seq[5]
@@ -105,7 +105,7 @@ def test_clean_points_and_reset_with_dead_slots():
 def test_capacity_pressure_forces_compaction():
     """Dead slots must never make a frame fail that fits once they are squeezed out (and vice versa)."""
     seq = synth.make_sequence(SMALL, wavy(30), seed=25, noise_mm=6.0)
-    o, h = pair(SMALL, stereo_border=20.0, max_sqrt_vertices=260, compact_garbage_pct=60)    # 67600 slots, P = 38400
+    o, h = pair(SMALL, stereo_border=20.0, max_sqrt_vertices=260, compact_period=1000)    # 67600 slots, P = 38400
     rcs = []
     for k, fr in enumerate(seq):
         ro = o.process_frame(*fr, allow=(0, -2)); rh = h.process_frame(*fr, allow=(0, -2))
@@ -120,7 +120,7 @@ def test_conflict_cap_and_id_zero_rule_with_dead_slots():
     """More conflicts than pixels (only the first W*H in surfel order count) while slots are dead,
     and the surfel the reference calls id 0 (never associated, never conflicting) is no longer in slot 0."""
     cam = dict(width=48, height=32, fx=40.0, fy=40.0, cx=23.5, cy=15.5)
-    o, h = pair(cam, stereo_border=0.0, conflict_cap=1, max_sqrt_vertices=200, compact_garbage_pct=60)
+    o, h = pair(cam, stereo_border=0.0, conflict_cap=1, max_sqrt_vertices=200, compact_period=1000)
     rng = np.random.default_rng(7)
     n = 20000
     m = synth.seeded_model(n, tick=1, seed=9)
