@@ -267,16 +267,29 @@ def main():
     logd = {k: log[k] for k in log.dtype.names}
     logd["P"] = P
     kb = kernel_bytes(logd)
-    kern = {}
+    kern, launches = {}, {}
     for name, b in kb.items():
         ms = tim[name]
         kern[name] = {"ms": ms, "MB": float(b.mean()) / 1e6,
                       "GBs": (float(b.mean()) / 1e9) / (ms * 1e-3) if ms > 0 else None}
+        launches[name] = K
+    # the cull slot holds one of two kernels: k_compact on the frames that compact, k_cull_lazy on the others
+    # (deferred compaction); each is averaged over its own frames.  "Moved" frames in the log: n_static < n_slots.
+    cull_b = kb.pop("k_compact")
+    del kern["k_compact"], launches["k_compact"]
+    moved = log["n_static"] < log["n_slots"] if len(log) else np.zeros(0, bool)
+    n_comp = int(tim.get("frames_compact", 0)) if sm_ev is not None else int(moved.sum())
+    for name, ms, sel, n in (("k_compact", tim.get("k_compact_own", 0.0), moved, n_comp),
+                             ("k_cull_lazy", tim.get("k_cull_lazy", 0.0), ~moved, K - n_comp)):
+        mb = float(cull_b[sel].mean()) / 1e6 if sel.any() else 0.0
+        kern[name] = {"ms": ms, "MB": mb, "GBs": (mb / 1e3) / (ms * 1e-3) if ms > 0 else None, "launches": n}
+        launches[name] = n
     for name in ("k_scan_cull", "k_scan_new"):
         kern[name] = {"ms": tim[name], "MB": None, "GBs": None}
-    dom = max(kb.keys(), key=lambda n: tim[n])
+    # dominant kernel = the one the run spends most time in (average duration x launches)
+    dom = max(launches.keys(), key=lambda n: kern[n]["ms"] * launches[n])
     achieved = kern[dom]["GBs"] or 0.0
-    traffic = None
+    traffic, valu = None, None
     tpath = os.path.join(ROOT, "profiles", f"traffic_{args.workload}.json")
     if os.path.exists(tpath):
         # HBM bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this very
@@ -284,9 +297,15 @@ def main():
         tj = json.load(open(tpath))
         if tj.get("steps") == K and tj.get("warmup") == Wm:
             traffic = tj.get("kernels", {}).get(dom, {}).get("hbm_bytes_per_launch")
+            valu = tj.get("kernels", {}).get(dom, {}).get("valu_issue_util")
     roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "ms_per_launch": kern[dom]["ms"], "alg_bytes_per_launch": kern[dom]["MB"] * 1e6}
+                "ms_per_launch": kern[dom]["ms"], "alg_bytes_per_launch": kern[dom]["MB"] * 1e6,
+                "launches": launches[dom],
+                "valu_issue_util": valu,
+                "note": "the surfel kernels sit nearer their VALU issue limit than the HBM roof: IEEE-exact fp32 "
+                        "(correctly rounded / and sqrt, no FMA contraction) costs ~250 VALU instructions per surfel "
+                        "(DESIGN.md 4, profiles/ SQ pass)"}
 
     # ---- CPU baseline: the oracle over the very same frames (rank 0, N=1 only)
     cpu = None

@@ -82,6 +82,10 @@ typedef struct sm_timings {
     float k_prep, k_conflict, k_scan_cull, k_compact, k_associate, k_scan_new, k_append;
     uint32_t frames;          /* frames averaged */
     float event_overhead;     /* measured cost of one event record, already subtracted from the k_* fields */
+    /* the cull slot by kernel: k_compact above averages over ALL frames; these two over their own frames */
+    float k_compact_own;      /* k_compact, averaged over the frames that compacted */
+    float k_cull_lazy;        /* k_cull_lazy, averaged over the frames that only marked the dead */
+    uint32_t frames_compact;  /* how many of `frames` compacted */
 } sm_timings;
 
 /* Per-frame counters written by the device at the end of every fusing frame (ring of

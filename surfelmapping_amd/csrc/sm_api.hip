@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 using namespace sm;
@@ -181,6 +182,7 @@ struct sm_ctx {
     std::vector<void *> user_allocs;
     // timing
     hipEvent_t ev[N_EV][EV_RING];     // per-frame timeline: before prep, then after each kernel
+    bool ev_compacted[EV_RING] = {};  // which cull kernel the frame of that slot ran
     FrameLog *d_log = nullptr;
     bool ev_ok = false;
     uint64_t ev_frames = 0, ev_read = 0;
@@ -378,11 +380,21 @@ int launch_compact(sm_ctx *s, const FrameParams &fp, bool splat, bool timed)
 bool decide_compact(sm_ctx *s)
 {
     if (s->sh_world > 1 || s->cfg.compact_period <= 1) return true;
-    const unsigned long long v = __atomic_load_n(s->h_stat, __ATOMIC_RELAXED);
-    const uint32_t fr = (uint32_t)(v >> 32), slots = (uint32_t)v;
-    uint64_t bound = s->count_bound;
-    if (s->frames_enq >= fr) bound = std::min<uint64_t>(bound, (uint64_t)slots + (uint64_t)(s->frames_enq - fr) * s->n_odd_pixels);
-    if (bound + s->n_odd_pixels > s->cap) return true;
+    // Capacity: a cull that only marks the dead must not be able to make the frame overflow because of them.
+    // bound = slots at the last device update + one frame's worth of new surfels for every append enqueued since.
+    // When the host has run far ahead of the device the bound is loose; rather than compacting for nothing it then
+    // lets the device catch up (the queue still holds every frame in between, so the GPU stays busy).
+    for (uint32_t spins = 0;; ++spins) {
+        const unsigned long long v = __atomic_load_n(s->h_stat, __ATOMIC_RELAXED);
+        const uint32_t fr = (uint32_t)(v >> 32), slots = (uint32_t)v;
+        uint64_t bound = s->count_bound;
+        const uint32_t ahead = s->frames_enq >= fr ? s->frames_enq - fr : 0u;
+        if (s->frames_enq >= fr) bound = std::min<uint64_t>(bound, (uint64_t)slots + (uint64_t)ahead * s->n_odd_pixels);
+        if (bound + s->n_odd_pixels <= s->cap) break;                  // fits even if every candidate pixel is new
+        if (ahead <= 1u || spins > (1u << 22)) return true;            // the bound is (nearly) exact: compact
+        if ((uint64_t)slots + 2ull * s->n_odd_pixels > s->cap) return true;   // would not fit with the device caught up either
+        std::this_thread::yield();
+    }
     return s->culls_since_compact + 1 >= s->cfg.compact_period;
 }
 
@@ -592,6 +604,7 @@ int enqueue_frame(sm_ctx *s, const uint8_t *d_rgb, const uint16_t *d_raw, const 
     if (rc <= 0) return rc;
     fp.compact_now = decide_compact(s) ? 1u : 0u;
     note_cull(s, fp.compact_now != 0u);
+    if (s->ev_ok) s->ev_compacted[s->ev_frames % EV_RING] = fp.compact_now != 0u;
     if ((rc = launch_conflict(s, fp, true))) return rc;    // :178-187
     if ((rc = launch_compact(s, fp, true, true))) return rc;   // :189-197 (cull + mirror + index map)
     if ((rc = launch_associate(s, fp, true))) return rc;   // :212-239
@@ -1193,8 +1206,8 @@ int sm_stage_timings(sm_ctx *s, sm_timings *out)
     HIPCK(hipStreamSynchronize(s->stream));
     uint64_t first = s->ev_read;
     if (s->ev_frames - first > EV_RING) first = s->ev_frames - EV_RING;
-    double seg[7] = {0}, run = 0, ovh = 0;
-    uint32_t nfr = 0;
+    double seg[7] = {0}, run = 0, ovh = 0, cull[2] = {0, 0};
+    uint32_t nfr = 0, ncls[2] = {0, 0};
     for (uint64_t f = first; f < s->ev_frames; ++f) {
         const int slot = (int)(f % EV_RING);
         float ms = 0;
@@ -1209,6 +1222,8 @@ int sm_stage_timings(sm_ctx *s, sm_timings *out)
         ok = ok && hipEventElapsedTime(&o, s->ev[8][slot], s->ev[0][slot]) == hipSuccess;
         if (!ok) continue;
         for (int k = 0; k < 7; ++k) seg[k] += loc[k];
+        cull[s->ev_compacted[slot] ? 1 : 0] += loc[3];
+        ncls[s->ev_compacted[slot] ? 1 : 0]++;
         run += ms;
         ovh += o;
         nfr++;
@@ -1225,6 +1240,9 @@ int sm_stage_timings(sm_ctx *s, sm_timings *out)
         out->k_prep = (float)(seg[0] * inv); out->k_conflict = (float)(seg[1] * inv); out->k_scan_cull = (float)(seg[2] * inv);
         out->k_compact = (float)(seg[3] * inv); out->k_associate = (float)(seg[4] * inv); out->k_scan_new = (float)(seg[5] * inv);
         out->k_append = (float)(seg[6] * inv);
+        out->k_cull_lazy = ncls[0] ? (float)std::max(0.0, cull[0] / ncls[0] - oh) : 0.0f;
+        out->k_compact_own = ncls[1] ? (float)std::max(0.0, cull[1] / ncls[1] - oh) : 0.0f;
+        out->frames_compact = ncls[1];
         out->preprocess = out->k_prep;
         out->conflict = out->k_conflict + out->k_scan_cull + out->k_compact;
         out->index_map = 0.0f;

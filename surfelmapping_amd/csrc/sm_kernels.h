@@ -738,9 +738,8 @@ __global__ __launch_bounds__(256) void k_compact(Model M, DevState *__restrict__
     uint32_t vis = 0, skipped = 0, iter = 0;
     uint64_t skipmask = 0;
     uint32_t m_nconf = 0, m_nkill = 0, m_allow = 0, m_base = 0, m_dead = 0;
-    // Deferred compaction: unless this cull compacts, survivors stay in their slots (slot = id for the key map: the
-    // order of slots is the order of ids) and the dead are only cleared from the alive mask.
-    const bool compacting = st->do_compact != 0u;
+    // Deferred compaction: this kernel runs on the culls that compact; the slots left dead by the culls in between
+    // (k_cull_lazy) are squeezed out together with this cull's own victims.
     const bool had_dead = st->garbage_prev != 0u;
     const bool cap_binds = st->cap_binds != 0u;
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x, ++iter) {
@@ -753,7 +752,7 @@ __global__ __launch_bounds__(256) void k_compact(Model M, DevState *__restrict__
             skipmask = __ballot(in && (tile_flags[tt] & 2u));
             m_nconf = tile_cnt[tt * 3]; m_nkill = tile_cnt[tt * 3 + 1];
             m_allow = cap_binds ? tile_allow[tt] : m_nconf;         // every conflict takes effect unless the cap binds
-            m_base = compacting ? tile_keep_prefix[tt] + group_keep_base[tt / GROUP] : tt * (uint32_t)TILE;
+            m_base = tile_keep_prefix[tt] + group_keep_base[tt / GROUP];
             m_dead = had_dead ? tile_dead[tt] : 0u;
         }
         const int sl = (int)(iter & 63u);
@@ -762,7 +761,7 @@ __global__ __launch_bounds__(256) void k_compact(Model M, DevState *__restrict__
         const uint32_t tdead = (uint32_t)__shfl((int)m_dead, sl);
         // fast path (workgroup-uniform): nothing of this tile conflicts, dies or moves -- the bulk of the map
         // once the camera has passed.  No masks, no LDS, no barriers: read pos+time, splat.
-        if (nconf == 0 && nkill_full == 0 && base_id == tile * (uint32_t)TILE && (tdead == 0u || !compacting)) {
+        if (nconf == 0 && nkill_full == 0 && base_id == tile * (uint32_t)TILE && tdead == 0u) {
             // ... and if its box cannot reach the index map (index_map.vert:45-55: 0 < z < far inside the image,
             // updated within timeDelta frames) it is not even read
             if (SPLAT && ((skipmask >> (iter & 63u)) & 1ull)) {
@@ -782,9 +781,8 @@ __global__ __launch_bounds__(256) void k_compact(Model M, DevState *__restrict__
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const uint32_t k = (tile * TILE_WORDS + r * 4 + wave) * 64u + lane;
-                    bool drew = false, live = k < N;
-                    if (tdead) live = live && ((alive[tile * TILE_WORDS + r * 4 + wave] >> lane) & 1ull);   // workgroup-uniform branch
-                    if (live)
+                    bool drew = false;
+                    if (k < N)
                         drew = splat_one(fp, pv[r].x, pv[r].y, pv[r].z, pt[r], local_to_global(k, seg_lstart, seg_gbase, fp.nseg), keyT);
                     vis += (uint32_t)__popcll(__ballot(drew));
                 }
@@ -792,7 +790,7 @@ __global__ __launch_bounds__(256) void k_compact(Model M, DevState *__restrict__
             continue;
         }
         // conservative: a tile classified "moving" that turns out static is handled correctly (it rewrites itself)
-        const bool moving = compacting && ((base_id != tile * (uint32_t)TILE) || nkill_full != 0u || tdead != 0u);   // workgroup-uniform
+        const bool moving = (base_id != tile * (uint32_t)TILE) || nkill_full != 0u || tdead != 0u;   // workgroup-uniform
         // ---- issue every surfel load of the tile first (unconditional, clamped: a per-lane branch would serialise
         // them behind s_waitcnt); the mask bookkeeping below overlaps their latency
         float4 v[4], nr[4];
@@ -808,7 +806,7 @@ __global__ __launch_bounds__(256) void k_compact(Model M, DevState *__restrict__
             nr[r] = make_float4(0.f, 0.f, 0.f, 0.f); col[r] = 0; it[r] = 0.f;
             if (moving) { nr[r] = set.norm_rad[kc]; col[r] = set.color[kc]; it[r] = set.init_time[kc]; }
         }
-        uint64_t c = 0, d = 0, z = 0, valid = 0, beyond = 0;   // beyond: bits of slots >= N (free slots count as alive)
+        uint64_t c = 0, d = 0, z = 0, valid = 0;
         if (threadIdx.x < TILE_WORDS) {
             const uint32_t word = tile * TILE_WORDS + threadIdx.x;
             const uint64_t base = (uint64_t)word * 64u;
@@ -816,7 +814,6 @@ __global__ __launch_bounds__(256) void k_compact(Model M, DevState *__restrict__
                 c = cm[word]; d = dm[word]; z = zm[word];
                 const uint64_t rem = (uint64_t)N - base;
                 valid = rem >= 64 ? ~0ull : ((1ull << rem) - 1ull);
-                beyond = ~valid;
                 if (had_dead) valid &= alive[word];
             }
             s_cpop[threadIdx.x] = (uint32_t)__popcll(c);
@@ -832,7 +829,6 @@ __global__ __launch_bounds__(256) void k_compact(Model M, DevState *__restrict__
             const uint64_t keep = ~(z | (ce & d)) & valid;
             s_ceff[threadIdx.x] = ce;
             s_keep[threadIdx.x] = keep;
-            if (!compacting && keep != valid) alive[tile * TILE_WORDS + threadIdx.x] = keep | beyond;   // the dead keep their slots
         }
         __syncthreads();
         if (threadIdx.x <= TILE_WORDS) {
@@ -842,14 +838,12 @@ __global__ __launch_bounds__(256) void k_compact(Model M, DevState *__restrict__
         }
         __syncthreads();
         const uint32_t kcount = s_kpre[TILE_WORDS];
-        if (!compacting && threadIdx.x == 0) tile_dead[tile] = min((uint32_t)TILE, N - tile * TILE) - kcount;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int w = r * 4 + wave;
             const uint64_t keepw = s_keep[w];
             kept[r] = (keepw >> lane) & 1ull;
-            nid[r] = compacting ? base_id + s_kpre[w] + (uint32_t)__popcll(keepw & ((1ull << lane) - 1ull))
-                                : (tile * TILE_WORDS + w) * 64u + lane;
+            nid[r] = base_id + s_kpre[w] + (uint32_t)__popcll(keepw & ((1ull << lane) - 1ull));
             if (kept[r] && ((s_ceff[w] >> lane) & 1ull)) {
                 v[r].w -= 1.0f;                           // conflict.vert:72
                 if (!moving) set.pos_conf[(tile * TILE_WORDS + w) * 64u + lane].w = v[r].w;

@@ -5,8 +5,12 @@
   pmc_fetch/  --pmc FETCH_SIZE                -> HBM bytes read per launch
   pmc_write/  --pmc WRITE_SIZE                -> HBM bytes written per launch
 
-`--last K` restricts every average to the last K launches of each kernel, i.e. the launches of
-bench.py's timed region (the first launches belong to its warm-up frames).  gfx950 correction
+  pmc_sq/     --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY ... -> VALU issue utilisation
+
+`--last K` restricts every average to the launches of the last K frames, i.e. of bench.py's timed region (the earlier
+launches belong to its warm-up frames and to its un-instrumented pass): a frame starts with a `k_prep` launch, so
+everything dispatched from the K-th last `k_prep` on is averaged -- kernels that run only on some frames
+(`k_compact` on compacting frames, `k_cull_lazy` on the others) are averaged over their own launches in that window.  gfx950 correction
 (/opt/skills/guides/MI355X_MICROARCH.md, HBM): FETCH_SIZE (KB) reports exactly 1/2 of the bytes
 of a wide coalesced streaming read -> doubled; WRITE_SIZE (KB) is exact.
 """
@@ -31,17 +35,28 @@ def main():
     ap.add_argument("--out", default=None)
     ap.add_argument("--steps", type=int, default=None, help="recorded in the json (bench.py --steps of the profiled command)")
     ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--simds", type=int, default=1024, help="SIMDs of the device (MI355X: 256 CUs x 4)")
+    ap.add_argument("--mhz", type=float, default=2400.0, help="shader clock used to turn durations into cycles")
     a = ap.parse_args()
     res = collections.defaultdict(dict)
+
+    def window(per):
+        """per: kernel -> sorted [(order key, value)]; returns kernel -> values inside the last `--last` frames"""
+        if not a.last or "k_prep" not in per or len(per["k_prep"]) < a.last:
+            return {k: [x[1] for x in v] for k, v in per.items()}
+        t0 = per["k_prep"][-a.last][0]
+        return {k: [x[1] for x in v if x[0] >= t0] for k, v in per.items()}
+
     tr = glob.glob(os.path.join(a.dir, "trace", "*", "*_kernel_trace.csv"))
     if tr:
         per = collections.defaultdict(list)
         for r in csv.DictReader(open(tr[0])):
             per[short(r["Kernel_Name"])].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
-        for k, v in per.items():
+        for v in per.values():
             v.sort()
-            d = [x[1] for x in v][-a.last:] if a.last else [x[1] for x in v]
-            res[k].update(calls=len(v), averaged=len(d), avg_us=sum(d) / len(d) / 1e3, min_us=min(d) / 1e3, max_us=max(d) / 1e3)
+        for k, d in window(per).items():
+            if d:
+                res[k].update(calls=len(per[k]), averaged=len(d), avg_us=sum(d) / len(d) / 1e3, min_us=min(d) / 1e3, max_us=max(d) / 1e3)
     for sub, ctr, mult in (("pmc_fetch", "FETCH_SIZE", 2.0), ("pmc_write", "WRITE_SIZE", 1.0)):
         f = glob.glob(os.path.join(a.dir, sub, "*", "*_counter_collection.csv"))
         if not f:
@@ -50,21 +65,40 @@ def main():
         for r in csv.DictReader(open(f[0])):
             if r["Counter_Name"] == ctr:
                 per[short(r["Kernel_Name"])].append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
-        for k, v in per.items():
+        for v in per.values():
             v.sort()
-            d = [x[1] for x in v][-a.last:] if a.last else [x[1] for x in v]
-            res[k][ctr + "_bytes_per_launch"] = sum(d) / len(d) * 1024.0 * mult
+        for k, d in window(per).items():
+            if d:
+                res[k][ctr + "_bytes_per_launch"] = sum(d) / len(d) * 1024.0 * mult
+    f = glob.glob(os.path.join(a.dir, "pmc_sq", "*", "*_counter_collection.csv"))
+    if f:
+        # SQ counters are quad-cycles (MI355X_MICROARCH.md): a wave64 VALU instruction occupies its SIMD for 4 cycles,
+        # so  4 * SQ_ACTIVE_INST_VALU / (SIMDs * kernel cycles)  is the fraction of all VALU issue slots in use
+        ctrs = collections.defaultdict(lambda: collections.defaultdict(list))
+        for r in csv.DictReader(open(f[0])):
+            ctrs[r["Counter_Name"]][short(r["Kernel_Name"])].append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
+        for name, per in ctrs.items():
+            for v in per.values():
+                v.sort()
+            for k, d in window(per).items():
+                if d:
+                    res[k][name] = sum(d) / len(d)
+        for k, v in res.items():
+            if "SQ_ACTIVE_INST_VALU" in v and v.get("avg_us"):
+                v["valu_issue_util"] = 4.0 * v["SQ_ACTIVE_INST_VALU"] / (a.simds * v["avg_us"] * a.mhz)
+            if "SQ_WAIT_ANY" in v and v.get("SQ_WAVE_CYCLES"):
+                v["wave_wait_frac"] = v["SQ_WAIT_ANY"] / v["SQ_WAVE_CYCLES"]
     for k, v in res.items():
         if "FETCH_SIZE_bytes_per_launch" in v and "WRITE_SIZE_bytes_per_launch" in v:
             v["hbm_bytes_per_launch"] = v["FETCH_SIZE_bytes_per_launch"] + v["WRITE_SIZE_bytes_per_launch"]
     rows = sorted(res.items(), key=lambda kv: -kv[1].get("avg_us", 0) * kv[1].get("calls", 0))
-    print(f"{'kernel':28s} {'calls':>6s} {'avg_us':>9s} {'min_us':>8s} {'max_us':>8s} {'HBM MB/launch':>14s}")
+    print(f"{'kernel':28s} {'calls':>6s} {'avgd':>5s} {'avg_us':>9s} {'min_us':>8s} {'max_us':>8s} {'HBM MB/launch':>14s} {'VALU util':>10s} {'wave wait':>10s}")
     for k, v in rows:
         if not k.startswith("k_"):
             continue
         hb = v.get("hbm_bytes_per_launch")
-        print(f"{k:28s} {v.get('calls', 0):6d} {v.get('avg_us', 0):9.2f} {v.get('min_us', 0):8.2f} {v.get('max_us', 0):8.2f} "
-              f"{(hb / 1e6 if hb else float('nan')):14.2f}")
+        print(f"{k:28s} {v.get('calls', 0):6d} {v.get('averaged', 0):5d} {v.get('avg_us', 0):9.2f} {v.get('min_us', 0):8.2f} {v.get('max_us', 0):8.2f} "
+              f"{(hb / 1e6 if hb else float('nan')):14.2f} {v.get('valu_issue_util', float('nan')):10.2f} {v.get('wave_wait_frac', float('nan')):10.2f}")
     if a.out:
         json.dump({"last": a.last, "steps": a.steps, "warmup": a.warmup, "kernels": {k: v for k, v in rows if k.startswith('k_')}}, open(a.out, "w"), indent=1)
 
