@@ -1467,9 +1467,11 @@ __global__ __launch_bounds__(PIX_BLOCK) void k_append_scan(Model M, DevState *__
     post_compact_fill(st, alive, tile_dead, blockIdx.x * PIX_BLOCK + threadIdx.x, gridDim.x * PIX_BLOCK);
     const int q = blockIdx.x * PIX_BLOCK + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const bool last = blockIdx.x == gridDim.x - 1;
+    // block 0 also publishes the frame totals: it is dispatched first, so its longer chain (all counts, the cull's
+    // partials, DevState, the frame log) overlaps with the other blocks instead of trailing them
+    const bool last = blockIdx.x == 0;
     if (!last && blk_cnt[blockIdx.x].x == 0u) return;             // no new surfel in this block's pixels (sky, border)
-    const int upto = last ? (int)gridDim.x : (int)blockIdx.x;     // the last block needs the totals
+    const int upto = last ? (int)gridDim.x : (int)blockIdx.x;     // the totals block needs every count
     uint32_t pn = 0, pf = 0, tn = 0;                              // prefix of new; totals (last block only)
     for (int b = threadIdx.x; b < upto; b += PIX_BLOCK) {
         const uint2 c = blk_cnt[b];
