@@ -295,7 +295,7 @@ def main():
         # HBM bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this very
         # command (profiles/README.md), gfx950-corrected by tools/prof_summary.py
         tj = json.load(open(tpath))
-        if tj.get("steps") == K and tj.get("warmup") == Wm:
+        if tj.get("steps") == K and tj.get("warmup") == Wm and tj.get("compact_period", 8) == args.compact_period:
             traffic = tj.get("kernels", {}).get(dom, {}).get("hbm_bytes_per_launch")
             valu = tj.get("kernels", {}).get(dom, {}).get("valu_issue_util")
     roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

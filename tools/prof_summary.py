@@ -35,6 +35,7 @@ def main():
     ap.add_argument("--out", default=None)
     ap.add_argument("--steps", type=int, default=None, help="recorded in the json (bench.py --steps of the profiled command)")
     ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--compact-period", type=int, default=8, help="recorded in the json (bench.py --compact-period of the profiled command)")
     ap.add_argument("--simds", type=int, default=1024, help="SIMDs of the device (MI355X: 256 CUs x 4)")
     ap.add_argument("--mhz", type=float, default=2400.0, help="shader clock used to turn durations into cycles")
     a = ap.parse_args()
@@ -100,7 +101,7 @@ def main():
         print(f"{k:28s} {v.get('calls', 0):6d} {v.get('averaged', 0):5d} {v.get('avg_us', 0):9.2f} {v.get('min_us', 0):8.2f} {v.get('max_us', 0):8.2f} "
               f"{(hb / 1e6 if hb else float('nan')):14.2f} {v.get('valu_issue_util', float('nan')):10.2f} {v.get('wave_wait_frac', float('nan')):10.2f}")
     if a.out:
-        json.dump({"last": a.last, "steps": a.steps, "warmup": a.warmup, "kernels": {k: v for k, v in rows if k.startswith('k_')}}, open(a.out, "w"), indent=1)
+        json.dump({"last": a.last, "steps": a.steps, "warmup": a.warmup, "compact_period": a.compact_period, "kernels": {k: v for k, v in rows if k.startswith('k_')}}, open(a.out, "w"), indent=1)
 
 
 if __name__ == "__main__":
