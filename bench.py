@@ -72,7 +72,7 @@ def kernel_bytes(log):
     # frame the rest is read in full (44) and its survivors rewritten (44); every drawn surfel costs one 8-byte key atomic
     compact = 20.0 * np.maximum(Ns - Ss, 0.0) + 44.0 * np.maximum(Sl - Ns, 0.0) + 44.0 * np.maximum(Np - Ns, 0.0) + 8.0 * V
     return {
-        "k_prep": np.full_like(N, 6.0 * P + 16.0 * P),          # u8x3+u16+u8 in, f32+u32+u64 out
+        "k_prep": np.full_like(N, 6.0 * P + 24.0 * P),          # u8x3+u16+u8 in, f32+u32+u64+(f32,u32) out
         "k_conflict": 16.0 * np.maximum(Sl - Cs, 0.0),            # tiles skipped by their bounds are not read
         "k_compact": compact,
         "k_associate": 16.0 * P + 84.0 * F,                       # depth+rgbs+key per pixel, gather 44 + scatter 40 per fuse
