@@ -379,7 +379,8 @@ int launch_compact(sm_ctx *s, const FrameParams &fp, bool splat, bool timed)
 // surfels for every append enqueued since.
 bool decide_compact(sm_ctx *s)
 {
-    if (s->sh_world > 1 || s->cfg.compact_period <= 1) return true;
+    // (the experimental single-kernel association does not maintain the slot statistic: it compacts at every cull)
+    if (s->sh_world > 1 || s->cfg.compact_period <= 1 || s->use_fused_assoc) return true;
     // Capacity: a cull that only marks the dead must not be able to make the frame overflow because of them.
     // bound = slots at the last device update + one frame's worth of new surfels for every append enqueued since.
     // When the host has run far ahead of the device the bound is loose; rather than compacting for nothing it then
