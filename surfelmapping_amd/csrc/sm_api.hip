@@ -120,6 +120,17 @@ struct sm_ctx {
     int W = 0, H = 0, P = 0;
     uint32_t cap = 0;                 // MAX_VERTICES
     hipStream_t stream = nullptr;
+    // Second stream for the pre-processing of frame f+1 (metricise/pack/transpose/key clear, + the depth filter chain):
+    // it only depends on the caller's images, so it runs while frame f's association and append are still on `stream`.
+    // The four frame planes it writes are double-buffered (the *_nx pointers are the set of the other frame).
+    hipStream_t stream2 = nullptr;
+    hipEvent_t ev_prep = nullptr, ev_main = nullptr, ev_done[2] = {nullptr, nullptr};
+    bool chain_on_main = false;        // the last pre-processing chain ran on `stream` (a non-overlapping frame)
+    bool ev_done_valid[2] = {false, false};
+    int plane_set = 0;                 // which plane set the current frame uses
+    bool overlap = false;              // this frame overlaps (set per call)
+    bool overlap_capable = false;      // second stream + second plane set exist
+    bool idle_hint = true;             // the host has waited for the device since the last frame: nothing to overlap with
     Model M{};
     DevState *d_state = nullptr;
     DevState *h_state = nullptr;      // pinned mirror
@@ -127,6 +138,7 @@ struct sm_ctx {
     float *d_depthT = nullptr, *d_filteredT = nullptr, *d_lastT = nullptr;
     uint32_t *d_rgbsT = nullptr;
     uint2 *d_dcT = nullptr;            // (depth bits, rgbs) of the frame the conflict test sees
+    float *d_depthT_nx = nullptr; uint32_t *d_rgbsT_nx = nullptr; uint64_t *d_keyT_nx = nullptr; uint2 *d_dcT_nx = nullptr;
     uint64_t *d_keyT = nullptr;
     // row-major staging of the caller's inputs
     uint8_t *d_rgb = nullptr, *d_sem = nullptr;
@@ -271,6 +283,7 @@ int pull_state(sm_ctx *s)
 {
     HIPCK(hipMemcpyAsync(s->h_state, s->d_state, sizeof(DevState), hipMemcpyDeviceToHost, s->stream));
     HIPCK(hipStreamSynchronize(s->stream));
+    s->idle_hint = true;
     const DevState &d = *s->h_state;
     s->counts.count = s->pending_cull ? s->count_before_cull : d.count - d.garbage;   // dead slots are not surfels
     s->counts.offset = d.offset - d.garbage;
@@ -300,10 +313,10 @@ int take_error(sm_ctx *s)
 // ---- launches ----
 
 int launch_prep(sm_ctx *s, const uint8_t *rgb, const uint16_t *raw, const uint8_t *sem, const float *dm,
-                const FrameParams &fp, bool clear_keys)
+                const FrameParams &fp, bool clear_keys, hipStream_t st = nullptr)
 {
     const int tiles = ((s->W + 31) / 32) * ((s->H + 31) / 32);
-    hipLaunchKernelGGL(k_prep, dim3(tiles), dim3(1024), 0, s->stream, rgb, raw, sem, dm, s->d_depthT, s->d_rgbsT,
+    hipLaunchKernelGGL(k_prep, dim3(tiles), dim3(1024), 0, st ? st : s->stream, rgb, raw, sem, dm, s->d_depthT, s->d_rgbsT,
                        clear_keys ? s->d_keyT : nullptr, fp, s->d_dcT);
     HIPCK(hipGetLastError());
     return SM_OK;
@@ -539,15 +552,26 @@ int begin_frame(sm_ctx *s, const uint8_t *d_rgb, const uint16_t *d_raw, const ui
     int rc;
     if ((rc = mark(s, 8, fusing))) return rc;    // back-to-back pair 8 -> 0: the cost of an event record itself
     if ((rc = mark(s, 0, fusing))) return rc;
+    hipStream_t ps = s->stream;
+    if (s->overlap) {
+        // this frame's planes are the set the frame before the previous one used: wait until that frame is through
+        ps = s->stream2;
+        s->plane_set ^= 1;
+        std::swap(s->d_depthT, s->d_depthT_nx); std::swap(s->d_rgbsT, s->d_rgbsT_nx);
+        std::swap(s->d_keyT, s->d_keyT_nx); std::swap(s->d_dcT, s->d_dcT_nx);
+        if (s->ev_done_valid[s->plane_set]) HIPCK(hipStreamWaitEvent(ps, s->ev_done[s->plane_set], 0));
+        // the filter chain carries LAST / DEPTH_FILTERED from frame to frame: follow a chain that ran on the main stream
+        if (s->chain_on_main) { HIPCK(hipStreamWaitEvent(ps, s->ev_main, 0)); s->chain_on_main = false; }
+    }
     // metriciseDepth (+ filterDepth when preprocess=1)   src/SurfelMapping.cpp:136-139
-    if ((rc = launch_prep(s, d_rgb, d_raw, d_sem, nullptr, fp, true))) return rc;
+    if ((rc = launch_prep(s, d_rgb, d_raw, d_sem, nullptr, fp, true, ps))) return rc;
     const int pblocks = (s->P + 255) / 256;
     if (s->cfg.preprocess) {                              // filterDepth src/SurfelMapping.cpp:269-334
         const int stiles = ((s->W + 31) / 32) * ((s->H + 31) / 32);
         const int border = (int)std::ceil(s->cfg.stereo_border - 0.5f);
-        hipLaunchKernelGGL(k_filter_depth, dim3(pblocks), dim3(256), 0, s->stream, s->d_depthT, s->d_rgbsT, s->d_filteredT, fp, 0.15f);
-        hipLaunchKernelGGL(k_smooth_depth, dim3(stiles), dim3(1024), 0, s->stream, s->d_filteredT, s->d_rgbsT, s->d_depthT, fp, s->d_wtab, border);
-        hipLaunchKernelGGL(k_filter_depth, dim3(pblocks), dim3(256), 0, s->stream, s->d_depthT, s->d_rgbsT, s->d_filteredT, fp, 0.1f);
+        hipLaunchKernelGGL(k_filter_depth, dim3(pblocks), dim3(256), 0, ps, s->d_depthT, s->d_rgbsT, s->d_filteredT, fp, 0.15f);
+        hipLaunchKernelGGL(k_smooth_depth, dim3(stiles), dim3(1024), 0, ps, s->d_filteredT, s->d_rgbsT, s->d_depthT, fp, s->d_wtab, border);
+        hipLaunchKernelGGL(k_filter_depth, dim3(pblocks), dim3(256), 0, ps, s->d_depthT, s->d_rgbsT, s->d_filteredT, fp, 0.1f);
         HIPCK(hipGetLastError());
     }
     // preprocess == 0: DEPTH_FILTERED and LAST are the metric depth itself (nothing reads them on the
@@ -557,6 +581,13 @@ int begin_frame(sm_ctx *s, const uint8_t *d_rgb, const uint16_t *d_raw, const ui
         memcpy(s->last_pose, s->curr_pose, 64);
         s->ref_set = true;
         s->tick++;
+        if (s->overlap) {                                 // everything later on `stream` is ordered after this pre-processing
+            HIPCK(hipEventRecord(s->ev_prep, ps));
+            HIPCK(hipStreamWaitEvent(s->stream, s->ev_prep, 0));
+        } else if (s->overlap_capable) {
+            HIPCK(hipEventRecord(s->ev_main, s->stream));
+            s->chain_on_main = true;
+        }
         return 0;
     }
     if (s->cfg.preprocess) {                              // removeMovings src/SurfelMapping.cpp:156,336-365
@@ -564,9 +595,16 @@ int begin_frame(sm_ctx *s, const uint8_t *d_rgb, const uint16_t *d_raw, const ui
         float linv[16];
         invert4(s->last_pose, linv);
         mul4(linv, s->curr_pose, t_c2l.m);
-        hipLaunchKernelGGL(k_remove_movings, dim3(pblocks), dim3(256), 0, s->stream, s->d_filteredT, s->d_rgbsT, s->d_lastT,
+        hipLaunchKernelGGL(k_remove_movings, dim3(pblocks), dim3(256), 0, ps, s->d_filteredT, s->d_rgbsT, s->d_lastT,
                            s->d_depthT, fp, t_c2l, s->d_dcT);
         HIPCK(hipGetLastError());
+    }
+    if (s->overlap) {
+        HIPCK(hipEventRecord(s->ev_prep, ps));
+        HIPCK(hipStreamWaitEvent(s->stream, s->ev_prep, 0));
+    } else if (s->overlap_capable) {
+        HIPCK(hipEventRecord(s->ev_main, s->stream));
+        s->chain_on_main = true;
     }
     if ((rc = mark(s, 1, fusing))) return rc;
     if (s->tick == 0) {
@@ -594,6 +632,7 @@ void end_frame(sm_ctx *s, bool timed)
     memcpy(s->last_pose, s->curr_pose, 64);               // :245 (LAST aliases the metric depth when preprocess == 0)
     if (s->ev_ok && timed) s->ev_frames++;
     s->tick++;
+    if (s->overlap_capable && hipEventRecord(s->ev_done[s->plane_set], s->stream) == hipSuccess) s->ev_done_valid[s->plane_set] = true;
 }
 
 // SurfelMapping::processFrame body (src/SurfelMapping.cpp:130-251); enqueue only.
@@ -636,12 +675,15 @@ int ensure_seg(sm_ctx *s, size_t n)
     return SM_OK;
 }
 
-int upload_inputs(sm_ctx *s, const uint8_t *rgb, const uint16_t *depth, const uint8_t *sem)
+// `for_frame`: the images are consumed by begin_frame's pre-processing, which runs on the second stream when
+// frames overlap; every other consumer is on the main stream
+int upload_inputs(sm_ctx *s, const uint8_t *rgb, const uint16_t *depth, const uint8_t *sem, bool for_frame = false)
 {
     const size_t P = (size_t)s->P;
-    if (rgb) HIPCK(hipMemcpyAsync(s->d_rgb, rgb, P * 3, hipMemcpyHostToDevice, s->stream));
-    if (depth) HIPCK(hipMemcpyAsync(s->d_depth_raw, depth, P * 2, hipMemcpyHostToDevice, s->stream));
-    if (sem) HIPCK(hipMemcpyAsync(s->d_sem, sem, P, hipMemcpyHostToDevice, s->stream));
+    hipStream_t st = (for_frame && s->overlap) ? s->stream2 : s->stream;
+    if (rgb) HIPCK(hipMemcpyAsync(s->d_rgb, rgb, P * 3, hipMemcpyHostToDevice, st));
+    if (depth) HIPCK(hipMemcpyAsync(s->d_depth_raw, depth, P * 2, hipMemcpyHostToDevice, st));
+    if (sem) HIPCK(hipMemcpyAsync(s->d_sem, sem, P, hipMemcpyHostToDevice, st));
     return SM_OK;
 }
 
@@ -725,6 +767,15 @@ sm_ctx *sm_create(const sm_config *c)
     const size_t nwords = (cap + 63) / 64 + TILE_WORDS, ntiles = (cap + TILE - 1) / TILE + 1;
     s->n_pix_blocks = (s->P + PIX_BLOCK - 1) / PIX_BLOCK;
     bool ok = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) == hipSuccess;
+    // Worth it only when the pre-processing is long (the depth filter chain, ~55 us at KITTI size): the cross-stream
+    // events cost ~8 us per frame, more than the bare metricise kernel they would hide.  Timed contexts keep one timeline.
+    s->overlap_capable = c->preprocess != 0 && !c->enable_timing && std::getenv("SM_NO_OVERLAP") == nullptr;
+    if (s->overlap_capable)
+        ok = ok && hipStreamCreateWithFlags(&s->stream2, hipStreamNonBlocking) == hipSuccess &&
+             hipEventCreateWithFlags(&s->ev_prep, hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&s->ev_main, hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&s->ev_done[0], hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&s->ev_done[1], hipEventDisableTiming) == hipSuccess;
     ok = ok && alloc_set(s->M.s[0], cap) == SM_OK;      // one SoA set: the compaction is in place
     ok = ok && dalloc(&s->d_state, 1) == SM_OK && dalloc(&s->d_log, FRAME_LOG_LEN) == SM_OK;
     ok = ok && hipHostMalloc((void **)&s->h_state, sizeof(DevState), hipHostMallocDefault) == hipSuccess;
@@ -734,6 +785,10 @@ sm_ctx *sm_create(const sm_config *c)
     ok = ok && dalloc(&s->d_depthT, P) == SM_OK && dalloc(&s->d_filteredT, P) == SM_OK && dalloc(&s->d_lastT, P) == SM_OK;
     ok = ok && dalloc(&s->d_rgbsT, P) == SM_OK && dalloc(&s->d_keyT, P) == SM_OK && dalloc(&s->d_dcT, P) == SM_OK &&
          hipMemset(s->d_dcT, 0, P * 8) == hipSuccess;
+    if (s->overlap_capable)
+        ok = ok && dalloc(&s->d_depthT_nx, P) == SM_OK && dalloc(&s->d_rgbsT_nx, P) == SM_OK && dalloc(&s->d_keyT_nx, P) == SM_OK &&
+             dalloc(&s->d_dcT_nx, P) == SM_OK && hipMemset(s->d_depthT_nx, 0, P * 4) == hipSuccess &&
+             hipMemset(s->d_rgbsT_nx, 0, P * 4) == hipSuccess && hipMemset(s->d_dcT_nx, 0, P * 8) == hipSuccess;
     ok = ok && dalloc(&s->d_rgb, P * 3) == SM_OK && dalloc(&s->d_sem, P) == SM_OK && dalloc(&s->d_depth_raw, P) == SM_OK;
     ok = ok && dalloc(&s->d_depth_f32, P) == SM_OK;
     ok = ok && dalloc(&s->d_xs, (size_t)s->W * 2) == SM_OK && dalloc(&s->d_ys, (size_t)s->H * 2) == SM_OK && dalloc(&s->d_wtab, (size_t)169) == SM_OK;
@@ -841,7 +896,13 @@ void sm_destroy(sm_ctx *s)
 {
     if (!s) return;
     (void)hipSetDevice(s->cfg.device);
+    if (s->stream2) (void)hipStreamSynchronize(s->stream2);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
+    (void)hipFree(s->d_depthT_nx); (void)hipFree(s->d_rgbsT_nx); (void)hipFree(s->d_keyT_nx); (void)hipFree(s->d_dcT_nx);
+    if (s->ev_prep) (void)hipEventDestroy(s->ev_prep);
+    if (s->ev_main) (void)hipEventDestroy(s->ev_main);
+    for (auto &e : s->ev_done) if (e) (void)hipEventDestroy(e);
+    if (s->stream2) (void)hipStreamDestroy(s->stream2);
     free_set(s->M.s[0]); free_set(s->M.s[1]);
     (void)hipFree(s->d_state); (void)hipFree(s->d_log);
     if (s->h_state) (void)hipHostFree(s->h_state);
@@ -878,6 +939,10 @@ int sm_process_frame_device(sm_ctx *s, const uint8_t *d_rgb, const uint16_t *d_d
     if (!s || !d_rgb || !pose16) { g_err = "sm_process_frame_device: null argument"; return SM_E_ARG; }
     HIPCK(hipSetDevice(s->cfg.device));
     // a null depth / semantic keeps the previous texture (src/SurfelMapping.cpp:124-128)
+    // asynchronous call: this frame's pre-processing may run ahead of the previous frame's tail -- unless the caller has
+    // waited for the device in between (then the main stream is idle and the cross-stream hand-off is pure overhead)
+    s->overlap = s->overlap_capable && !s->idle_hint;
+    s->idle_hint = false;
     return enqueue_frame(s, d_rgb, d_depth_mm ? d_depth_mm : s->d_depth_raw, d_semantic ? d_semantic : s->d_sem, pose16);
 }
 
@@ -885,7 +950,8 @@ int sm_process_frame(sm_ctx *s, const uint8_t *rgb, const uint16_t *depth_mm, co
 {
     if (!s || !rgb || !pose16) { g_err = "sm_process_frame: null argument (rgb and pose are required)"; return SM_E_ARG; }
     HIPCK(hipSetDevice(s->cfg.device));
-    int rc = upload_inputs(s, rgb, depth_mm, semantic);
+    s->overlap = false;                          // the caller waits for the result: nothing to overlap with
+    int rc = upload_inputs(s, rgb, depth_mm, semantic, true);
     if (rc) return rc;
     rc = enqueue_frame(s, s->d_rgb, s->d_depth_raw, s->d_sem, pose16);
     if (rc) return rc;
@@ -1383,7 +1449,8 @@ int sm_shard_begin_frame(sm_ctx *s, const uint8_t *rgb, const uint16_t *depth_mm
     if (!s || !rgb || !pose16) return SM_E_ARG;
     HIPCK(hipSetDevice(s->cfg.device));
     if (s->sh_in_frame) { g_err = "sm_shard_begin_frame: previous frame not finished (sm_shard_append)"; return SM_E_ARG; }
-    int rc = upload_inputs(s, rgb, depth_mm, semantic);
+    s->overlap = false;
+    int rc = upload_inputs(s, rgb, depth_mm, semantic, true);
     if (rc) return rc;
     FrameParams fp;
     rc = begin_frame(s, s->d_rgb, s->d_depth_raw, s->d_sem, pose16, &fp);

@@ -256,6 +256,32 @@ def test_preprocess_chain_kitti_size():
     assert o.counts()["count"] > 100000
 
 
+def test_async_frames_overlap_the_depth_filter_chain():
+    """With preprocess=1 the asynchronous entry point runs frame f+1's pre-processing on a second stream while frame f
+    is still associating (double-buffered frame planes); synchronous and asynchronous calls may be mixed."""
+    cam = dict(width=320, height=120, fx=180.0, fy=180.0, cx=159.5, cy=59.5)
+    seq = moving_boxes_sequence(cam, 14, seed=33)
+    o, h = pair(cam, preprocess=1, stereo_border=20.0, max_sqrt_vertices=600)
+    P = cam["width"] * cam["height"]
+    bufs = []
+    for rgb, d, s, p in seq:
+        dr, dd, ds = h.device_alloc(P * 3), h.device_alloc(P * 2), h.device_alloc(P)
+        h.device_upload(dr, rgb); h.device_upload(dd, d); h.device_upload(ds, s)
+        bufs.append((dr, dd, ds, p))
+    for k, fr in enumerate(seq):
+        o.process_frame(*fr)
+        if k in (4, 9):
+            h.process_frame(*fr)                    # synchronous call in between: its chain runs on the main stream
+            check_depth_textures(o, h, f"frame {k}")
+        else:
+            h.process_frame_device(*bufs[k])        # enqueue only
+        if k in (6, 13):
+            h.sync()
+            check_depth_textures(o, h, f"frame {k}")
+            check(o, h, f"frame {k}")
+    assert o.counts()["count"] > 5000
+
+
 def test_fused_associate_append_variant_matches_oracle():
     """SM_FUSED_ASSOC=1 selects the single-kernel association+append (decoupled look-back); it is not the
     default (measured slower) but must stay bit-exact."""
