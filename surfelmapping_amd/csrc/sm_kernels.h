@@ -55,6 +55,57 @@ __device__ __forceinline__ uint32_t tile_flags_one(uint32_t t, const FrameParams
     return f;
 }
 
+// The same flags for the next (up to) 64 tiles of a workgroup, corner-parallel: the 8 box corners of a tile go to 8
+// lanes (one transform per lane instead of eight), 8 tiles per wave and pass, 32 per workgroup and pass -- a workgroup
+// rarely owns more than a handful of tiles per batch, and the per-lane form above made every wave pay the full
+// 8-corner evaluation for them (it was 44 % of k_conflict's VALU instructions at KITTI size).  Results go to s_flags[64]
+// (entry b <-> tile first + b*stride); the caller synchronises before reading them.
+__device__ __forceinline__ void tile_flags_batch(uint32_t first, uint32_t stride, uint32_t ntiles, const FrameParams &fp,
+                                                 const uint32_t *__restrict__ tb, uint8_t *s_flags)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane >> 3, c = lane & 7;                       // tile within the pass, corner
+    const uint64_t nb64 = first < ntiles ? ((uint64_t)(ntiles - first) + stride - 1) / stride : 0;
+    const uint32_t nb = (uint32_t)(nb64 < 64 ? nb64 : 64);        // tiles in this batch
+    for (uint32_t pass = 0; pass * 32u < nb; ++pass) {            // workgroup-uniform
+        const uint32_t b = pass * 32u + (uint32_t)wave * 8u + (uint32_t)j;
+        const bool in = b < nb;
+        const uint32_t t = in ? first + b * stride : first;
+        const uint32_t *bd = tb + (size_t)t * 8;
+        const uint32_t b0 = bd[0], b1 = bd[1], b2 = bd[2], b3 = bd[3], b4 = bd[4], b5 = bd[5], b6 = bd[6], b7 = bd[7];
+        const float3 p = xform3(fp.t_inv, (c & 1) ? ord2f(b4) : ord2f(~b0), (c & 2) ? ord2f(b5) : ord2f(~b1),
+                                (c & 4) ? ord2f(b6) : ord2f(~b2));
+        const bool fin = (p.x - p.x == 0.0f) && (p.y - p.y == 0.0f) && (p.z - p.z == 0.0f);
+        const bool r_ = fp.fx * p.x + (fp.cx - fp.cols - 2.0f) * p.z > 0.0f;
+        const bool lc = fp.fx * p.x + (fp.cx - fp.stereo_border + 2.0f) * p.z < 0.0f;
+        const bool ls = fp.fx * p.x + (fp.cx + 2.0f) * p.z < 0.0f;
+        const bool be = fp.fy * p.y + (fp.cy - fp.rows - 2.0f) * p.z > 0.0f;
+        const bool ab = fp.fy * p.y + (fp.cy + 2.0f) * p.z < 0.0f;
+        float zmin = p.z, zmax = p.z;
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) { zmin = fminf(zmin, __shfl_xor(zmin, o)); zmax = fmaxf(zmax, __shfl_xor(zmax, o)); }
+        const int sh = j * 8;                                      // "all 8 corners" = the tile's byte of the ballot is 0xFF
+        const bool finite = ((__ballot(fin) >> sh) & 0xFFull) == 0xFFull;
+        const bool right = ((__ballot(r_) >> sh) & 0xFFull) == 0xFFull, left_c = ((__ballot(lc) >> sh) & 0xFFull) == 0xFFull;
+        const bool left_s = ((__ballot(ls) >> sh) & 0xFFull) == 0xFFull, below = ((__ballot(be) >> sh) & 0xFFull) == 0xFFull;
+        const bool above = ((__ballot(ab) >> sh) & 0xFFull) == 0xFFull;
+        uint32_t f = 0;
+        if (fp.use_bounds && b3 == 0u) {
+            if (b0 == 0u && b4 == 0u) {
+                f = 3u;                                            // no surfel recorded at all
+            } else if (finite) {
+                const bool front = zmin > 1.0e-3f;
+                if (zmax < fp.min_depth - 0.01f || zmin > fp.max_depth + 0.01f || (front && (right || left_c || below || above))) f |= 1u;
+                if (zmax < -0.01f || zmin > fp.depth_cutoff + 0.01f || (front && (right || left_s || below || above)) ||
+                    (float)fp.time - ord2f(b7) > (float)fp.time_delta)
+                    f |= 2u;
+            }
+        }
+        if (in && c == 0) s_flags[b] = (uint8_t)f;
+    }
+    for (uint32_t b = nb + threadIdx.x; b < 64u; b += blockDim.x) s_flags[b] = 0;     // beyond the last tile
+}
+
 // ---------------------------------------------------------------------------------------------
 // p0a metricise (depth_metric.frag:15-35) + u8 RGB/semantic pack + LDS-tiled transpose to the
 // column-major frame layout + key-map clear.  32x32 pixel tile per 1024-thread workgroup.
@@ -273,6 +324,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SM_CONFLICT
 {
     __shared__ uint32_t s_red[4][3];
     __shared__ uint64_t s_m[3][TILE_WORDS];
+    __shared__ uint8_t s_flags[64];
     const uint32_t N = st->count;
     const bool has_dead = st->garbage != 0u;          // slots of surfels killed since the last physical compaction
     const uint32_t exempt = fp.world > 1 ? fp.exempt_local : st->first_live;   // the surfel with (global) id 0
@@ -286,14 +338,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SM_CONFLICT
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x, ++iter) {
         uint32_t nconf = 0, nkill = 0, nzero = 0;
         if ((iter & 63u) == 0u) {
-            // the skip flags of this workgroup's next 64 tiles, one tile per lane: bit 0 stays in the ballot mask,
-            // bit 1 (splat) is stored for k_compact
+            // the skip flags of this workgroup's next 64 tiles (corner-parallel, via LDS): bit 0 stays in a ballot mask,
+            // bit 1 (splat) is stored for the cull kernel
+            __syncthreads();
+            tile_flags_batch(tile, gridDim.x, ntiles, fp, tb, s_flags);
+            __syncthreads();
             const uint64_t tl = (uint64_t)tile + (uint64_t)lane * gridDim.x;
-            uint32_t f = 0;
-            if (tl < ntiles) {
-                f = tile_flags_one((uint32_t)tl, fp, tb);
-                if (wave == 0) tile_flags[tl] = (uint8_t)f;
-            }
+            const uint32_t f = s_flags[lane];
+            if (wave == 0 && tl < ntiles) tile_flags[tl] = (uint8_t)f;
             skipmask = __ballot((f & 1u) != 0u);
         }
         // whole tile outside the conflict view volume (conflict.vert:35)?  Then nothing conflicts, and a tile
