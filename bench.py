@@ -303,9 +303,9 @@ def main():
                 "ms_per_launch": kern[dom]["ms"], "alg_bytes_per_launch": kern[dom]["MB"] * 1e6,
                 "launches": launches[dom],
                 "valu_issue_util": valu,
-                "note": "the surfel kernels sit nearer their VALU issue limit than the HBM roof: IEEE-exact fp32 "
-                        "(correctly rounded / and sqrt, no FMA contraction) costs ~250 VALU instructions per surfel "
-                        "(DESIGN.md 4, profiles/ SQ pass)"}
+                "note": "not byte-bound: a frame touches ~100 MB; the surfel kernels are limited by instruction issue "
+                        "(IEEE-exact fp32: ~200 VALU instructions per surfel, correctly rounded / and sqrt) and by the "
+                        "chain of dependent round trips of a launch that owns ~1 tile per workgroup (DESIGN.md 4)"}
 
     # ---- CPU baseline: the oracle over the very same frames (rank 0, N=1 only)
     cpu = None
