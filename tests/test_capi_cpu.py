@@ -36,6 +36,30 @@ def test_config_struct_matches_header_defaults():
     assert c.conflict_cap == 1 and c.device == 0
 
 
+def test_ctypes_mirrors_have_the_header_layout(tmp_path):
+    """The ctypes structures of surfelmapping_amd/capi.py against the C compiler's view of include/sm_c_api.h:
+    same size and the same offset for every field."""
+    import subprocess
+    from surfelmapping_amd import capi
+    mirrors = {"sm_config": capi.SmConfig, "sm_counts": capi.SmCounts, "sm_timings": capi.SmTimings}
+    lines = []
+    for cname, cls in mirrors.items():
+        lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')
+        for fname, _ in cls._fields_:
+            lines.append(f'printf("{cname}.{fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines.append('printf("sm_frame_log %zu\\n", sizeof(sm_frame_log));')
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "sm_c_api.h"\nint main(void) {\n' + "\n".join(lines) + "\nreturn 0; }\n")
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(src)])
+    got = dict(l.split() for l in subprocess.check_output([str(exe)]).decode().splitlines())
+    for cname, cls in mirrors.items():
+        assert int(got[cname]) == C.sizeof(cls), cname
+        for fname, _ in cls._fields_:
+            assert int(got[f"{cname}.{fname}"]) == getattr(cls, fname).offset, f"{cname}.{fname}"
+    assert int(got["sm_frame_log"]) == capi.FRAME_LOG_DTYPE.itemsize
+
+
 def test_null_arguments_are_rejected_without_touching_the_gpu():
     from surfelmapping_amd import capi
     L = capi.load()
