@@ -116,9 +116,11 @@ __global__ __launch_bounds__(1024) void k_prep(const uint8_t *__restrict__ rgb,
                                                const float *__restrict__ depth_f32,  // optional: metric depth given directly
                                                float *__restrict__ depthT, uint32_t *__restrict__ rgbsT,
                                                uint64_t *__restrict__ keyT, FrameParams fp,
-                                               uint2 *__restrict__ dcT /* (depth bits, rgbs) per pixel: one 8-byte gather for the conflict test */)
+                                               uint2 *__restrict__ dcT /* (depth bits, rgbs) per pixel: one 8-byte gather for the conflict test */,
+                                               uint32_t *__restrict__ conf_sub /* this frame's 64 conflict sub-counters, or null */)
 {
     __shared__ float s_d[32][33];
+    if (conf_sub && blockIdx.x == 0 && threadIdx.x < 64) conf_sub[threadIdx.x] = 0u;
     __shared__ uint32_t s_c[32][33];
     const int W = fp.W, H = fp.H;
     const int tiles_x = (W + 31) >> 5;
@@ -320,7 +322,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SM_CONFLICT
                                                   uint64_t *__restrict__ zm, uint32_t *__restrict__ tile_cnt,
                                                   const uint32_t *__restrict__ tb, uint8_t *__restrict__ tile_flags,
                                                   uint32_t *__restrict__ blk_part /* [grid][4]: skipped, nconf, nkill, - */,
-                                                  const uint64_t *__restrict__ alive)
+                                                  const uint64_t *__restrict__ alive,
+                                                  uint32_t *__restrict__ conf_sub /* 64 sub-counters of the frame's conflicts (zeroed by k_prep) */)
 {
     __shared__ uint32_t s_red[4][3];
     __shared__ uint64_t s_m[3][TILE_WORDS];
@@ -444,7 +447,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SM_CONFLICT
     }
     // per-workgroup partials, summed by k_cull_finalize (no same-address atomics)
     if (threadIdx.x < 2) blk_part[blockIdx.x * 4 + 1 + threadIdx.x] = acc;
-    if (threadIdx.x == 0) blk_part[blockIdx.x * 4] = skipped;
+    if (threadIdx.x == 0) {
+        blk_part[blockIdx.x * 4] = skipped;
+        // the conflict total in a form the next kernel can read in one instruction: 64 counters, <= 32 adders each
+        if (acc) atomicAdd(&conf_sub[blockIdx.x & 63u], acc);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1045,6 +1052,214 @@ __global__ __launch_bounds__(256) void k_cull_lazy(Model M, const DevState *__re
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_cull_lazy for the frame path with the finalize step folded in (one launch fewer on 7 of 8 frames).  A cull that
+// only marks the dead needs nothing global except "does the W*H conflict cap bind?", which every wave reads from the
+// 64 conflict sub-counters k_conflict maintains (one load per lane + a wave reduction).  One extra workgroup (the last
+// of the grid, no tiles) publishes DevState; the number of kills is only known when all workgroups are done, so it
+// travels as a third per-workgroup partial to the append kernel, which completes DevState::garbage / n_kill.
+// DevState fields the workers read (count, cur) are not changed by a lazy cull.  If the cap binds (rare) each
+// workgroup rebuilds the "first W*H conflicts" rule from prefix sums of the tile counts.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_cull_lazy_frame(Model M, DevState *__restrict__ st, FrameParams fp,
+                                                         const uint64_t *__restrict__ cm, const uint64_t *__restrict__ dm,
+                                                         const uint64_t *__restrict__ zm, const uint32_t *__restrict__ tile_cnt,
+                                                         uint64_t *__restrict__ keyT, const uint8_t *__restrict__ tile_flags,
+                                                         uint4 *__restrict__ blk_part /* [workers] (visible, splat-skipped, killed, -) */,
+                                                         uint64_t *__restrict__ alive, uint32_t *__restrict__ tile_dead,
+                                                         const uint32_t *__restrict__ conf_part, uint32_t n_conf_part,
+                                                         const uint32_t *__restrict__ conf_sub,
+                                                         unsigned long long *__restrict__ host_stat)
+{
+    __shared__ uint32_t s_a[4], s_b[4], s_c[4];
+    __shared__ uint32_t s_fl;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t nwg = gridDim.x - 1u;               // workers; workgroup 0 (dispatched first) publishes
+    const bool publisher = blockIdx.x == 0u;
+    const uint32_t wi = blockIdx.x - 1u;               // worker index
+    uint32_t ctotal = conf_sub[lane];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ctotal += __shfl_xor(ctotal, o);
+    const uint32_t N = st->count;                      // occupied slots: unchanged by this cull
+    const SurfelSet set = M.s[st->cur];
+    const uint32_t ntiles = (N + TILE - 1) / TILE;
+    const uint32_t cap = fp.conflict_cap;
+    const bool cap_binds = ctotal > cap;
+    if (publisher) {
+        const uint32_t g0 = st->garbage, old_first = st->first_live;
+        uint32_t cskip = 0;
+        for (uint32_t b = threadIdx.x; b < n_conf_part; b += 256u) cskip += conf_part[(size_t)b * 4];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) cskip += __shfl_xor(cskip, o);
+        if (lane == 0) s_a[wave] = cskip;
+        if (threadIdx.x == 0) s_fl = 0xFFFFFFFFu;
+        __syncthreads();
+        const uint32_t cskip_tot = s_a[0] + s_a[1] + s_a[2] + s_a[3];
+        // slot of the first live surfel after this cull (the reference's id 0): unchanged if that surfel survives
+        uint32_t first_live = N;
+        bool keep_first = false;
+        if (old_first < N) {
+            const uint32_t w = old_first / 64u, bit = old_first % 64u;
+            keep_first = !(((zm[w] | (cm[w] & dm[w])) >> bit) & 1ull);     // all conflicts counted: conservative under the cap
+        }
+        if (keep_first) {
+            first_live = old_first;
+        } else if (N) {
+            // search upwards from its tile, 16 tiles (256 words) per round; under a binding cap the allowance of a
+            // tile needs the conflicts of all tiles below it
+            const uint32_t t0 = min(old_first, N - 1u) / TILE;
+            uint32_t before = 0;
+            if (cap_binds) {
+                uint32_t part = 0;
+                for (uint32_t t = threadIdx.x; t < t0; t += 256u) part += tile_cnt[t * 3];
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+                if (lane == 0) s_c[wave] = part;
+                __syncthreads();
+                before = s_c[0] + s_c[1] + s_c[2] + s_c[3];
+                __syncthreads();
+            }
+            for (uint32_t base = t0; base < ntiles; base += 16u) {
+                const uint32_t t = base + (threadIdx.x >> 4);
+                const int w = (int)(threadIdx.x & 15u);
+                if (t < ntiles) {
+                    const uint32_t nconf = tile_cnt[t * 3];
+                    uint32_t allow = nconf;
+                    if (cap_binds) {
+                        uint32_t pre = before;
+                        for (uint32_t x = base; x < t; ++x) pre += tile_cnt[x * 3];
+                        allow = pre >= cap ? 0u : min(nconf, cap - pre);
+                    }
+                    const uint64_t k = keep_word(t, w, N, cm, dm, zm, alive, allow, nconf);
+                    if (k) atomicMin(&s_fl, (t * TILE_WORDS + (uint32_t)w) * 64u + (uint32_t)(__ffsll((long long)k) - 1));
+                }
+                __syncthreads();
+                const uint32_t found = s_fl;
+                if (cap_binds && wave == 0) {          // advance the running conflict prefix by this round's 16 tiles
+                    uint32_t add = 0;
+                    if (lane < 16 && base + (uint32_t)lane < ntiles) add = tile_cnt[(base + (uint32_t)lane) * 3];
+#pragma unroll
+                    for (int o = 8; o > 0; o >>= 1) add += __shfl_xor(add, o);
+                    if (lane == 0) s_c[0] = add;
+                }
+                __syncthreads();
+                if (cap_binds) before += s_c[0];
+                __syncthreads();
+                if (found != 0xFFFFFFFFu) { first_live = found; break; }
+            }
+        }
+        if (threadIdx.x == 0) {
+            st->n_conf_skipped = cskip_tot;
+            st->n_static = N;
+            st->conflict_count = min(ctotal, cap);
+            if (fp.splat_follows) st->visible_count = 0;
+            st->cull_n = N;
+            st->cull_src = st->cur;
+            st->cull_dst = st->cur;
+            st->garbage_prev = g0;
+            st->cap_binds = cap_binds ? 1u : 0u;
+            st->do_compact = 0u;
+            st->first_live = first_live;
+            st->offset = N;                             // the dead keep their slots until the next compaction
+            if (host_stat)
+                __hip_atomic_store(host_stat, ((unsigned long long)st->stat_frames << 32) | (unsigned long long)N, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        return;
+    }
+    // conflicts in all tiles below this workgroup's first one (only needed when the cap binds)
+    uint32_t cpre = 0;
+    if (cap_binds) {
+        uint32_t part = 0;
+        for (uint32_t t = threadIdx.x; t < min(wi, ntiles); t += 256u) part += tile_cnt[t * 3];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+        if (lane == 0) s_c[wave] = part;
+        __syncthreads();
+        cpre = s_c[0] + s_c[1] + s_c[2] + s_c[3];
+        __syncthreads();
+    }
+    // ---- the cull proper (as k_cull_lazy<true>)
+    uint32_t vis = 0, skipped = 0, killed_wg = 0, iter = 0;
+    uint64_t skipmask = 0;
+    uint32_t m_nconf = 0, m_nkill = 0, m_dead = 0;
+    for (uint32_t tile = wi; tile < ntiles; tile += nwg, ++iter) {
+        if ((iter & 63u) == 0u) {                    // metadata of this workgroup's next 64 tiles, one per lane
+            const uint64_t tl = (uint64_t)tile + (uint64_t)lane * nwg;
+            const bool in = tl < ntiles;
+            const uint32_t tt = in ? (uint32_t)tl : 0u;
+            skipmask = __ballot(in && (tile_flags[tt] & 2u));
+            m_nconf = tile_cnt[tt * 3]; m_nkill = tile_cnt[tt * 3 + 1];
+            m_dead = tile_dead[tt];
+        }
+        const int sl = (int)(iter & 63u);
+        const uint32_t nconf = (uint32_t)__shfl((int)m_nconf, sl), nkill = (uint32_t)__shfl((int)m_nkill, sl);
+        const uint32_t tdead = (uint32_t)__shfl((int)m_dead, sl);
+        const uint32_t tn = min((uint32_t)TILE, N - tile * TILE);
+        uint32_t allow = nconf;
+        if (cap_binds) {                             // workgroup-uniform
+            allow = cpre >= cap ? 0u : min(nconf, cap - cpre);
+            uint32_t part = 0;                       // conflicts of the tiles up to this workgroup's next one
+            for (uint32_t t = tile + threadIdx.x; t < min(tile + nwg, ntiles); t += 256u) part += tile_cnt[t * 3];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+            __syncthreads();
+            if (lane == 0) s_c[wave] = part;
+            __syncthreads();
+            cpre += s_c[0] + s_c[1] + s_c[2] + s_c[3];
+        }
+        const bool touched = nconf != 0u || nkill != 0u;                                  // workgroup-uniform
+        const bool nosplat = ((skipmask >> (iter & 63u)) & 1ull) != 0ull;                // box outside the index map's view
+        if (nosplat) skipped += tn;
+        if (!touched && nosplat) continue;                                                // the bulk of the map: not even read
+        float4 pv[4];
+        float pt[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {                // unconditional, clamped: all loads of the lane in flight together
+            const uint32_t kc = min((tile * TILE_WORDS + r * 4 + wave) * 64u + lane, N - 1u);
+            pv[r] = set.pos_conf[kc];
+            pt[r] = nosplat ? 0.0f : set.time[kc];
+        }
+        uint32_t killed = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int w = r * 4 + wave;
+            const uint32_t word = tile * TILE_WORDS + (uint32_t)w;
+            const uint32_t k = word * 64u + lane;
+            const uint64_t base = (uint64_t)word * 64u;
+            uint64_t range = 0ull;
+            if (base < N) { const uint64_t rem = (uint64_t)N - base; range = rem >= 64 ? ~0ull : ((1ull << rem) - 1ull); }
+            const uint64_t valid = range & ((tdead != 0u) ? alive[word] : ~0ull);
+            uint64_t keep = valid, ce = 0ull;
+            if (touched) {
+                ce = cm[word];
+                if (allow != nconf) {                // the conflict cap binds inside this tile: only its first `allow` conflicts count
+                    uint32_t before = 0;
+                    for (int x = 0; x < w; ++x) before += (uint32_t)__popcll(cm[tile * TILE_WORDS + x]);
+                    ce = before >= allow ? 0ull : first_n_bits(ce, allow - before);
+                }
+                keep = ~(zm[word] | (ce & dm[word])) & valid;
+                if (keep != valid && lane == 0) alive[word] = keep | ~range;            // the dead keep their slots
+                killed += (uint32_t)__popcll(valid ^ keep);
+            }
+            const bool kp = (keep >> lane) & 1ull;
+            if (kp && ((ce >> lane) & 1ull)) set.pos_conf[k].w = pv[r].w - 1.0f;       // conflict.vert:72
+            if (!nosplat) {                                                              // workgroup-uniform
+                bool drew = false;
+                if (kp) drew = splat_one(fp, pv[r].x, pv[r].y, pv[r].z, pt[r], k, keyT);
+                vis += (uint32_t)__popcll(__ballot(drew));
+            }
+        }
+        if (killed && lane == 0) atomicAdd(&tile_dead[tile], killed);
+        killed_wg += killed;
+    }
+    __syncthreads();
+    if (lane == 0) { s_a[wave] = vis; s_b[wave] = killed_wg; }
+    __syncthreads();
+    if (threadIdx.x == 0)
+        blk_part[wi] = make_uint4(s_a[0] + s_a[1] + s_a[2] + s_a[3], skipped, s_b[0] + s_b[1] + s_b[2] + s_b[3], 0u);
+}
+
 // standalone p6 (IndexMap::predictIndices) over the current model
 __global__ __launch_bounds__(256) void k_splat(Model M, DevState *__restrict__ st, FrameParams fp,
                                                uint64_t *__restrict__ keyT, const uint32_t *__restrict__ seg_lstart,
@@ -1509,10 +1724,11 @@ __global__ __launch_bounds__(PIX_BLOCK) void k_append_scan(Model M, DevState *__
                                                            uint32_t *__restrict__ tb, const uint2 *__restrict__ compact_part,
                                                            uint32_t n_compact_part, uint64_t *__restrict__ alive,
                                                            uint32_t *__restrict__ tile_dead,
-                                                           unsigned long long *__restrict__ host_stat)
+                                                           unsigned long long *__restrict__ host_stat,
+                                                           const uint4 *__restrict__ lazy_part /* k_cull_lazy_frame's partials (then compact_part is unused) */)
 {
     __shared__ uint32_t s_red[2][4];
-    __shared__ uint32_t s_cp[2][4];
+    __shared__ uint32_t s_cp[3][4];
     const SurfelSet cur = M.s[st->cur];
     const uint32_t offset = st->offset;
     const uint32_t garbage = st->garbage, garbage_prev = st->garbage_prev, n_slots = st->cull_n;
@@ -1530,12 +1746,15 @@ __global__ __launch_bounds__(PIX_BLOCK) void k_append_scan(Model M, DevState *__
         if (b < (int)blockIdx.x) pn += c.x;
         if (last) { pf += c.y; tn += c.x; }
     }
-    uint32_t cv = 0, cs = 0;                                      // visible / splat-skipped partials of k_compact
+    uint32_t cv = 0, cs = 0, ck = 0;                              // visible / splat-skipped (/ killed) partials of the cull kernel
     if (last) {
-        for (uint32_t b = threadIdx.x; b < n_compact_part; b += PIX_BLOCK) { const uint2 c = compact_part[b]; cv += c.x; cs += c.y; }
+        if (lazy_part)
+            for (uint32_t b = threadIdx.x; b < n_compact_part; b += PIX_BLOCK) { const uint4 c = lazy_part[b]; cv += c.x; cs += c.y; ck += c.z; }
+        else
+            for (uint32_t b = threadIdx.x; b < n_compact_part; b += PIX_BLOCK) { const uint2 c = compact_part[b]; cv += c.x; cs += c.y; }
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { cv += __shfl_xor(cv, o); cs += __shfl_xor(cs, o); }
-        if (lane == 0) { s_cp[0][wave] = cv; s_cp[1][wave] = cs; }
+        for (int o = 32; o > 0; o >>= 1) { cv += __shfl_xor(cv, o); cs += __shfl_xor(cs, o); ck += __shfl_xor(ck, o); }
+        if (lane == 0) { s_cp[0][wave] = cv; s_cp[1][wave] = cs; s_cp[2][wave] = ck; }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { pn += __shfl_xor(pn, o); pf += __shfl_xor(pf, o); tn += __shfl_xor(tn, o); }
@@ -1550,6 +1769,13 @@ __global__ __launch_bounds__(PIX_BLOCK) void k_append_scan(Model M, DevState *__
         if (n_compact_part) {
             st->visible_count = s_cp[0][0] + s_cp[0][1] + s_cp[0][2] + s_cp[0][3];
             st->n_splat_skipped = s_cp[1][0] + s_cp[1][1] + s_cp[1][2] + s_cp[1][3];
+        }
+        uint32_t garbage_now = garbage;
+        if (lazy_part) {                          // the cull folded its finalize step in: complete the kill bookkeeping
+            const uint32_t killed = s_cp[2][0] + s_cp[2][1] + s_cp[2][2] + s_cp[2][3];
+            garbage_now = garbage_prev + killed;
+            st->garbage = garbage_now;
+            st->n_kill = killed;
         }
         st->unstable_count = ntot;
         st->fused_count = ftot;
@@ -1571,7 +1797,7 @@ __global__ __launch_bounds__(PIX_BLOCK) void k_append_scan(Model M, DevState *__
         }
         if (fp.log_frame && log) {
             FrameLog e;
-            e.tick = (uint32_t)fp.time; e.n_before = n_slots - garbage_prev; e.n_after_cull = offset - garbage; e.n_kill = st->n_kill;
+            e.tick = (uint32_t)fp.time; e.n_before = n_slots - garbage_prev; e.n_after_cull = offset - garbage_now; e.n_kill = st->n_kill;
             e.conflict_count = st->conflict_count; e.visible_count = st->visible_count;
             e.fused_count = ftot; e.unstable_count = ntot; e.n_static = st->n_static;
             e.n_conf_skipped = st->n_conf_skipped; e.n_splat_skipped = st->n_splat_skipped; e.n_slots = n_slots;
