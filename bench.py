@@ -280,7 +280,8 @@ def main():
     moved = log["n_static"] < log["n_slots"] if len(log) else np.zeros(0, bool)
     n_comp = int(tim.get("frames_compact", 0)) if sm_ev is not None else int(moved.sum())
     for name, ms, sel, n in (("k_compact", tim.get("k_compact_own", 0.0), moved, n_comp),
-                             ("k_cull_lazy", tim.get("k_cull_lazy", 0.0), ~moved, K - n_comp)):
+                             # (the lazy cull runs with its finalize step folded in unless the depth filter chain is on)
+                             ("k_cull_lazy" if args.preprocess else "k_cull_lazy_frame", tim.get("k_cull_lazy", 0.0), ~moved, K - n_comp)):
         mb = float(cull_b[sel].mean()) / 1e6 if sel.any() else 0.0
         kern[name] = {"ms": ms, "MB": mb, "GBs": (mb / 1e3) / (ms * 1e-3) if ms > 0 else None, "launches": n}
         launches[name] = n
