@@ -153,6 +153,7 @@ struct sm_ctx {
     uint32_t *d_tile_dead = nullptr;   // dead slots per tile
     size_t alive_words = 0, dead_tiles = 0;
     bool maybe_garbage = false;        // a deferred-compaction cull ran since the last physical compaction
+    bool keys_are_slots = false;       // the key map was drawn by a cull that did not compact: its ids are slot numbers
     int culls_since_compact = 0;       // deferred-compaction schedule (host side: it picks the kernels)
     uint32_t frames_enq = 0;           // appends enqueued so far (compared with the tag of *h_stat)
     unsigned long long *h_stat = nullptr, *d_stat = nullptr;   // pinned, device-written: frames<<32 | occupied slots
@@ -482,8 +483,10 @@ int ensure_compact(sm_ctx *s)
     hipLaunchKernelGGL(k_cull_finalize, dim3(1), dim3(1024), 0, s->stream, s->d_state, fp, s->d_cm, s->d_dm, s->d_zm,
                        s->d_tile_cnt, s->d_tile_allow, s->d_tile_keep, s->d_group_tot, s->d_group_base, s->d_conf_part, 0u,
                        s->d_alive, s->d_tile_dead, s->d_stat);
-    hipLaunchKernelGGL(k_remap_keys, dim3((s->P + 255) / 256), dim3(256), 0, s->stream, s->d_state, s->d_keyT, s->P, s->d_alive,
-                       s->d_tile_keep, s->d_group_base);
+    if (s->keys_are_slots)     // ids of the index map: slot -> position among the live surfels, as the API hands them out
+        hipLaunchKernelGGL(k_remap_keys, dim3((s->P + 255) / 256), dim3(256), 0, s->stream, s->d_state, s->d_keyT, s->P, s->d_alive,
+                           s->d_tile_keep, s->d_group_base);
+    s->keys_are_slots = false;
     HIPCK(hipGetLastError());
     const uint32_t keep_part = s->n_compact_part;
     int rc = launch_compact(s, fp, false, false);
@@ -559,6 +562,28 @@ int launch_associate(sm_ctx *s, const FrameParams &fp, bool timed)
     return launch_append(s, fp, timed);
 }
 
+int rebuild_bounds(sm_ctx *s, uint32_t first_surfel, uint32_t count);
+
+// empty the model on the device (reset path; synchronises)
+int discard_model(sm_ctx *s)
+{
+    int rc = pull_state(s);
+    if (rc) return rc;
+    if (s->h_state->count == 0 && !s->maybe_garbage && s->h_state->conflict_count == 0 && s->h_state->visible_count == 0) return SM_OK;
+    if (s->maybe_garbage) {
+        HIPCK(hipMemsetAsync(s->d_alive, 0xFF, s->alive_words * 8, s->stream));
+        HIPCK(hipMemsetAsync(s->d_tile_dead, 0, s->dead_tiles * 4, s->stream));
+        s->maybe_garbage = false;
+    }
+    s->culls_since_compact = 0;
+    DevState &d = *s->h_state;
+    d.count = 0; d.offset = 0; d.garbage = 0; d.garbage_prev = 0; d.first_live = 0; d.do_compact = 0;
+    d.conflict_count = 0; d.visible_count = 0;      // no conflict pass, no index map in the initialising frame
+    if ((rc = push_state(s))) return rc;
+    if ((rc = rebuild_bounds(s, 0, 0))) return rc;
+    return pull_state(s);
+}
+
 void bump_bound(sm_ctx *s)
 {
     s->count_bound = (uint32_t)std::min<uint64_t>((uint64_t)s->count_bound + s->n_odd_pixels, s->cap);
@@ -580,13 +605,17 @@ int begin_frame(sm_ctx *s, const uint8_t *d_rgb, const uint16_t *d_raw, const ui
     if ((rc = mark(s, 8, fusing))) return rc;    // back-to-back pair 8 -> 0: the cost of an event record itself
     if ((rc = mark(s, 0, fusing))) return rc;
     hipStream_t ps = s->stream;
+    // The reference frame and the frame after reset() do not draw the index map: its textures keep what the last
+    // predictIndices left (src/SurfelMapping.cpp:142-169), so the key map is neither cleared nor exchanged then.
+    const bool will_splat = fusing;
     // frame parity: the conflict sub-counters (and, where a second stream exists, the frame planes) alternate between two
     // sets, so that the pre-processing of frame f+1 never touches what frame f still reads
     s->plane_set ^= 1;
     s->conf_sub_set = s->plane_set;
     if (s->overlap_capable) {
         std::swap(s->d_depthT, s->d_depthT_nx); std::swap(s->d_rgbsT, s->d_rgbsT_nx);
-        std::swap(s->d_keyT, s->d_keyT_nx); std::swap(s->d_dcT, s->d_dcT_nx);
+        std::swap(s->d_dcT, s->d_dcT_nx);
+        if (will_splat) std::swap(s->d_keyT, s->d_keyT_nx);
     }
     if (s->overlap) {
         // this frame's set is the one the frame before the previous one used: wait until that frame is through
@@ -596,7 +625,7 @@ int begin_frame(sm_ctx *s, const uint8_t *d_rgb, const uint16_t *d_raw, const ui
         if (s->chain_on_main) { HIPCK(hipStreamWaitEvent(ps, s->ev_main, 0)); s->chain_on_main = false; }
     }
     // metriciseDepth (+ filterDepth when preprocess=1)   src/SurfelMapping.cpp:136-139
-    if ((rc = launch_prep(s, d_rgb, d_raw, d_sem, nullptr, fp, true, ps))) return rc;
+    if ((rc = launch_prep(s, d_rgb, d_raw, d_sem, nullptr, fp, will_splat, ps))) return rc;
     const int pblocks = (s->P + 255) / 256;
     if (s->cfg.preprocess) {                              // filterDepth src/SurfelMapping.cpp:269-334
         const int stiles = ((s->W + 31) / 32) * ((s->H + 31) / 32);
@@ -645,6 +674,10 @@ int begin_frame(sm_ctx *s, const uint8_t *d_rgb, const uint16_t *d_raw, const ui
         if (s->sh_world > 1) { g_err = "reset() is not supported in sharded mode"; return SM_E_UNSUPPORTED; }
         fp.init_mode = 1;
         fp.log_frame = 0;
+        // GlobalModel::initialize writes the raw cloud from the first slot of modelVbo on and sets count to the number written
+        // (src/GlobalModel.cpp:211-228): a map that was
+        // uploaded after reset() is discarded, not extended
+        if ((rc = discard_model(s))) return rc;
         s->n_compact_part = 0;                            // no cull / splat ran: nothing to fold into visible_count
         s->lazy_part_live = false;
         if ((rc = launch_associate(s, fp, false))) return rc;
@@ -677,6 +710,7 @@ int enqueue_frame(sm_ctx *s, const uint8_t *d_rgb, const uint16_t *d_raw, const 
     if (rc <= 0) return rc;
     fp.compact_now = decide_compact(s) ? 1u : 0u;
     note_cull(s, fp.compact_now != 0u);
+    s->keys_are_slots = fp.compact_now == 0u;      // this frame's splat writes slot numbers iff nothing moves
     if (s->ev_ok) s->ev_compacted[s->ev_frames % EV_RING] = fp.compact_now != 0u;
     // a cull that only marks the dead folds its finalize step into the cull kernel (measured: 66.0 -> 62.9 us/frame; with the
     // depth filter chain on a second stream it is the other way round, 86.5 -> 94.5 us, so those contexts keep the kernel)
@@ -1003,8 +1037,11 @@ int sm_clean_points(sm_ctx *s, const uint16_t *depth_mm, const uint8_t *semantic
     if (!s || !depth_mm || !semantic || !pose16) { g_err = "sm_clean_points: null argument"; return SM_E_ARG; }
     HIPCK(hipSetDevice(s->cfg.device));
     if (s->pending_cull) { g_err = "sm_stage_conflict without sm_stage_cull"; return SM_E_ARG; }
-    int rc = upload_inputs(s, nullptr, depth_mm, semantic);
+    // cleanPoints culls without redrawing the index map (src/SurfelMapping.cpp:496-532): the map keeps ids of the model
+    // as it was, so they are settled (slot -> position) before this cull changes the positions
+    int rc = ensure_compact(s);
     if (rc) return rc;
+    if ((rc = upload_inputs(s, nullptr, depth_mm, semantic))) return rc;
     memcpy(s->curr_pose, pose16, 64);
     FrameParams fp = make_params(s, pose16);
     if ((rc = launch_prep(s, s->d_rgb, s->d_depth_raw, s->d_sem, nullptr, fp, false))) return rc;   // metriciseDepth only
@@ -1023,13 +1060,11 @@ int sm_reset(sm_ctx *s)
 {
     if (!s) return SM_E_ARG;
     HIPCK(hipSetDevice(s->cfg.device));
-    int rc = pull_state(s);
+    // the index map survives reset() (the reference only resets the model buffer, src/SurfelMapping.cpp:436-441): bring
+    // its ids to the form the API hands out (positions among the live surfels) while the slots can still be translated
+    int rc = s->pending_cull ? SM_OK : ensure_compact(s);
     if (rc) return rc;
-    if (s->maybe_garbage) {
-        HIPCK(hipMemsetAsync(s->d_alive, 0xFF, s->alive_words * 8, s->stream));
-        HIPCK(hipMemsetAsync(s->d_tile_dead, 0, s->dead_tiles * 4, s->stream));
-        s->maybe_garbage = false;
-    }
+    if ((rc = pull_state(s))) return rc;
     const uint32_t cur = s->h_state->cur;
     memset(s->h_state, 0, sizeof(DevState));
     s->h_state->cur = cur;
