@@ -3,6 +3,7 @@ point (processFrame, cleanPoints, reset, map upload / download, index-map downlo
 inputs (NaN / infinite / negative confidences and positions in uploaded maps, zero and out-of-range depth, every
 compaction period).  After every step the counters agree; at every download the stored model is bit-identical."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -45,8 +46,8 @@ def random_frame(rng, W, H):
     return rgb, depth, sem
 
 
-@pytest.mark.parametrize("seed", list(range(64)))
-def test_random_call_sequences_match_the_oracle(seed):
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("SM_FUZZ_SEEDS", "64")))))   # SM_FUZZ_SEEDS=2000 for a soak
+def test_random_call_sequences_match_the_oracle(seed, tmp_path):
     rng = np.random.default_rng(1000 + seed)
     W, H = int(rng.choice([48, 64, 96])), int(rng.choice([32, 48]))
     cam = dict(width=W, height=H, fx=0.8 * W, fy=0.8 * W, cx=W / 2 - 0.5, cy=H / 2 - 0.5)
@@ -58,8 +59,9 @@ def test_random_call_sequences_match_the_oracle(seed):
     h = make("hip", *args, compact_period=int(rng.choice([1, 2, 3, 8, 1000])), **over)
     cap = over["max_sqrt_vertices"] ** 2
     z = 0.0
+    last = None
     for step in range(60):
-        what = rng.choice(["frame"] * 12 + ["clean", "reset", "upload", "download", "index"])
+        what = rng.choice(["frame"] * 10 + ["burst"] * 2 + ["clean", "reset", "upload", "download", "index", "render", "saveload"])
         tag = f"seed {seed} step {step} {what}"
         if what == "frame":
             z += rng.uniform(-0.05, 0.25)
@@ -69,7 +71,37 @@ def test_random_call_sequences_match_the_oracle(seed):
             rh = h.process_frame(*fr, pose, allow=(0, -2))
             assert ro == rh, tag
             last = (fr, pose)
-        elif what == "clean" and step > 2:
+        elif what == "burst":
+            # several frames enqueued without waiting (device-resident inputs), then one sync
+            P = W * H
+            for _ in range(int(rng.integers(2, 6))):
+                z += rng.uniform(-0.05, 0.25)
+                pose = synth.pose_to_colmajor(synth.pose_matrix(0.05 * math.sin(step), 0.0, z, float(rng.uniform(-3, 3))))
+                fr = random_frame(rng, W, H)
+                ro = o.process_frame(*fr, pose, allow=(0, -2))
+                dr, dd, ds = h.device_alloc(P * 3), h.device_alloc(P * 2), h.device_alloc(P)
+                h.device_upload(dr, fr[0]); h.device_upload(dd, fr[1]); h.device_upload(ds, fr[2])
+                h.process_frame_device(dr, dd, ds, pose)
+                last = (fr, pose)
+                if ro != 0:
+                    break                                   # capacity error on the oracle: let the sync below report it too
+            rh = h.sync(allow=(0, -2))
+            assert (ro != 0) == (rh != 0), tag
+        elif what == "render" and o.counts()["count"] > 0:
+            view = synth.pose_to_colmajor(synth.pose_matrix(0.1, 0.0, z - 0.5, 2.0))
+            a = o.render_image(view, 40, 30, 30.0, 30.0, 19.5, 14.5)
+            b = h.render_image(view, 40, 30, 30.0, 30.0, 19.5, 14.5)
+            np.testing.assert_array_equal(a[0], b[0], err_msg=tag); np.testing.assert_array_equal(a[1], b[1], err_msg=tag)
+        elif what == "saveload":
+            path = str(tmp_path / f"m{step}.bin")
+            h.save_map(path, 1, 2)
+            raw = open(path, "rb").read()
+            n = int(np.frombuffer(raw[:4], np.uint32)[0])
+            assert n == o.counts()["count"], tag
+            assert_models_equal(np.frombuffer(raw[12:], np.float32).reshape(n, 12), o.download_model(), tag)
+            assert h.load_map(path) == (1, 2)
+            o.upload_model(np.frombuffer(raw[12:], np.float32).reshape(n, 12).copy())
+        elif what == "clean" and last is not None:
             fr, pose = last
             o.clean_points(fr[1], fr[2], pose); h.clean_points(fr[1], fr[2], pose)
         elif what == "reset":
@@ -83,7 +115,7 @@ def test_random_call_sequences_match_the_oracle(seed):
         elif what == "index":
             np.testing.assert_array_equal(o.download_index_map()[0], h.download_index_map()[0], err_msg=tag)
         co, ch = o.counts(), h.counts()
-        if what in ("frame", "upload", "download"):
+        if what in ("frame", "burst", "upload", "download", "saveload"):
             assert {k: co[k] for k in COUNT_KEYS} == {k: ch[k] for k in COUNT_KEYS}, tag
         else:
             assert co["count"] == ch["count"] and co["tick"] == ch["tick"], tag
