@@ -135,7 +135,9 @@ int sm_sync(sm_ctx *s);
 /* SurfelMapping::cleanPoints (src/SurfelMapping.cpp:496-532) */
 int sm_clean_points(sm_ctx *s, const uint16_t *depth_mm, const uint8_t *semantic,
                     const float *pose16);
-/* SurfelMapping::reset (src/SurfelMapping.cpp:436-441) */
+/* SurfelMapping::reset (src/SurfelMapping.cpp:436-441): empties the model and sets tick = 0; the next processFrame
+ * builds the model anew from that frame's raw cloud (GlobalModel::initialize), discarding anything uploaded in between.
+ * The index map is left as the last predictIndices drew it. */
 int sm_reset(sm_ctx *s);
 
 /* GlobalModel::getModel/getData/getConflict/getUnstable/getOffset counts */
@@ -148,7 +150,10 @@ int sm_upload_model_aos(sm_ctx *s, const float *src12, uint32_t n);
 int sm_save_map(sm_ctx *s, const char *path, int32_t start_id, int32_t end_id);
 int sm_load_map(sm_ctx *s, const char *path, int32_t *start_id, int32_t *end_id);
 /* IndexMap::indexTex/vertConfTex/colorTimeTex/normalRadTex read-back (src/IndexMap.h:70-88),
- * row-major H*W; any pointer may be NULL. */
+ * row-major H*W; any pointer may be NULL.  Ids are surfel positions in the model at the time of the last
+ * predictIndices (a later cleanPoints / reset / upload does not redraw the map, as in the reference); the three
+ * attribute planes are re-derived from the surfels those ids address in the model as it is NOW, i.e. they equal the
+ * reference's textures only while the model has not changed since. */
 int sm_download_index_map(sm_ctx *s, int32_t *id, float *vert_conf4, float *color_time4,
                           float *norm_rad4);
 /* SurfelMapping::getTexture(DEPTH_METRIC / DEPTH_FILTERED / "LAST") read-back, row-major */
