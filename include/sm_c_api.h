@@ -31,7 +31,9 @@ enum {
     SM_E_UNSUPPORTED = -3,
     SM_E_HIP = -4,          /* a HIP runtime call failed; see sm_last_error() */
     SM_E_NO_DEVICE = -5,    /* no gfx950 device visible: the product has NO CPU fallback */
-    SM_E_STALL = -6         /* an in-kernel hand-off wait hit its spin bound (GPU shared with another job?) */
+    SM_E_STALL = -6         /* an in-kernel hand-off wait hit its spin bound: the in-place compaction needs its whole grid
+                               resident, which another job -- or another sm_ctx compacting at the same moment on the same
+                               GPU -- can prevent.  Use one context per GPU (or serialise their frames). */
 };
 
 /* Config singleton values (src/Config.cpp:32-37) + the magic numbers of the hot path
