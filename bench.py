@@ -179,9 +179,10 @@ def main():
                                                         max_sqrt_vertices=10000 if hd else 5000,
                                                         compact_period=args.compact_period))
     sm = mk(0)                                    # raises without a GPU: no CPU fallback
-    # second context: the same frames again with HIP events between the kernels (the events cost
-    # ~25 us per frame, so they stay out of the run that produces `value`)
-    sm_ev = None if args.no_events else mk(1)
+    # A second context replays the same frames with HIP events between the kernels (the events cost ~25 us per frame,
+    # so they stay out of the run that produces `value`).  It is created AFTER the timed run: the timed context is then
+    # the only one on its GPU, as in deployment (contexts that share a GPU chain their compaction kernels).
+    sm_ev = None
 
     # ---- stage every frame in HBM
     dptr = []
@@ -193,10 +194,8 @@ def main():
     seed_model = None
     if hd:
         seed_model = synth.seeded_model(args.seed_surfels, tick=300, seed=args.seed)
-        for ctx in (sm, sm_ev):
-            if ctx is not None:
-                ctx.upload_model(seed_model)
-                ctx.set_tick(300)
+        sm.upload_model(seed_model)
+        sm.set_tick(300)
 
     def run(ctx, lo, hi):
         for k in range(lo, hi):
@@ -207,7 +206,6 @@ def main():
     sm_global = None
     if dist:
         from surfelmapping_amd import dist as smd
-        sm_global = capi.SurfelMap(capi.make_config(**cam, preprocess=0, device=local_rank))
         # warm the collective path (RCCL communicator setup is not part of a frame)
         g0, c0 = smd.gather_model_device(sm, local_rank)
         del g0
@@ -229,6 +227,8 @@ def main():
     # the per-frame hot path of a camera touches only its own slice -- so it is timed separately.
     global_count, gather_ms = None, None
     if dist:
+        sm_global = capi.SurfelMap(capi.make_config(**cam, preprocess=0, device=local_rank))
+        barrier()
         g0 = time.perf_counter()
         gathered, gcounts = smd.gather_model_device(sm, local_rank)
         global_count = smd.build_global_model(sm_global, gathered, gcounts)
@@ -239,7 +239,11 @@ def main():
 
     # ---- the same K frames on the instrumented context: per-kernel durations for the roofline
     tim = {k: 0.0 for k in ("k_prep", "k_conflict", "k_scan_cull", "k_compact", "k_associate", "k_scan_new", "k_append", "run")}
-    if sm_ev is not None:
+    if not args.no_events:
+        sm_ev = mk(1)
+        if hd:
+            sm_ev.upload_model(seed_model)
+            sm_ev.set_tick(300)
         run(sm_ev, 0, Wm)
         sm_ev.sync()
         sm_ev.timings()                           # drop warm-up samples

@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -113,6 +114,18 @@ float exp_spec(float x)
     return ldexpf(p, (int)k);
 }
 
+}  // namespace
+
+// Contexts of one process that share a GPU: the in-place compaction kernel waits on tile hand-off flags and needs its
+// whole grid resident, so two of them running at the same time can starve each other (SM_E_STALL).  Their launches are
+// therefore chained through one event per device.  (Other kernels of other contexts are harmless: they finish on their
+// own and give the CUs back.  Contexts of different PROCESSES on one GPU are not covered.)
+namespace {
+constexpr int MAX_DEV = 64;
+std::mutex g_compact_mu;
+int g_ctx_on_dev[MAX_DEV] = {};
+hipEvent_t g_compact_ev[MAX_DEV] = {};
+bool g_compact_ev_valid[MAX_DEV] = {};
 }  // namespace
 
 struct sm_ctx {
@@ -397,6 +410,19 @@ int launch_compact(sm_ctx *s, const FrameParams &fp, bool splat, bool timed)
     const int grid = std::min(grid_surfels(s), s->compact_grid);
     const uint32_t epoch = ++s->cull_epoch;
     s->n_compact_part = splat ? (uint32_t)grid : 0u;
+    const int dev = s->cfg.device;
+    std::unique_lock<std::mutex> chain(g_compact_mu, std::defer_lock);
+    bool chained = false;
+    if (dev >= 0 && dev < MAX_DEV) {
+        chain.lock();
+        chained = g_ctx_on_dev[dev] > 1;            // another context of this process uses the same GPU
+        if (chained) {
+            if (!g_compact_ev[dev]) HIPCK(hipEventCreateWithFlags(&g_compact_ev[dev], hipEventDisableTiming));
+            if (g_compact_ev_valid[dev]) HIPCK(hipStreamWaitEvent(s->stream, g_compact_ev[dev], 0));
+        } else {
+            chain.unlock();
+        }
+    }
     if (splat)
         hipLaunchKernelGGL(k_compact<true>, dim3(grid), dim3(256), 0, s->stream, s->M, s->d_state, fp, s->d_cm,
                            s->d_dm, s->d_zm, s->d_tile_cnt, s->d_tile_allow, s->d_tile_keep, s->d_keyT, s->d_tile_flag, epoch,
@@ -408,6 +434,7 @@ int launch_compact(sm_ctx *s, const FrameParams &fp, bool splat, bool timed)
                            s->d_seg_lstart, s->d_seg_gbase, s->d_group_base, s->d_tb, s->d_tile_flags, s->d_compact_part, s->d_alive,
                            s->d_tile_dead);
     HIPCK(hipGetLastError());
+    if (chained) { HIPCK(hipEventRecord(g_compact_ev[dev], s->stream)); g_compact_ev_valid[dev] = true; }
     if (mark(s, 4, timed)) return SM_E_HIP;
     return SM_OK;
 }
@@ -831,6 +858,7 @@ sm_ctx *sm_create(const sm_config *c)
     if (hipSetDevice(c->device) != hipSuccess) { g_err = "hipSetDevice failed"; return nullptr; }
     sm_ctx *s = new sm_ctx();
     s->cfg = *c;
+    if (c->device >= 0 && c->device < MAX_DEV) { std::lock_guard<std::mutex> lk(g_compact_mu); g_ctx_on_dev[c->device]++; }
     s->W = c->width; s->H = c->height; s->P = c->width * c->height;
     s->cap = (uint32_t)c->max_sqrt_vertices * (uint32_t)c->max_sqrt_vertices;
     for (int i = 0; i < 16; ++i) s->curr_pose[i] = s->last_pose[i] = (i % 5 == 0) ? 1.0f : 0.0f;
@@ -969,6 +997,7 @@ sm_ctx *sm_create(const sm_config *c)
 void sm_destroy(sm_ctx *s)
 {
     if (!s) return;
+    if (s->cfg.device >= 0 && s->cfg.device < MAX_DEV) { std::lock_guard<std::mutex> lk(g_compact_mu); g_ctx_on_dev[s->cfg.device]--; }
     (void)hipSetDevice(s->cfg.device);
     if (s->stream2) (void)hipStreamSynchronize(s->stream2);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
