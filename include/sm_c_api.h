@@ -32,8 +32,8 @@ enum {
     SM_E_HIP = -4,          /* a HIP runtime call failed; see sm_last_error() */
     SM_E_NO_DEVICE = -5,    /* no gfx950 device visible: the product has NO CPU fallback */
     SM_E_STALL = -6         /* an in-kernel hand-off wait hit its spin bound: the in-place compaction needs its whole grid
-                               resident, which another job -- or another sm_ctx compacting at the same moment on the same
-                               GPU -- can prevent.  Use one context per GPU (or serialise their frames). */
+                               resident, which another job on the same GPU can prevent.  Contexts of one process that
+                               share a GPU are safe (their compactions are chained); give every PROCESS its own GPU. */
 };
 
 /* Config singleton values (src/Config.cpp:32-37) + the magic numbers of the hot path
