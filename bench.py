@@ -178,6 +178,9 @@ def main():
                                                         enable_timing=timing, conflict_cap=0 if hd else 1,
                                                         max_sqrt_vertices=10000 if hd else 5000,
                                                         compact_period=args.compact_period))
+    # this process creates a second (instrumented) context later, but the two never run at the same time: keep the
+    # default round-robin form of the compaction kernel for both (the library would switch to ticket order otherwise)
+    os.environ.setdefault("SM_COMPACT_TICKETS", "0")
     sm = mk(0)                                    # raises without a GPU: no CPU fallback
     # A second context replays the same frames with HIP events between the kernels (the events cost ~25 us per frame,
     # so they stay out of the run that produces `value`).  It is created AFTER the timed run: the timed context is then

@@ -116,16 +116,24 @@ float exp_spec(float x)
 
 }  // namespace
 
-// Contexts of one process that share a GPU: the in-place compaction kernel waits on tile hand-off flags and needs its
-// whole grid resident, so two of them running at the same time can starve each other (SM_E_STALL).  Their launches are
-// therefore chained through one event per device.  (Other kernels of other contexts are harmless: they finish on their
-// own and give the CUs back.  Contexts of different PROCESSES on one GPU are not covered.)
+// Contexts of one process that share a GPU: the in-place compaction kernel waits on tile hand-off flags and, in its
+// default form, needs its whole grid resident -- two of them running at the same time can starve each other
+// (SM_E_STALL).  As soon as a second context exists on a device, compactions there use the ticket-ordered form of the
+// kernel, which makes no residency assumption (SM_COMPACT_TICKETS=1 forces it, e.g. when several PROCESSES share a GPU;
+// =0 keeps the round-robin form for a process whose contexts never run at the same time).
 namespace {
 constexpr int MAX_DEV = 64;
 std::mutex g_compact_mu;
 int g_ctx_on_dev[MAX_DEV] = {};
-hipEvent_t g_compact_ev[MAX_DEV] = {};
-bool g_compact_ev_valid[MAX_DEV] = {};
+
+bool compaction_needs_tickets(int dev)
+{
+    static const char *env = std::getenv("SM_COMPACT_TICKETS");      // "1": always, "0": never (contexts known not to overlap)
+    if (env) return env[0] != '0';
+    if (dev < 0 || dev >= MAX_DEV) return true;
+    std::lock_guard<std::mutex> lk(g_compact_mu);
+    return g_ctx_on_dev[dev] > 1;
+}
 }  // namespace
 
 struct sm_ctx {
@@ -410,31 +418,19 @@ int launch_compact(sm_ctx *s, const FrameParams &fp, bool splat, bool timed)
     const int grid = std::min(grid_surfels(s), s->compact_grid);
     const uint32_t epoch = ++s->cull_epoch;
     s->n_compact_part = splat ? (uint32_t)grid : 0u;
-    const int dev = s->cfg.device;
-    std::unique_lock<std::mutex> chain(g_compact_mu, std::defer_lock);
-    bool chained = false;
-    if (dev >= 0 && dev < MAX_DEV) {
-        chain.lock();
-        chained = g_ctx_on_dev[dev] > 1;            // another context of this process uses the same GPU
-        if (chained) {
-            if (!g_compact_ev[dev]) HIPCK(hipEventCreateWithFlags(&g_compact_ev[dev], hipEventDisableTiming));
-            if (g_compact_ev_valid[dev]) HIPCK(hipStreamWaitEvent(s->stream, g_compact_ev[dev], 0));
-        } else {
-            chain.unlock();
-        }
-    }
+    FrameParams fpc = fp;
+    fpc.compact_tickets = compaction_needs_tickets(s->cfg.device) ? 1 : 0;
     if (splat)
-        hipLaunchKernelGGL(k_compact<true>, dim3(grid), dim3(256), 0, s->stream, s->M, s->d_state, fp, s->d_cm,
+        hipLaunchKernelGGL(k_compact<true>, dim3(grid), dim3(256), 0, s->stream, s->M, s->d_state, fpc, s->d_cm,
                            s->d_dm, s->d_zm, s->d_tile_cnt, s->d_tile_allow, s->d_tile_keep, s->d_keyT, s->d_tile_flag, epoch,
                            s->d_seg_lstart, s->d_seg_gbase, s->d_group_base, s->d_tb, s->d_tile_flags, s->d_compact_part, s->d_alive,
                            s->d_tile_dead);
     else
-        hipLaunchKernelGGL(k_compact<false>, dim3(grid), dim3(256), 0, s->stream, s->M, s->d_state, fp, s->d_cm,
+        hipLaunchKernelGGL(k_compact<false>, dim3(grid), dim3(256), 0, s->stream, s->M, s->d_state, fpc, s->d_cm,
                            s->d_dm, s->d_zm, s->d_tile_cnt, s->d_tile_allow, s->d_tile_keep, s->d_keyT, s->d_tile_flag, epoch,
                            s->d_seg_lstart, s->d_seg_gbase, s->d_group_base, s->d_tb, s->d_tile_flags, s->d_compact_part, s->d_alive,
                            s->d_tile_dead);
     HIPCK(hipGetLastError());
-    if (chained) { HIPCK(hipEventRecord(g_compact_ev[dev], s->stream)); g_compact_ev_valid[dev] = true; }
     if (mark(s, 4, timed)) return SM_E_HIP;
     return SM_OK;
 }

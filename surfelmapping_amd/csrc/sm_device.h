@@ -56,6 +56,8 @@ struct DevState {
     uint32_t garbage_prev;    // its value before the last cull
     uint32_t do_compact;      // the last cull compacts physically (otherwise it only marks the dead in `alive`)
     uint32_t cap_binds;       // the last cull had more conflicts than the conflict cap (tile_allow is in force)
+    uint32_t first_moving;    // first tile the pending compaction moves or thins out (tiles below it stay in place)
+    uint32_t compact_ticket;  // work queue of k_compact: next moving tile (relative to first_moving) to hand out
     uint32_t stat_frames;     // frames whose append has completed (tag of the host-visible slot statistic)
     uint32_t first_live;      // slot of the first live surfel = the reference's surfel id 0 (conflict.geom:15, data.vert:142)
 };
@@ -96,6 +98,7 @@ struct FrameParams {
     uint32_t compact_now;     // 1: this cull moves the survivors (k_scan_cull + k_compact); 0: it only marks the dead (k_cull_lazy).
                               // Decided by the host (a fixed period + a capacity bound), so that it can launch the matching kernels
     int maintenance;          // 1: compaction outside a frame (no kills): frame statistics are left alone
+    int compact_tickets;      // 1: k_compact hands its moving tiles out in order from a ticket counter (no co-residency needed)
 };
 
 // local index -> global id through the per-segment tables (segments = surfels created by one frame,

@@ -621,11 +621,13 @@ __global__ __launch_bounds__(1024) void k_cull_finalize(DevState *__restrict__ s
         for (uint32_t t = t0; t < t1; ++t) {
             const uint32_t kills = tile_keep_prefix[t];
             const uint32_t nv = min((uint32_t)TILE, N - t * TILE) - tile_dead[t];
-            if (kpre == t * TILE && kills == 0) ns += nv;
+            if (kpre == t * TILE && kills == 0 && tile_dead[t] == 0u) ns += nv;
+            else atomicMin(&s_first, t);             // first tile that moves or thins out
             tile_keep_prefix[t] = kpre;
             kpre += nv - kills;
         }
         block_scan_1024(ns, &nstatic, s_scan);
+        __syncthreads();
     }
     // ---- deferred compaction: mark the dead now, move the survivors only once enough slots are dead
     const uint32_t kept = ktotal;                     // live surfels after this cull
@@ -675,6 +677,8 @@ __global__ __launch_bounds__(1024) void k_cull_finalize(DevState *__restrict__ s
         st->garbage_prev = g0;
         st->cap_binds = cap_binds ? 1u : 0u;
         st->do_compact = compact ? 1u : 0u;
+        st->first_moving = (compact && s_first != 0xFFFFFFFFu) ? min(s_first, ntiles) : ntiles;
+        st->compact_ticket = 0u;
         st->first_live = first_live;
         if (compact) {
             st->count = kept;                             // src/GlobalModel.cpp:575
@@ -801,29 +805,68 @@ __global__ __launch_bounds__(256) void k_compact(Model M, DevState *__restrict__
     // (k_cull_lazy) are squeezed out together with this cull's own victims.
     const bool had_dead = st->garbage_prev != 0u;
     const bool cap_binds = st->cap_binds != 0u;
-    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x, ++iter) {
-        if ((iter & 63u) == 0u) {
-            // metadata of this workgroup's next 64 tiles in one round of loads (lane i <-> i-th tile), so that the
-            // per-tile critical path holds a single memory latency (the surfel loads themselves)
-            const uint64_t tl = (uint64_t)tile + (uint64_t)lane * gridDim.x;
-            const bool in = tl < ntiles;
-            const uint32_t tt = in ? (uint32_t)tl : 0u;
-            skipmask = __ballot(in && (tile_flags[tt] & 2u));
-            m_nconf = tile_cnt[tt * 3]; m_nkill = tile_cnt[tt * 3 + 1];
-            m_allow = cap_binds ? tile_allow[tt] : m_nconf;         // every conflict takes effect unless the cap binds
-            m_base = tile_keep_prefix[tt] + group_keep_base[tt / GROUP];
-            m_dead = had_dead ? tile_dead[tt] : 0u;
+    // Two ways to share out the tiles.  Round-robin over a grid that is known to be fully resident (the default: a tile
+    // only waits for lower tiles, all of which are then running).  Or, when the GPU is shared and residency cannot be
+    // counted on (fp.compact_tickets): the tiles below `fm` stay in place (nothing killed or dead in or before them) and
+    // go round-robin, the tiles from `fm` on -- the ones that wait for hand-off flags -- are handed out IN ORDER from a
+    // ticket counter: whoever holds a ticket is running, and a running tile publishes its flag before it waits for
+    // anything, so progress never depends on how many workgroups the GPU keeps resident.  (+1 returning atomic per
+    // moving tile on its critical path: k_compact 50 -> 66 us at KITTI size, hence not the default.)
+    const bool use_tickets = fp.compact_tickets != 0;
+    const uint32_t fm = use_tickets ? min(st->first_moving, ntiles) : ntiles;
+    constexpr uint32_t TICKET = 1;                    // one tile per ticket: a tile must be able to publish without first finishing a lower one
+    __shared__ uint32_t s_tk;
+    bool ticketing = false;
+    uint32_t rr_tile = blockIdx.x, tk_tile = 0, tk_left = 0;
+    for (;;) {
+        uint32_t tile, allow, nconf, nkill_full, base_id, tdead;
+        bool skipbit;
+        if (!ticketing && rr_tile >= fm) {                                      // workgroup-uniform
+            if (!use_tickets) break;
+            ticketing = true;
         }
-        const int sl = (int)(iter & 63u);
-        const uint32_t allow = (uint32_t)__shfl((int)m_allow, sl), nconf = (uint32_t)__shfl((int)m_nconf, sl);
-        const uint32_t nkill_full = (uint32_t)__shfl((int)m_nkill, sl), base_id = (uint32_t)__shfl((int)m_base, sl);
-        const uint32_t tdead = (uint32_t)__shfl((int)m_dead, sl);
+        if (!ticketing) {
+            tile = rr_tile;
+            if ((iter & 63u) == 0u) {
+                // metadata of this workgroup's next 64 tiles in one round of loads (lane i <-> i-th tile), so that the
+                // per-tile critical path holds a single memory latency (the surfel loads themselves)
+                const uint64_t tl = (uint64_t)tile + (uint64_t)lane * gridDim.x;
+                const bool in = tl < fm;
+                const uint32_t tt = in ? (uint32_t)tl : 0u;
+                skipmask = __ballot(in && (tile_flags[tt] & 2u));
+                m_nconf = tile_cnt[tt * 3]; m_nkill = tile_cnt[tt * 3 + 1];
+                m_allow = cap_binds ? tile_allow[tt] : m_nconf;         // every conflict takes effect unless the cap binds
+                m_base = tile_keep_prefix[tt] + group_keep_base[tt / GROUP];
+                m_dead = had_dead ? tile_dead[tt] : 0u;
+            }
+            const int sl = (int)(iter & 63u);
+            allow = (uint32_t)__shfl((int)m_allow, sl); nconf = (uint32_t)__shfl((int)m_nconf, sl);
+            nkill_full = (uint32_t)__shfl((int)m_nkill, sl); base_id = (uint32_t)__shfl((int)m_base, sl);
+            tdead = (uint32_t)__shfl((int)m_dead, sl);
+            skipbit = (skipmask >> (iter & 63u)) & 1ull;
+            rr_tile += gridDim.x; ++iter;
+        } else {
+            if (tk_left == 0u) {
+                __syncthreads();
+                if (threadIdx.x == 0) s_tk = atomicAdd(&st->compact_ticket, TICKET);
+                __syncthreads();
+                tk_tile = fm + s_tk; tk_left = TICKET;
+            }
+            tile = tk_tile;
+            if (tile >= ntiles) break;
+            ++tk_tile; --tk_left;
+            nconf = tile_cnt[tile * 3]; nkill_full = tile_cnt[tile * 3 + 1];
+            allow = cap_binds ? tile_allow[tile] : nconf;
+            base_id = tile_keep_prefix[tile] + group_keep_base[tile / GROUP];
+            tdead = had_dead ? tile_dead[tile] : 0u;
+            skipbit = false;
+        }
         // fast path (workgroup-uniform): nothing of this tile conflicts, dies or moves -- the bulk of the map
         // once the camera has passed.  No masks, no LDS, no barriers: read pos+time, splat.
-        if (nconf == 0 && nkill_full == 0 && base_id == tile * (uint32_t)TILE && tdead == 0u) {
+        if (!ticketing && nconf == 0 && nkill_full == 0 && base_id == tile * (uint32_t)TILE && tdead == 0u) {
             // ... and if its box cannot reach the index map (index_map.vert:45-55: 0 < z < far inside the image,
             // updated within timeDelta frames) it is not even read
-            if (SPLAT && ((skipmask >> (iter & 63u)) & 1ull)) {
+            if (SPLAT && skipbit) {
                 skipped += min((uint32_t)TILE, N - tile * TILE);
                 continue;
             }
@@ -849,7 +892,7 @@ __global__ __launch_bounds__(256) void k_compact(Model M, DevState *__restrict__
             continue;
         }
         // conservative: a tile classified "moving" that turns out static is handled correctly (it rewrites itself)
-        const bool moving = (base_id != tile * (uint32_t)TILE) || nkill_full != 0u || tdead != 0u;   // workgroup-uniform
+        const bool moving = ticketing || (base_id != tile * (uint32_t)TILE) || nkill_full != 0u || tdead != 0u;   // workgroup-uniform
         // ---- issue every surfel load of the tile first (unconditional, clamped: a per-lane branch would serialise
         // them behind s_waitcnt); the mask bookkeeping below overlaps their latency
         float4 v[4], nr[4];

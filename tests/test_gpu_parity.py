@@ -294,6 +294,20 @@ def test_fused_associate_append_variant_matches_oracle():
     assert r.returncode == 0 and "smoke ok" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
 
 
+@pytest.mark.parametrize("env", [{"SM_COMPACT_TICKETS": "1"}, {"SM_NO_MERGED_FINALIZE": "1"}])
+def test_kernel_variants_behind_switches_stay_bit_exact(env):
+    """SM_COMPACT_TICKETS=1: the in-place compaction hands its moving tiles out from a ticket counter (the form used as
+    soon as two contexts share a GPU: no co-residency assumption).  SM_NO_MERGED_FINALIZE=1: the lazy cull keeps its
+    separate finalize kernel.  Both run the deferred-compaction and fuzz tests in a child process."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-m", "gpu", "-x", "tests/test_deferred_compaction.py",
+                        "tests/test_fuzz_gpu.py"], cwd=root, env=dict(os.environ, SM_FUZZ_SEEDS="24", **env),
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2500:] + r.stderr[-1500:]
+
+
 def assert_models_equal_nan_tolerant(a, b, what=""):
     """As assert_models_equal, but any NaN equals any NaN: the raw feedback cloud has no neighbour test
     (surfel_feedback.vert), so border pixels get 0/0 normals whose NaN payload/sign is not specified."""
