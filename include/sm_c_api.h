@@ -33,7 +33,8 @@ enum {
     SM_E_NO_DEVICE = -5,    /* no gfx950 device visible: the product has NO CPU fallback */
     SM_E_STALL = -6         /* an in-kernel hand-off wait hit its spin bound: the in-place compaction needs its whole grid
                                resident, which another job on the same GPU can prevent.  Contexts of one process that
-                               share a GPU are safe (their compactions are chained); give every PROCESS its own GPU. */
+                               share a GPU are safe (they use the ticket-ordered form of the kernel); for several
+                               PROCESSES on one GPU set SM_COMPACT_TICKETS=1 in their environment. */
 };
 
 /* Config singleton values (src/Config.cpp:32-37) + the magic numbers of the hot path
