@@ -285,6 +285,35 @@ __device__ __forceinline__ float ord2f(uint32_t o)
     return __uint_as_float((o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o);
 }
 
+// Wave-wide reductions with DPP (gfx9 row_shr / row_bcast): six VALU instructions and no LDS traffic, against six
+// ds_bpermute round trips for a __shfl_xor butterfly.  All 64 lanes must be active; lanes that do not take part pass the
+// identity (0 for both max and sum of unsigned).  The result is returned wave-uniform (read from lane 63).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_take(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, true);   // out-of-range source lanes read 0
+}
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
+{
+    v = max(v, dpp_take<0x111, 0xF>(v));      // row_shr:1
+    v = max(v, dpp_take<0x112, 0xF>(v));      // row_shr:2
+    v = max(v, dpp_take<0x114, 0xF>(v));      // row_shr:4
+    v = max(v, dpp_take<0x118, 0xF>(v));      // row_shr:8   -> lane 15 of every row holds the row's maximum
+    v = max(v, dpp_take<0x142, 0xA>(v));      // row_bcast:15 into rows 1 and 3
+    v = max(v, dpp_take<0x143, 0xC>(v));      // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave's maximum
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
+{
+    v += dpp_take<0x111, 0xF>(v);
+    v += dpp_take<0x112, 0xF>(v);
+    v += dpp_take<0x114, 0xF>(v);
+    v += dpp_take<0x118, 0xF>(v);
+    v += dpp_take<0x142, 0xA>(v);
+    v += dpp_take<0x143, 0xC>(v);
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 // expand the bounds of the tiles touched by this wave: each active lane contributes one surfel
 // (position, time, "bad") to tile `tile`; lanes are grouped by tile with ballots, reduced with
 // shuffles, and ONE atomicMax wave instruction (lanes 0..7 -> words 0..7 of the tile) publishes the group.
@@ -301,13 +330,8 @@ __device__ __forceinline__ void bounds_expand_wave(uint32_t *__restrict__ tb, bo
         uint32_t w0 = mine ? ~f2ord(x) : 0u, w1 = mine ? ~f2ord(y) : 0u, w2 = mine ? ~f2ord(z) : 0u;
         uint32_t w4 = mine ? f2ord(x) : 0u, w5 = mine ? f2ord(y) : 0u, w6 = mine ? f2ord(z) : 0u, w7 = mine ? f2ord(t) : 0u;
         const uint32_t nb = (uint32_t)__popcll(__ballot(mine && (bad || x != x || y != y || z != z)));
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            w0 = max(w0, (uint32_t)__shfl_xor((int)w0, o)); w1 = max(w1, (uint32_t)__shfl_xor((int)w1, o));
-            w2 = max(w2, (uint32_t)__shfl_xor((int)w2, o)); w4 = max(w4, (uint32_t)__shfl_xor((int)w4, o));
-            w5 = max(w5, (uint32_t)__shfl_xor((int)w5, o)); w6 = max(w6, (uint32_t)__shfl_xor((int)w6, o));
-            w7 = max(w7, (uint32_t)__shfl_xor((int)w7, o));
-        }
+        w0 = wave_max_u32(w0); w1 = wave_max_u32(w1); w2 = wave_max_u32(w2); w4 = wave_max_u32(w4);
+        w5 = wave_max_u32(w5); w6 = wave_max_u32(w6); w7 = wave_max_u32(w7);
         if (lane < 8 && lane != 3) {
             const uint32_t val = lane == 0 ? w0 : lane == 1 ? w1 : lane == 2 ? w2 : lane == 4 ? w4 : lane == 5 ? w5 : lane == 6 ? w6 : w7;
             atomicMax(&tb[(size_t)tcur * 8 + lane], val);

@@ -1795,12 +1795,10 @@ __global__ __launch_bounds__(PIX_BLOCK) void k_append_scan(Model M, DevState *__
             for (uint32_t b = threadIdx.x; b < n_compact_part; b += PIX_BLOCK) { const uint4 c = lazy_part[b]; cv += c.x; cs += c.y; ck += c.z; }
         else
             for (uint32_t b = threadIdx.x; b < n_compact_part; b += PIX_BLOCK) { const uint2 c = compact_part[b]; cv += c.x; cs += c.y; }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { cv += __shfl_xor(cv, o); cs += __shfl_xor(cs, o); ck += __shfl_xor(ck, o); }
+        cv = wave_sum_u32(cv); cs = wave_sum_u32(cs); ck = wave_sum_u32(ck);
         if (lane == 0) { s_cp[0][wave] = cv; s_cp[1][wave] = cs; s_cp[2][wave] = ck; }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { pn += __shfl_xor(pn, o); pf += __shfl_xor(pf, o); tn += __shfl_xor(tn, o); }
+    pn = wave_sum_u32(pn); pf = wave_sum_u32(pf); tn = wave_sum_u32(tn);
     if (lane == 0) { s_red[0][wave] = pn; s_red[1][wave] = pf; }
     __shared__ uint32_t s_tn[4];
     if (lane == 0) s_tn[wave] = tn;
