@@ -285,6 +285,12 @@ __device__ __forceinline__ float ord2f(uint32_t o)
     return __uint_as_float((o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o);
 }
 
+// value of lane `l` (wave-uniform index) for every lane: v_readlane instead of a ds_bpermute round trip
+__device__ __forceinline__ uint32_t lane_bcast(uint32_t v, int l)
+{
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, __builtin_amdgcn_readfirstlane(l));
+}
+
 // Wave-wide reductions with DPP (gfx9 row_shr / row_bcast): six VALU instructions and no LDS traffic, against six
 // ds_bpermute round trips for a __shfl_xor butterfly.  All 64 lanes must be active; lanes that do not take part pass the
 // identity (0 for both max and sum of unsigned).  The result is returned wave-uniform (read from lane 63).

@@ -840,9 +840,9 @@ __global__ __launch_bounds__(256) void k_compact(Model M, DevState *__restrict__
                 m_dead = had_dead ? tile_dead[tt] : 0u;
             }
             const int sl = (int)(iter & 63u);
-            allow = (uint32_t)__shfl((int)m_allow, sl); nconf = (uint32_t)__shfl((int)m_nconf, sl);
-            nkill_full = (uint32_t)__shfl((int)m_nkill, sl); base_id = (uint32_t)__shfl((int)m_base, sl);
-            tdead = (uint32_t)__shfl((int)m_dead, sl);
+            allow = lane_bcast(m_allow, sl); nconf = lane_bcast(m_nconf, sl);
+            nkill_full = lane_bcast(m_nkill, sl); base_id = lane_bcast(m_base, sl);
+            tdead = lane_bcast(m_dead, sl);
             skipbit = (skipmask >> (iter & 63u)) & 1ull;
             rr_tile += gridDim.x; ++iter;
         } else {
@@ -1040,8 +1040,8 @@ __global__ __launch_bounds__(256) void k_cull_lazy(Model M, const DevState *__re
             m_dead = had_dead ? tile_dead[tt] : 0u;
         }
         const int sl = (int)(iter & 63u);
-        const uint32_t nconf = (uint32_t)__shfl((int)m_nconf, sl), nkill = (uint32_t)__shfl((int)m_nkill, sl);
-        const uint32_t tdead = (uint32_t)__shfl((int)m_dead, sl);
+        const uint32_t nconf = lane_bcast(m_nconf, sl), nkill = lane_bcast(m_nkill, sl);
+        const uint32_t tdead = lane_bcast(m_dead, sl);
         const uint32_t tn = min((uint32_t)TILE, N - tile * TILE);
         const bool touched = nconf != 0u || nkill != 0u;                                  // workgroup-uniform
         const bool nosplat = !SPLAT || ((skipmask >> (iter & 63u)) & 1ull);              // box outside the index map's view
@@ -1120,9 +1120,7 @@ __global__ __launch_bounds__(256) void k_cull_lazy_frame(Model M, DevState *__re
     const uint32_t nwg = gridDim.x - 1u;               // workers; workgroup 0 (dispatched first) publishes
     const bool publisher = blockIdx.x == 0u;
     const uint32_t wi = blockIdx.x - 1u;               // worker index
-    uint32_t ctotal = conf_sub[lane];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) ctotal += __shfl_xor(ctotal, o);
+    const uint32_t ctotal = wave_sum_u32(conf_sub[lane]);
     const uint32_t N = st->count;                      // occupied slots: unchanged by this cull
     const SurfelSet set = M.s[st->cur];
     const uint32_t ntiles = (N + TILE - 1) / TILE;
@@ -1236,8 +1234,8 @@ __global__ __launch_bounds__(256) void k_cull_lazy_frame(Model M, DevState *__re
             m_dead = tile_dead[tt];
         }
         const int sl = (int)(iter & 63u);
-        const uint32_t nconf = (uint32_t)__shfl((int)m_nconf, sl), nkill = (uint32_t)__shfl((int)m_nkill, sl);
-        const uint32_t tdead = (uint32_t)__shfl((int)m_dead, sl);
+        const uint32_t nconf = lane_bcast(m_nconf, sl), nkill = lane_bcast(m_nkill, sl);
+        const uint32_t tdead = lane_bcast(m_dead, sl);
         const uint32_t tn = min((uint32_t)TILE, N - tile * TILE);
         uint32_t allow = nconf;
         if (cap_binds) {                             // workgroup-uniform
