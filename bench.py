@@ -223,6 +223,7 @@ def main():
     barrier()
     t0 = time.perf_counter()
     run(sm, Wm, Wm + K)
+    t_enq = time.perf_counter() - t0              # host time to enqueue the K frames (no waiting inside)
     sm.sync()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -367,6 +368,7 @@ def main():
         "cpu_baseline": cpu,
         "kernels": kern,
         "frame_ms_gpu_events": tim["run"],
+        "host_enqueue_ms_per_step": t_enq / K * 1e3,
         "event_overhead_ms": tim.get("event_overhead", 0.0),
         "gen_seconds": t_gen,
     }

@@ -20,6 +20,20 @@
 
 #define SURFEL_F 12
 
+/* ---- sensitivity variants (tools/oracle_sensitivity.py).  The parity contract is the build with NONE of these
+ * defined; each switch replaces one of the free choices DESIGN.md 2 lists by another plausible GL behaviour, so that
+ * the effect of that choice on counts and fields can be measured (profiles/oracle_sensitivity.md):
+ *   SMO_VAR_RCP        a / b evaluated as a * (1 / b)     (shader compilers commonly lower division this way)
+ *   SMO_VAR_LIBM       acosf / expf of libm instead of the fixed kernels
+ *   SMO_VAR_D24_TRUNC  24-bit depth = trunc(z * (2^24 - 1)) instead of round-half-up
+ *   SMO_VAR_INV_DOUBLE pose.inverse() evaluated in double precision, rounded once
+ * (FMA contraction is a compiler switch: -ffp-contract=fast -mfma.) */
+#ifdef SMO_VAR_RCP
+static inline float fdiv(float a, float b) { return a * (1.0f / b); }
+#else
+static inline float fdiv(float a, float b) { return a / b; }
+#endif
+
 struct smo_ctx {
     smo_config c;
     int P;
@@ -96,7 +110,7 @@ static inline void cross3(const float *a, const float *b, float *o)
 static inline void normalize3(float *v)
 {
     float l = sqrtf(dot3(v, v));
-    v[0] = v[0] / l; v[1] = v[1] / l; v[2] = v[2] / l;
+    v[0] = fdiv(v[0], l); v[1] = fdiv(v[1], l); v[2] = fdiv(v[2], l);
 }
 
 /* acos: fixed rational approximation (fdlibm asinf kernel constants), evaluated with
@@ -104,6 +118,9 @@ static inline void normalize3(float *v)
  * |x|>1 or NaN -> NaN (data.vert:54-57 then compares NaN < 0.5 -> false, K13). */
 float smo_acosf(float x)
 {
+#ifdef SMO_VAR_LIBM
+    return acosf(x);
+#endif
     const float pS0 = 1.6666586697e-01f, pS1 = -4.2743422091e-02f, pS2 = -8.6563630030e-03f;
     const float qS1 = -7.0662963390e-01f;
     const float PIO2 = 1.57079637050628662109375f, PI = 3.1415927410125732421875f;
@@ -128,6 +145,9 @@ float smo_acosf(float x)
 /* exp: k = rint(x*log2e); r = (x - k*ln2hi) - k*ln2lo; degree-6 Taylor Horner; ldexp (A9) */
 float smo_expf(float x)
 {
+#ifdef SMO_VAR_LIBM
+    return expf(x);
+#endif
     const float LOG2E = 1.44269502162933349609375f;
     const float LN2HI = 0.693145751953125f, LN2LO = 1.428606765330187045037746429443359375e-06f;
     float k = rintf(x * LOG2E);
@@ -163,19 +183,26 @@ float smo_encode_color(float r, float g, float b, uint32_t sem)
 /* surfels.glsl:19-32; cam.z = 1/fx, cam.w = 1/fy */
 float smo_get_radius(float depth, float norm_z, float inv_fx, float inv_fy)
 {
-    float meanFocal = ((1.0f / fabsf(inv_fx)) + (1.0f / fabsf(inv_fy))) / 2.0f;
+    float meanFocal = fdiv(fdiv(1.0f, fabsf(inv_fx)) + fdiv(1.0f, fabsf(inv_fy)), 2.0f);
     const float sqrt2 = 1.41421356237f;
-    float radius = (depth / meanFocal) * sqrt2;
-    float radius_n = radius / fabsf(norm_z);
+    float radius = fdiv(depth, meanFocal) * sqrt2;
+    float radius_n = fdiv(radius, fabsf(norm_z));
     radius_n = min_glsl(2.0f * radius, radius_n);
     return radius_n;
 }
 
 /* general 4x4 inverse, column-major, cofactor expansion, inv = adj * (1/det).
  * Stands in for Eigen::Matrix4f::inverse() (src/GlobalModel.cpp:419, src/IndexMap.cpp:157). */
+#ifdef SMO_VAR_INV_DOUBLE
+void smo_invert4(const float *mf, float *out)
+{
+    double m[16], inv[16];
+    for (int i = 0; i < 16; ++i) m[i] = mf[i];
+#else
 void smo_invert4(const float *m, float *out)
 {
     float inv[16];
+#endif
     inv[0] = m[5] * m[10] * m[15] - m[5] * m[11] * m[14] - m[9] * m[6] * m[15] +
              m[9] * m[7] * m[14] + m[13] * m[6] * m[11] - m[13] * m[7] * m[10];
     inv[4] = -m[4] * m[10] * m[15] + m[4] * m[11] * m[14] + m[8] * m[6] * m[15] -
@@ -208,9 +235,14 @@ void smo_invert4(const float *m, float *out)
               m[4] * m[3] * m[9] - m[8] * m[1] * m[7] + m[8] * m[3] * m[5];
     inv[15] = m[0] * m[5] * m[10] - m[0] * m[6] * m[9] - m[4] * m[1] * m[10] +
               m[4] * m[2] * m[9] + m[8] * m[1] * m[6] - m[8] * m[2] * m[5];
+#ifdef SMO_VAR_INV_DOUBLE
+    double det = m[0] * inv[0] + m[1] * inv[4] + m[2] * inv[8] + m[3] * inv[12];
+    for (int i = 0; i < 16; ++i) out[i] = (float)(inv[i] / det);
+#else
     float det = m[0] * inv[0] + m[1] * inv[4] + m[2] * inv[8] + m[3] * inv[12];
     float rdet = 1.0f / det;
     for (int i = 0; i < 16; ++i) out[i] = inv[i] * rdet;
+#endif
 }
 
 /* column-major 4x4 product, c_ij = ((a_i0 b_0j + a_i1 b_1j) + a_i2 b_2j) + a_i3 b_3j */
@@ -500,15 +532,15 @@ int smo_stage_process_conflict(smo_ctx *s, const float *pose, float min_depth, f
         const float *v = s->model + (size_t)k * SURFEL_F;
         float ph[4];
         xform(t_inv, v[0], v[1], v[2], ph);
-        float xl = ph[0] / ph[2];
-        float yl = ph[1] / ph[2];
+        float xl = fdiv(ph[0], ph[2]);
+        float yl = fdiv(ph[1], ph[2]);
         float u = c->fx * xl + c->cx;
         float vv = c->fy * yl + c->cy;
         if (u < c->stereo_border || u > cols || vv < 0.0f || vv > rows || ph[2] <= min_depth ||
             ph[2] >= max_depth)
             continue;   /* conf_id = -10 */
         float lambda = sqrtf((xl * xl + yl * yl) + 1.0f);
-        int ti = tex_idx(u / cols, W), tj = tex_idx(vv / rows, H);
+        int ti = tex_idx(fdiv(u, cols), W), tj = tex_idx(fdiv(vv, rows), H);
         float depth = s->depth_metric[(size_t)tj * W + ti];
         uint32_t sem = s->sem[(size_t)tj * W + ti];
         if (sem == 10u) depth = max_depth + 1.0f;
@@ -607,9 +639,9 @@ int smo_stage_predict_indices(smo_ctx *s, const float *pose, int time, float dep
         if (ph[2] >= depth_cutoff * 1.5f || ph[2] <= 0.0f ||
             (float)time - v[7] > (float)time_delta)
             continue;                             /* index_map.vert:45-50 (clipped at -10,-10) */
-        float xn = ((((c->fx * ph[0]) / ph[2]) + c->cx) - (cols * 0.5f)) / (cols * 0.5f);
-        float yn = ((((c->fy * ph[1]) / ph[2]) + c->cy) - (rows * 0.5f)) / (rows * 0.5f);
-        float zn = ph[2] / depth_cutoff;
+        float xn = fdiv((fdiv(c->fx * ph[0], ph[2]) + c->cx) - (cols * 0.5f), cols * 0.5f);
+        float yn = fdiv((fdiv(c->fy * ph[1], ph[2]) + c->cy) - (rows * 0.5f), rows * 0.5f);
+        float zn = fdiv(ph[2], depth_cutoff);
         if (!(xn >= -1.0f && xn <= 1.0f && yn >= -1.0f && yn <= 1.0f && zn >= -1.0f && zn <= 1.0f))
             continue;                             /* clip volume */
         float xw = (cols * 0.5f) * xn + (cols * 0.5f);
@@ -618,7 +650,11 @@ int smo_stage_predict_indices(smo_ctx *s, const float *pose, int time, float dep
         if (!(fxw >= 0.0f && fxw < cols && fyw >= 0.0f && fyw < rows)) continue;
         int px = (int)fxw, py = (int)fyw;
         float zw = 0.5f * zn + 0.5f;
+#ifdef SMO_VAR_D24_TRUNC
+        uint32_t d24 = (uint32_t)((double)zw * 16777215.0);
+#else
         uint32_t d24 = (uint32_t)floor((double)zw * 16777215.0 + 0.5);
+#endif
         if (d24 >= 16777215u) continue;           /* fails GL_LESS against the clear value */
         vis++;
         size_t p = (size_t)py * W + px;
@@ -717,11 +753,11 @@ int smo_stage_data_associate(smo_ctx *s, const float *pose, int time_i, float de
                     fabsf(vertConf[2] * lambda - vPosLocal[2] * lambda) <= fuseThresh) {
                     float cr[3];
                     cross3(ray, vertConf, cr);
-                    float dist = sqrtf(dot3(cr, cr)) / sqrtf(dot3(ray, ray));
+                    float dist = fdiv(sqrtf(dot3(cr, cr)), sqrtf(dot3(ray, ray)));
                     const float *normRad = s->inr + p * 4;
-                    float ang = smo_acosf(dot3(normRad, vNormLocal) /
-                                          (sqrtf(dot3(normRad, normRad)) *
-                                           sqrtf(dot3(vNormLocal, vNormLocal))));
+                    float ang = smo_acosf(fdiv(dot3(normRad, vNormLocal),
+                                               sqrtf(dot3(normRad, normRad)) *
+                                               sqrtf(dot3(vNormLocal, vNormLocal))));
                     if (dist < bestDist && fabsf(ang) < 0.5f) {
                         updateCounter++;
                         bestDist = dist;
@@ -746,20 +782,20 @@ int smo_stage_data_associate(smo_ctx *s, const float *pose, int time_i, float de
                     float w = c_n + c_o;
                     float pn[3];
                     for (int q = 0; q < 3; ++q)
-                        pn[q] = ((c_n * vPosLocal[q]) + (c_o * posLocal_o[q])) / w;
+                        pn[q] = fdiv((c_n * vPosLocal[q]) + (c_o * posLocal_o[q]), w);
                     xform(pose, pn[0], pn[1], pn[2], t4);
                     o[0] = t4[0]; o[1] = t4[1]; o[2] = t4[2]; o[3] = w;
                     float avg[3];
                     for (int q = 0; q < 3; ++q)
-                        avg[q] = ((c_n * color_n[q]) + (c_o * color_n[q])) / w;   /* sic :183 */
+                        avg[q] = fdiv((c_n * color_n[q]) + (c_o * color_n[q]), w);   /* sic :183 */
                     o[4] = smo_encode_color(avg[0], avg[1], avg[2], sem_n);
                     o[5] = u2f((uint32_t)bestID);
                     o[6] = initTime_o;
                     o[7] = time;
                     float nr[4];
-                    nr[0] = ((c_n * vNormLocal[0]) + (c_o * normRad_o[0])) / w;
-                    nr[1] = ((c_n * vNormLocal[1]) + (c_o * normRad_o[1])) / w;
-                    nr[2] = ((c_n * vNormLocal[2]) + (c_o * normRad_o[2])) / w;
+                    nr[0] = fdiv((c_n * vNormLocal[0]) + (c_o * normRad_o[0]), w);
+                    nr[1] = fdiv((c_n * vNormLocal[1]) + (c_o * normRad_o[1]), w);
+                    nr[2] = fdiv((c_n * vNormLocal[2]) + (c_o * normRad_o[2]), w);
                     rot3(pose, nr[0], nr[1], nr[2], n3);
                     normalize3(n3);
                     o[8] = n3[0]; o[9] = n3[1]; o[10] = n3[2];

@@ -182,8 +182,15 @@ struct sm_ctx {
     uint8_t *d_tile_flags = nullptr;   // per-tile skip flags of the current frame
     uint32_t *d_conf_part = nullptr;   // per-workgroup partial counters (instead of same-address atomics)
     uint2 *d_compact_part = nullptr;
-    uint4 *d_lazy_part = nullptr;      // partials of k_cull_lazy_frame (visible, splat-skipped, killed)
+    uint4 *d_lazy_part = nullptr;      // partials of k_cull_lazy_frame / k_surfel_pass (visible, splat-skipped, killed, conflict-skipped)
     bool lazy_part_live = false;       // the next append folds d_lazy_part (not d_compact_part) into the counters
+    // one pass over the surfels per frame (k_surfel_pass + k_pass_fixup) on the frames whose cull only marks the dead
+    bool one_pass = true;              // SM_ONE_PASS=0: keep k_conflict + k_cull_lazy(_frame)
+    uint4 *d_wave_cnt = nullptr;       // conflicts per quarter tile (one word per wave)
+    float *d_undo = nullptr;           // confidence before this frame's decrement, per slot (read only if the conflict cap binds)
+    uint2 *d_fix_part = nullptr;       // partials of k_pass_fixup (visible added, resurrected)
+    bool fix_part_live = false;        // the next append also folds d_fix_part in (when the cap bound)
+    bool ev_one_pass[EV_RING] = {};    // which frames of the event ring ran the one-pass kernels
     bool merged_finalize = true;       // SM_NO_MERGED_FINALIZE=1: keep k_cull_finalize + k_cull_lazy as separate launches
     uint32_t *d_conf_sub = nullptr;    // 2 x 64 conflict sub-counters (one set per frame parity: zeroed by that frame's k_prep)
     int conf_sub_set = 0;
@@ -390,6 +397,7 @@ int launch_cull_lazy_frame(sm_ctx *s, const FrameParams &fp, bool timed)
     const int grid = grid_surfels(s);
     s->n_compact_part = (uint32_t)grid;
     s->lazy_part_live = true;
+    s->fix_part_live = false;
     hipLaunchKernelGGL(k_cull_lazy_frame, dim3(grid + 1), dim3(256), 0, s->stream, s->M, s->d_state, fp, s->d_cm, s->d_dm, s->d_zm,
                        s->d_tile_cnt, s->d_keyT, s->d_tile_flags, s->d_lazy_part, s->d_alive, s->d_tile_dead, s->d_conf_part,
                        s->n_conf_part, s->d_conf_sub + 64 * s->conf_sub_set, s->d_stat);
@@ -398,9 +406,31 @@ int launch_cull_lazy_frame(sm_ctx *s, const FrameParams &fp, bool timed)
     return SM_OK;
 }
 
+// conflict test + cull (marks only) + splat in ONE pass over the surfels, then the publisher / cap fixup kernel
+int launch_surfel_pass(sm_ctx *s, const FrameParams &fp, bool timed)
+{
+    const int grid = grid_surfels(s);
+    s->n_conf_part = (uint32_t)grid;
+    s->n_compact_part = (uint32_t)grid;
+    s->lazy_part_live = true;
+    s->fix_part_live = true;
+    uint32_t *sub = s->d_conf_sub + 64 * s->conf_sub_set;
+    hipLaunchKernelGGL(k_surfel_pass, dim3(grid), dim3(256), 0, s->stream, s->M, s->d_state, fp, s->d_dcT, s->d_cm, s->d_dm /* km */,
+                       s->d_wave_cnt, s->d_tb, s->d_tile_flags, s->d_lazy_part, s->d_alive, s->d_tile_dead, sub, s->d_keyT, s->d_undo);
+    HIPCK(hipGetLastError());
+    if (mark(s, 2, timed) || mark(s, 3, timed)) return SM_E_HIP;
+    hipLaunchKernelGGL(k_pass_fixup, dim3(grid + 1), dim3(256), 0, s->stream, s->M, s->d_state, fp, s->d_cm, s->d_dm /* km */, s->d_wave_cnt,
+                       s->d_tile_flags, s->d_lazy_part, (uint32_t)grid, s->d_fix_part, s->d_alive, s->d_tile_dead, sub, s->d_keyT, s->d_undo,
+                       s->d_stat);
+    HIPCK(hipGetLastError());
+    if (mark(s, 4, timed)) return SM_E_HIP;
+    return SM_OK;
+}
+
 int launch_compact(sm_ctx *s, const FrameParams &fp, bool splat, bool timed)
 {
     s->lazy_part_live = false;
+    s->fix_part_live = false;
     if (!fp.compact_now) {
         // deferred compaction: the cull only marks the dead -- lean kernel, no co-residency requirement
         const int grid = grid_surfels(s);
@@ -575,8 +605,10 @@ int launch_associate(sm_ctx *s, const FrameParams &fp, bool timed)
         if (mark(s, 6, timed)) return SM_E_HIP;
         hipLaunchKernelGGL(k_append_scan, dim3(s->n_pix_blocks), dim3(PIX_BLOCK), 0, s->stream, s->M, s->d_state, fp, s->d_depthT,
                            s->d_rgbsT, s->d_xs, s->d_ys, s->d_validmask, s->d_fusedmask, s->d_blk_cnt, s->d_log, s->d_tb, s->d_compact_part,
-                           s->n_compact_part, s->d_alive, s->d_tile_dead, s->d_stat, s->lazy_part_live ? s->d_lazy_part : nullptr);
+                           s->n_compact_part, s->d_alive, s->d_tile_dead, s->d_stat, s->lazy_part_live ? s->d_lazy_part : nullptr,
+                           (s->lazy_part_live && s->fix_part_live) ? s->d_fix_part : nullptr);
         s->lazy_part_live = false;
+        s->fix_part_live = false;
         s->frames_enq++;
         HIPCK(hipGetLastError());
         if (mark(s, 7, timed)) return SM_E_HIP;
@@ -738,9 +770,15 @@ int enqueue_frame(sm_ctx *s, const uint8_t *d_rgb, const uint16_t *d_raw, const 
     // a cull that only marks the dead folds its finalize step into the cull kernel (measured: 66.0 -> 62.9 us/frame; with the
     // depth filter chain on a second stream it is the other way round, 86.5 -> 94.5 us, so those contexts keep the kernel)
     const bool fold = !fp.compact_now && s->merged_finalize && !s->use_fused_assoc && !s->overlap_capable;
-    if ((rc = launch_conflict(s, fp, true, fold))) return rc;    // :178-187
-    if (fold) { if ((rc = launch_cull_lazy_frame(s, fp, true))) return rc; }
-    else if ((rc = launch_compact(s, fp, true, true))) return rc;   // :189-197 (cull + mirror + index map)
+    // ... and, by default, does the conflict test in the same pass over the surfels (k_surfel_pass + k_pass_fixup)
+    const bool one_pass = !fp.compact_now && s->one_pass && !s->use_fused_assoc;
+    if (s->ev_ok) s->ev_one_pass[s->ev_frames % EV_RING] = one_pass;
+    if (one_pass) { if ((rc = launch_surfel_pass(s, fp, true))) return rc; }    // :178-197
+    else {
+        if ((rc = launch_conflict(s, fp, true, fold))) return rc;    // :178-187
+        if (fold) { if ((rc = launch_cull_lazy_frame(s, fp, true))) return rc; }
+        else if ((rc = launch_compact(s, fp, true, true))) return rc;   // :189-197 (cull + mirror + index map)
+    }
     if ((rc = launch_associate(s, fp, true))) return rc;   // :212-239
     bump_bound(s);
     end_frame(s);
@@ -897,7 +935,8 @@ sm_ctx *sm_create(const sm_config *c)
          dalloc(&s->d_group_tot, (ntiles / GROUP + 2) * 4) == SM_OK && dalloc(&s->d_group_base, ntiles / GROUP + 2) == SM_OK;
     s->tb_tiles = (uint32_t)(ntiles + P / 2 / TILE + 8);
     ok = ok && dalloc(&s->d_conf_part, (size_t)MAX_GRID * 4) == SM_OK && dalloc(&s->d_compact_part, (size_t)MAX_GRID) == SM_OK &&
-         dalloc(&s->d_lazy_part, (size_t)MAX_GRID) == SM_OK && dalloc(&s->d_conf_sub, (size_t)128) == SM_OK &&
+         dalloc(&s->d_lazy_part, (size_t)MAX_GRID) == SM_OK && dalloc(&s->d_fix_part, (size_t)MAX_GRID) == SM_OK &&
+         dalloc(&s->d_wave_cnt, ntiles) == SM_OK && dalloc(&s->d_undo, cap + TILE) == SM_OK && dalloc(&s->d_conf_sub, (size_t)128) == SM_OK &&
          hipMemset(s->d_conf_sub, 0, 512) == hipSuccess;
     ok = ok && dalloc(&s->d_tb, (size_t)s->tb_tiles * 8) == SM_OK && dalloc(&s->d_tile_flags, (size_t)s->tb_tiles) == SM_OK &&
          hipMemset(s->d_tile_flags, 0, s->tb_tiles) == hipSuccess;
@@ -971,6 +1010,7 @@ sm_ctx *sm_create(const sm_config *c)
             s->assoc_grid = std::max(1, cus * std::min(4, std::max(1, per_cu_a - 1)));
         s->use_fused_assoc = std::getenv("SM_FUSED_ASSOC") != nullptr;
         s->merged_finalize = std::getenv("SM_NO_MERGED_FINALIZE") == nullptr;
+        if (const char *e = std::getenv("SM_ONE_PASS")) s->one_pass = e[0] != '0';
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess && cus > 0 &&
             hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_compact<true>, 256, 0) == hipSuccess && per_cu > 0) {
             // the occupancy API can over-report by one block per CU (MI355X_MICROARCH.md): stay at <= 4 and below it
@@ -1011,7 +1051,7 @@ void sm_destroy(sm_ctx *s)
     (void)hipFree(s->d_rgb); (void)hipFree(s->d_sem); (void)hipFree(s->d_depth_raw); (void)hipFree(s->d_depth_f32);
     (void)hipFree(s->d_xs); (void)hipFree(s->d_ys); (void)hipFree(s->d_wtab);
     (void)hipFree(s->d_cm); (void)hipFree(s->d_dm); (void)hipFree(s->d_zm); (void)hipFree(s->d_alive); (void)hipFree(s->d_tile_dead);
-    (void)hipFree(s->d_tile_cnt); (void)hipFree(s->d_tile_allow); (void)hipFree(s->d_tile_keep); (void)hipFree(s->d_tile_flag); (void)hipFree(s->d_group_tot); (void)hipFree(s->d_group_base); (void)hipFree(s->d_tb); (void)hipFree(s->d_tile_flags); (void)hipFree(s->d_conf_part); (void)hipFree(s->d_compact_part); (void)hipFree(s->d_lazy_part); (void)hipFree(s->d_conf_sub);
+    (void)hipFree(s->d_tile_cnt); (void)hipFree(s->d_tile_allow); (void)hipFree(s->d_tile_keep); (void)hipFree(s->d_tile_flag); (void)hipFree(s->d_group_tot); (void)hipFree(s->d_group_base); (void)hipFree(s->d_tb); (void)hipFree(s->d_tile_flags); (void)hipFree(s->d_conf_part); (void)hipFree(s->d_compact_part); (void)hipFree(s->d_lazy_part); (void)hipFree(s->d_conf_sub); (void)hipFree(s->d_fix_part); (void)hipFree(s->d_wave_cnt); (void)hipFree(s->d_undo);
     (void)hipFree(s->d_validmask); (void)hipFree(s->d_fusedmask); (void)hipFree(s->d_blk_prefix); (void)hipFree(s->d_desc); (void)hipFree(s->d_blk_cnt);
     (void)hipFree(s->d_seg_lstart); (void)hipFree(s->d_seg_gbase); (void)hipFree(s->d_gseg_base); (void)hipFree(s->d_seg_keep);
     if (s->d_export) (void)hipFree(s->d_export);

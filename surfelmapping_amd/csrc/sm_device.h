@@ -60,6 +60,7 @@ struct DevState {
     uint32_t compact_ticket;  // work queue of k_compact: next moving tile (relative to first_moving) to hand out
     uint32_t stat_frames;     // frames whose append has completed (tag of the host-visible slot statistic)
     uint32_t first_live;      // slot of the first live surfel = the reference's surfel id 0 (conflict.geom:15, data.vert:142)
+    uint32_t fl_dirty;        // k_surfel_pass saw that surfel die: k_pass_fixup looks for its successor
 };
 
 struct FrameLog { uint32_t tick, n_before, n_after_cull, n_kill, conflict_count, visible_count, fused_count, unstable_count, n_static, n_conf_skipped, n_splat_skipped, n_slots; };

@@ -1301,6 +1301,356 @@ __global__ __launch_bounds__(256) void k_cull_lazy_frame(Model M, DevState *__re
         blk_part[wi] = make_uint4(s_a[0] + s_a[1] + s_a[2] + s_a[3], skipped, s_b[0] + s_b[1] + s_b[2] + s_b[3], 0u);
 }
 
+// ---------------------------------------------------------------------------------------------
+// ONE pass over the surfels per frame (p2 + p3 + p4 + p6 of a frame whose cull only marks the dead):
+// conflict test (conflict.vert:25-83, conflict.geom:13-24), confidence decrement (conflict.vert:72,
+// update_conf.vert:11-27), cull (back_map.geom:15-28: the dead keep their slots) and index-map splat
+// (index_map.vert:38-64) from ONE load of pos_conf and ONE world->camera transform per surfel.
+//
+// The "first W*H conflicts only" rule (conflictVbo holds W*H records, src/GlobalModel.cpp:54-57) needs the
+// conflict total, which exists only after the pass: the pass therefore treats EVERY conflict as effective and
+// leaves what k_pass_fixup needs to take the surplus back, exactly, should the cap bind:
+//   cm[word]        conflicts of the 64 slots of `word` (valid, not the id-0 surfel)
+//   km[word]        slots this pass killed BECAUSE of a conflict (alive and conf > 0 before, conf - 1 <= 0)
+//   wave_cnt[tile]  conflicts per 256-slot quarter of the tile (uint4; one word per wave, no barrier)
+//   undo[slot]      the confidence a surviving, decremented surfel had before (restoring by +1.0f would
+//                   not be exact for every float)
+// Each wave settles four consecutive 64-slot words on its own: no LDS, no barrier inside a tile.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_surfel_pass(Model M, DevState *__restrict__ st, FrameParams fp,
+                                                     const uint2 *__restrict__ dcT, uint64_t *__restrict__ cm,
+                                                     uint64_t *__restrict__ km, uint4 *__restrict__ wave_cnt,
+                                                     const uint32_t *__restrict__ tb, uint8_t *__restrict__ tile_flags,
+                                                     uint4 *__restrict__ part /* [grid] (visible, splat-skipped, killed, conflict-skipped) */,
+                                                     uint64_t *__restrict__ alive, uint32_t *__restrict__ tile_dead,
+                                                     uint32_t *__restrict__ conf_sub, uint64_t *__restrict__ keyT,
+                                                     float *__restrict__ undo)
+{
+    __shared__ uint8_t s_flags[64];
+    __shared__ uint32_t s_a[4], s_b[4], s_c[4];
+    const uint32_t N = st->count;
+    const bool has_dead = st->garbage != 0u;
+    const uint32_t exempt = st->first_live;            // the surfel the reference addresses as id 0
+    const SurfelSet set = M.s[st->cur];
+    float4 *__restrict__ pc = set.pos_conf;
+    const uint32_t ntiles = (N + TILE - 1) / TILE;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t vis = 0, sskip = 0, cskip = 0, killed_w = 0, nconf_w = 0, iter = 0;
+    uint64_t skip0 = 0, skip1 = 0;
+    uint32_t m_dead = 0;
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x, ++iter) {
+        if ((iter & 63u) == 0u) {
+            __syncthreads();
+            tile_flags_batch(tile, gridDim.x, ntiles, fp, tb, s_flags);
+            __syncthreads();
+            const uint64_t tl = (uint64_t)tile + (uint64_t)lane * gridDim.x;
+            const uint32_t f = s_flags[lane];
+            if (wave == 0 && tl < ntiles) tile_flags[tl] = (uint8_t)f;      // bit 1 is read again by the fixup's repair
+            skip0 = __ballot((f & 1u) != 0u);
+            skip1 = __ballot((f & 2u) != 0u);
+            m_dead = (has_dead && tl < ntiles) ? tile_dead[tl] : 0u;
+        }
+        const int sl = (int)(iter & 63u);
+        const bool sk0 = (skip0 >> sl) & 1ull, sk1 = (skip1 >> sl) & 1ull;   // workgroup-uniform
+        const uint32_t tn = min((uint32_t)TILE, N - tile * TILE);
+        if (sk0) cskip += tn;
+        if (sk1) sskip += tn;
+        if (sk0 && sk1) {                       // the bulk of the map once the camera has passed: not even read
+            if (threadIdx.x == 0) wave_cnt[tile] = make_uint4(0u, 0u, 0u, 0u);
+            continue;
+        }
+        const uint32_t tdead = lane_bcast(m_dead, sl);
+        const uint32_t word0 = tile * TILE_WORDS + (uint32_t)wave * 4u;
+        // phase 1: the wave's four 16-byte loads (and the four times) in flight together
+        float4 v[4];
+        float pt[4];
+        uint64_t valid[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const uint32_t k = (word0 + r) * 64u + lane;
+            const uint32_t kc = min(k, N - 1u);
+            v[r] = pc[kc];
+            pt[r] = sk1 ? 0.0f : set.time[kc];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const uint64_t base = (uint64_t)(word0 + r) * 64u;
+            uint64_t range = 0ull;
+            if (base < N) { const uint64_t rem = (uint64_t)N - base; range = rem >= 64 ? ~0ull : ((1ull << rem) - 1ull); }
+            valid[r] = range & ((tdead != 0u) ? alive[word0 + r] : ~0ull);
+        }
+        uint64_t cw[4] = {0ull, 0ull, 0ull, 0ull}, kw[4] = {0ull, 0ull, 0ull, 0ull}, keep[4];
+        if (!sk0) {
+            // phase 2: projection + view test (conflict.vert:25-49); phase 3: the dependent (depth, class) gathers together
+            float zc[4], lam[4];
+            uint32_t qq[4];
+            bool inview[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                inview[r] = false; zc[r] = 0.f; lam[r] = 0.f; qq[r] = 0u;
+                if ((valid[r] >> lane) & 1ull) {
+                    const float3 ph = xform3(fp.t_inv, v[r].x, v[r].y, v[r].z);
+                    if (!(ph.z <= fp.min_depth || ph.z >= fp.max_depth)) {
+                        const float xl = ph.x / ph.z;
+                        const float yl = ph.y / ph.z;
+                        const float u = fp.fx * xl + fp.cx;
+                        const float vv = fp.fy * yl + fp.cy;
+                        if (!(u < fp.stereo_border || u > fp.cols || vv < 0.0f || vv > fp.rows)) {
+                            const int ti = tex_idx(u / fp.cols, fp.W), tj = tex_idx(vv / fp.rows, fp.H);
+                            qq[r] = (uint32_t)(ti * fp.H + tj);
+                            lam[r] = sqrtf((xl * xl + yl * yl) + 1.0f);
+                            zc[r] = ph.z;
+                            inview[r] = true;
+                        }
+                    }
+                }
+            }
+            uint2 g[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) g[r] = dcT[qq[r]];     // unconditional (pixel 0 for out-of-view lanes)
+            // phase 4: conflict rule (conflict.vert:51-73), ballots, the cull decision
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const uint32_t k = (word0 + r) * 64u + lane;
+                bool conflict = false;
+                if (inview[r]) {
+                    float depth = __uint_as_float(g[r].x);
+                    if ((g[r].y >> 24) == 10u) depth = fp.max_depth + 1.0f;
+                    if (fp.is_clean == 0 && depth == 0.0f) depth = fp.max_depth + 20.0f;
+                    conflict = (depth * lam[r] - zc[r] * lam[r] > fp.conflict_thresh * zc[r]) && (k != exempt);
+                }
+                const bool isv = (valid[r] >> lane) & 1ull;
+                const bool dies = isv && !(v[r].w - 1.0f > 0.0f);
+                const bool dead = isv && !(v[r].w > 0.0f);
+                const uint64_t c = __ballot(conflict), d = __ballot(dies), z = __ballot(dead);
+                cw[r] = c;
+                kw[r] = c & d & ~z;                        // killed by the conflict (and only by it)
+                keep[r] = valid[r] & ~(z | (c & d));
+                nconf_w += (uint32_t)__popcll(c);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) keep[r] = valid[r];   // a tile outside the conflict volume holds no dead surfel either
+        }
+        uint32_t killed = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const uint32_t word = word0 + r;
+            const uint32_t k = word * 64u + lane;
+            const bool kp = (keep[r] >> lane) & 1ull;
+            if (keep[r] != valid[r]) {
+                const uint64_t base = (uint64_t)word * 64u;
+                const uint64_t rem = (uint64_t)N - base;   // base < N here: valid[r] != 0
+                const uint64_t range = rem >= 64 ? ~0ull : ((1ull << rem) - 1ull);
+                if (lane == 0) alive[word] = keep[r] | ~range;                  // the dead keep their slots
+                killed += (uint32_t)__popcll(valid[r] ^ keep[r]);
+                if (k == exempt && ((valid[r] >> lane) & 1ull) && !kp) st->fl_dirty = 1u;   // "id 0" died: the fixup searches its successor
+            }
+            if (kp && ((cw[r] >> lane) & 1ull)) {
+                undo[k] = v[r].w;
+                pc[k].w = v[r].w - 1.0f;                                         // conflict.vert:72
+            }
+            if (!sk1) {                                                          // workgroup-uniform
+                bool drew = false;
+                if (kp) drew = splat_one(fp, v[r].x, v[r].y, v[r].z, pt[r], k, keyT);
+                vis += (uint32_t)__popcll(__ballot(drew));
+            }
+        }
+        if (!sk0) {
+            // the wave's 2 x 4 mask words in one store instruction (lanes 0..7), its conflict count in another
+            const uint64_t mw = (lane & 4) ? ((lane & 3) == 0 ? kw[0] : (lane & 3) == 1 ? kw[1] : (lane & 3) == 2 ? kw[2] : kw[3])
+                                           : ((lane & 3) == 0 ? cw[0] : (lane & 3) == 1 ? cw[1] : (lane & 3) == 2 ? cw[2] : cw[3]);
+            if (lane < 8) ((lane & 4) ? km : cm)[word0 + (lane & 3)] = mw;
+            uint32_t cwave = 0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) cwave += (uint32_t)__popcll(cw[r]);
+            if (lane == 0) reinterpret_cast<uint32_t *>(wave_cnt)[(size_t)tile * 4 + wave] = cwave;
+        } else if (lane == 0) {
+            reinterpret_cast<uint32_t *>(wave_cnt)[(size_t)tile * 4 + wave] = 0u;
+        }
+        if (killed && lane == 0) atomicAdd(&tile_dead[tile], killed);
+        killed_w += killed;
+    }
+    __syncthreads();
+    if (lane == 0) { s_a[wave] = vis; s_b[wave] = killed_w; s_c[wave] = nconf_w; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        part[blockIdx.x] = make_uint4(s_a[0] + s_a[1] + s_a[2] + s_a[3], sskip, s_b[0] + s_b[1] + s_b[2] + s_b[3], cskip);
+        const uint32_t nc = s_c[0] + s_c[1] + s_c[2] + s_c[3];
+        if (nc) atomicAdd(&conf_sub[blockIdx.x & 63u], nc);      // 64 counters, <= 32 adders each: one load per lane to read the total
+    }
+}
+
+// survivors of one 64-slot word after k_surfel_pass AND its fixup: alive now, or killed by a conflict that the cap
+// makes ineffective (ordinal >= cap).  `before` = conflicts in all slots below this word.
+__device__ __forceinline__ uint64_t ineffective_conflicts(uint64_t c, uint32_t before, uint32_t cap)
+{
+    if (before >= cap) return c;
+    return c & ~first_n_bits(c, cap - before);
+}
+
+// ---------------------------------------------------------------------------------------------
+// After k_surfel_pass: workgroup 0 publishes DevState (as k_cull_lazy_frame's publisher does); the other workgroups
+// return at once unless the conflict cap binds (total > W*H: src/GlobalModel.cpp:54-57).  Then they take
+// back every conflict beyond the first `cap` in slot order: a surfel the pass killed because of such a conflict is
+// resurrected (alive bit, dead count, splat), a surviving one gets its confidence back from the undo plane.
+// Conflict ordinals come from prefix sums of the per-quarter-tile counts.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pass_fixup(Model M, DevState *__restrict__ st, FrameParams fp,
+                                                    const uint64_t *__restrict__ cm, const uint64_t *__restrict__ km,
+                                                    const uint4 *__restrict__ wave_cnt, const uint8_t *__restrict__ tile_flags,
+                                                    const uint4 *__restrict__ part, uint32_t n_part,
+                                                    uint2 *__restrict__ fix_part /* [workers] (visible added, resurrected) */,
+                                                    uint64_t *__restrict__ alive, uint32_t *__restrict__ tile_dead,
+                                                    const uint32_t *__restrict__ conf_sub, uint64_t *__restrict__ keyT,
+                                                    const float *__restrict__ undo, unsigned long long *__restrict__ host_stat)
+{
+    __shared__ uint32_t s_a[4], s_b[4], s_c[4];
+    __shared__ uint32_t s_fl;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t nwg = gridDim.x - 1u;               // workers; workgroup 0 (dispatched first) publishes
+    const uint32_t ctotal = wave_sum_u32(conf_sub[lane]);
+    const uint32_t cap = fp.conflict_cap;
+    const bool cap_binds = ctotal > cap;
+    const uint32_t N = st->count;                      // occupied slots: unchanged by a cull that only marks the dead
+    const uint32_t ntiles = (N + TILE - 1) / TILE;
+    if (blockIdx.x == 0u) {
+        const uint32_t g0 = st->garbage, old_first = st->first_live;
+        const bool dirty = st->fl_dirty != 0u;
+        uint32_t cskip = 0;
+        for (uint32_t b = threadIdx.x; b < n_part; b += 256u) cskip += part[b].w;
+        cskip = wave_sum_u32(cskip);
+        if (lane == 0) s_a[wave] = cskip;
+        if (threadIdx.x == 0) s_fl = 0xFFFFFFFFu;
+        __syncthreads();
+        const uint32_t cskip_tot = s_a[0] + s_a[1] + s_a[2] + s_a[3];
+        uint32_t first_live = old_first;
+        if (dirty) {
+            // The surfel that was id 0 died in the pass (conf <= 0: only an uploaded model holds such surfels).  Its
+            // successor is the first slot that is alive after the fixup: alive now, or killed by a conflict beyond the cap.
+            first_live = N;
+            const uint32_t t0 = min(old_first, N ? N - 1u : 0u) / TILE;
+            uint32_t before = 0;                       // conflicts in the tiles below the one being searched
+            if (cap_binds) {
+                uint32_t p = 0;
+                for (uint32_t t = threadIdx.x; t < t0; t += 256u) { const uint4 c = wave_cnt[t]; p += c.x + c.y + c.z + c.w; }
+                p = wave_sum_u32(p);
+                if (lane == 0) s_c[wave] = p;
+                __syncthreads();
+                before = s_c[0] + s_c[1] + s_c[2] + s_c[3];
+                __syncthreads();
+            }
+            for (uint32_t t = t0; t < ntiles && N; ++t) {                 // one tile per round, 16 words on 16 threads
+                const uint4 c4 = wave_cnt[t];
+                if (threadIdx.x < TILE_WORDS) {
+                    const uint32_t word = t * TILE_WORDS + threadIdx.x;
+                    const uint64_t base = (uint64_t)word * 64u;
+                    if (base < N) {
+                        const uint64_t rem = (uint64_t)N - base;
+                        const uint64_t range = rem >= 64 ? ~0ull : ((1ull << rem) - 1ull);
+                        uint64_t live = alive[word] & range;
+                        if (cap_binds && (c4.x | c4.y | c4.z | c4.w)) {
+                            uint32_t pre = before;
+                            for (uint32_t x = t * TILE_WORDS; x < word; ++x) pre += (uint32_t)__popcll(cm[x]);
+                            live |= km[word] & ineffective_conflicts(cm[word], pre, cap) & range;
+                        }
+                        if (word == old_first / 64u) live &= ~((2ull << (old_first % 64u)) - 1ull);     // strictly after the old one
+                        if (live) atomicMin(&s_fl, word * 64u + (uint32_t)(__ffsll((long long)live) - 1));
+                    }
+                }
+                __syncthreads();
+                const uint32_t found = s_fl;
+                __syncthreads();
+                if (found != 0xFFFFFFFFu) { first_live = found; break; }
+                before += c4.x + c4.y + c4.z + c4.w;
+            }
+        }
+        if (threadIdx.x == 0) {
+            st->n_conf_skipped = cskip_tot;
+            st->n_static = N;
+            st->conflict_count = min(ctotal, cap);
+            if (fp.splat_follows) st->visible_count = 0;
+            st->cull_n = N;
+            st->cull_src = st->cur;
+            st->cull_dst = st->cur;
+            st->garbage_prev = g0;
+            st->cap_binds = cap_binds ? 1u : 0u;
+            st->do_compact = 0u;
+            st->first_live = first_live;
+            st->fl_dirty = 0u;
+            st->offset = N;                             // the dead keep their slots until the next compaction
+            if (host_stat)
+                __hip_atomic_store(host_stat, ((unsigned long long)st->stat_frames << 32) | (unsigned long long)N, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        return;
+    }
+    if (!cap_binds) return;
+    // ---- the cap binds: take the conflicts beyond the first `cap` back
+    const uint32_t wi = blockIdx.x - 1u;
+    const SurfelSet set = M.s[st->cur];
+    uint32_t cpre = 0;                                  // conflicts in all tiles below this workgroup's current one
+    {
+        uint32_t p = 0;
+        for (uint32_t t = threadIdx.x; t < min(wi, ntiles); t += 256u) { const uint4 c = wave_cnt[t]; p += c.x + c.y + c.z + c.w; }
+        p = wave_sum_u32(p);
+        if (lane == 0) s_c[wave] = p;
+        __syncthreads();
+        cpre = s_c[0] + s_c[1] + s_c[2] + s_c[3];
+        __syncthreads();
+    }
+    uint32_t vis = 0, resurrected = 0;
+    for (uint32_t tile = wi; tile < ntiles; tile += nwg) {
+        const uint4 c4 = wave_cnt[tile];
+        const uint32_t nconf = c4.x + c4.y + c4.z + c4.w;
+        const uint32_t tile_pre = cpre;
+        {   // advance the prefix to this workgroup's next tile
+            uint32_t p = 0;
+            for (uint32_t t = tile + threadIdx.x; t < min(tile + nwg, ntiles); t += 256u) { const uint4 c = wave_cnt[t]; p += c.x + c.y + c.z + c.w; }
+            p = wave_sum_u32(p);
+            __syncthreads();
+            if (lane == 0) s_c[wave] = p;
+            __syncthreads();
+            cpre += s_c[0] + s_c[1] + s_c[2] + s_c[3];
+        }
+        if (nconf == 0u || tile_pre + nconf <= cap) continue;              // every conflict of the tile is effective
+        const bool nosplat = (tile_flags[tile] & 2u) != 0u;
+        uint32_t wpre = tile_pre + (wave > 0 ? c4.x : 0u) + (wave > 1 ? c4.y : 0u) + (wave > 2 ? c4.z : 0u);
+        uint32_t res_wave = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const uint32_t word = tile * TILE_WORDS + (uint32_t)wave * 4u + (uint32_t)r;
+            if ((uint64_t)word * 64u >= N) break;                             // wave-uniform
+            const uint64_t c = cm[word];
+            const uint64_t ineff = ineffective_conflicts(c, wpre, cap);
+            wpre += (uint32_t)__popcll(c);
+            if (ineff == 0ull) continue;
+            const uint64_t res = ineff & km[word];                            // killed by a conflict that does not count
+            const uint64_t restore = ineff & ~res & alive[word];              // survived, decremented
+            const uint32_t k = word * 64u + lane;
+            if ((restore >> lane) & 1ull) set.pos_conf[k].w = undo[k];
+            if (res) {
+                if (lane == 0) alive[word] |= res;
+                res_wave += (uint32_t)__popcll(res);
+                if (!nosplat) {
+                    bool drew = false;
+                    if ((res >> lane) & 1ull) {
+                        const float4 pv = set.pos_conf[k];
+                        drew = splat_one(fp, pv.x, pv.y, pv.z, set.time[k], k, keyT);
+                    }
+                    vis += (uint32_t)__popcll(__ballot(drew));
+                }
+            }
+        }
+        if (res_wave && lane == 0) atomicSub(&tile_dead[tile], res_wave);
+        resurrected += res_wave;
+    }
+    __syncthreads();
+    if (lane == 0) { s_a[wave] = vis; s_b[wave] = resurrected; }
+    __syncthreads();
+    if (threadIdx.x == 0) fix_part[wi] = make_uint2(s_a[0] + s_a[1] + s_a[2] + s_a[3], s_b[0] + s_b[1] + s_b[2] + s_b[3]);
+}
+
 // standalone p6 (IndexMap::predictIndices) over the current model
 __global__ __launch_bounds__(256) void k_splat(Model M, DevState *__restrict__ st, FrameParams fp,
                                                uint64_t *__restrict__ keyT, const uint32_t *__restrict__ seg_lstart,
@@ -1766,7 +2116,8 @@ __global__ __launch_bounds__(PIX_BLOCK) void k_append_scan(Model M, DevState *__
                                                            uint32_t n_compact_part, uint64_t *__restrict__ alive,
                                                            uint32_t *__restrict__ tile_dead,
                                                            unsigned long long *__restrict__ host_stat,
-                                                           const uint4 *__restrict__ lazy_part /* k_cull_lazy_frame's partials (then compact_part is unused) */)
+                                                           const uint4 *__restrict__ lazy_part /* k_cull_lazy_frame's / k_surfel_pass's partials (then compact_part is unused) */,
+                                                           const uint2 *__restrict__ fix_part /* k_pass_fixup's (visible added, resurrected), read when the cap bound; or null */)
 {
     __shared__ uint32_t s_red[2][4];
     __shared__ uint32_t s_cp[3][4];
@@ -1789,9 +2140,11 @@ __global__ __launch_bounds__(PIX_BLOCK) void k_append_scan(Model M, DevState *__
     }
     uint32_t cv = 0, cs = 0, ck = 0;                              // visible / splat-skipped (/ killed) partials of the cull kernel
     if (last) {
-        if (lazy_part)
+        if (lazy_part) {
             for (uint32_t b = threadIdx.x; b < n_compact_part; b += PIX_BLOCK) { const uint4 c = lazy_part[b]; cv += c.x; cs += c.y; ck += c.z; }
-        else
+            if (fix_part && st->cap_binds)         // the conflict cap bound: the fixup resurrected surfels (and drew them)
+                for (uint32_t b = threadIdx.x; b < n_compact_part; b += PIX_BLOCK) { const uint2 c = fix_part[b]; cv += c.x; ck -= c.y; }
+        } else
             for (uint32_t b = threadIdx.x; b < n_compact_part; b += PIX_BLOCK) { const uint2 c = compact_part[b]; cv += c.x; cs += c.y; }
         cv = wave_sum_u32(cv); cs = wave_sum_u32(cs); ck = wave_sum_u32(ck);
         if (lane == 0) { s_cp[0][wave] = cv; s_cp[1][wave] = cs; s_cp[2][wave] = ck; }

@@ -159,3 +159,44 @@ def test_async_frames_with_dead_slots_match_oracle():
     h.sync()
     same_counts(o, h, "async")
     assert_models_equal(o.download_model(), h.download_model(), "async")
+
+
+@pytest.mark.parametrize("period", [1000, 3])
+def test_conflict_cap_binds_in_asynchronous_frames(period):
+    """The one-pass surfel kernel treats every conflict as effective and a fixup kernel takes the ones beyond the first
+    W*H (in surfel order) back: resurrect the surfels they killed, restore the confidences they decremented, draw the
+    resurrected ones into the index map.  Frames are enqueued without host waits; the cap binds in most of them
+    (20 000 surfels in view, 1 536 pixels), confidences are arbitrary floats (exact restore, not +1.0f)."""
+    cam = dict(width=48, height=32, fx=40.0, fy=40.0, cx=23.5, cy=15.5)
+    o, h = pair(cam, stereo_border=0.0, conflict_cap=1, max_sqrt_vertices=200, compact_period=period)
+    rng = np.random.default_rng(11)
+    n = 20000
+    m = synth.seeded_model(n, tick=1, seed=5)
+    m[:, 0] = rng.uniform(-1.5, 1.5, n)
+    m[:, 1] = rng.uniform(-1.0, 1.0, n)
+    m[:, 2] = rng.uniform(3.0, 6.0, n)
+    m[:, 3] = rng.uniform(0.5, 4.5, n).astype(np.float32)
+    m[::5, 3] = np.float32(16777218.0)            # conf - 1 is not representable: only an undo plane restores it
+    m[3::11, 3] = 0.0
+    o.upload_model(m); h.upload_model(m)
+    rgb = rng.integers(0, 255, (32, 48, 3), dtype=np.uint8)
+    sem = np.zeros((32, 48), np.uint8)
+    far = np.full((32, 48), 20000, np.uint16)
+    mid = np.full((32, 48), 4500, np.uint16)
+    P = 48 * 32
+    frames = [far, far, mid, far, far, mid, far, far, far]
+    bufs = []
+    for d in frames:
+        dr, dd, ds = h.device_alloc(P * 3), h.device_alloc(P * 2), h.device_alloc(P)
+        h.device_upload(dr, rgb); h.device_upload(dd, d); h.device_upload(ds, sem)
+        bufs.append((dr, dd, ds))
+    for d in frames:
+        o.process_frame(rgb, d, sem, IDENT)
+    for b in bufs:
+        h.process_frame_device(*b, IDENT)
+    h.sync()
+    same_counts(o, h, "async, cap binding")
+    log = h.read_frame_log(16)
+    assert (log["conflict_count"] == P).sum() >= 3, log["conflict_count"]
+    assert_models_equal(o.download_model(), h.download_model(), "async, cap binding")
+    np.testing.assert_array_equal(o.download_index_map()[0], h.download_index_map()[0])
