@@ -186,11 +186,19 @@ struct sm_ctx {
     bool lazy_part_live = false;       // the next append folds d_lazy_part (not d_compact_part) into the counters
     // one pass over the surfels per frame (k_surfel_pass + k_pass_fixup) on the frames whose cull only marks the dead
     bool one_pass = true;              // SM_ONE_PASS=0: keep k_conflict + k_cull_lazy(_frame)
+    bool use_list = true;              // SM_TILE_FLAGS_IN_PREP=0: the one-pass kernel evaluates the tile flags itself
     uint4 *d_wave_cnt = nullptr;       // conflicts per quarter tile (one word per wave)
     float *d_undo = nullptr;           // confidence before this frame's decrement, per slot (read only if the conflict cap binds)
     uint2 *d_fix_part = nullptr;       // partials of k_pass_fixup (visible added, resurrected)
     bool fix_part_live = false;        // the next append also folds d_fix_part in (when the cap bound)
+    uint32_t n_fix_part = 0;           // worker workgroups of the last k_pass_fixup
     bool ev_one_pass[EV_RING] = {};    // which frames of the event ring ran the one-pass kernels
+    // tile skip flags of the frame, evaluated by extra workgroups of k_prep (when k_prep runs after the previous frame: no second stream)
+    uint2 *d_prep_part = nullptr;
+    uint32_t n_prep_blocks = 0;        // flag workgroups the frame's k_prep ran (0: the pass kernel evaluates the flags itself)
+    bool want_list = false;            // set by enqueue_frame before begin_frame launches k_prep
+    int fix_grid = 128;
+    int pass_nw = 2;                   // 64-slot words a wave of k_surfel_pass settles at a time (SM_PASS_NW = 1, 2, 4)
     bool merged_finalize = true;       // SM_NO_MERGED_FINALIZE=1: keep k_cull_finalize + k_cull_lazy as separate launches
     uint32_t *d_conf_sub = nullptr;    // 2 x 64 conflict sub-counters (one set per frame parity: zeroed by that frame's k_prep)
     int conf_sub_set = 0;
@@ -350,9 +358,19 @@ int launch_prep(sm_ctx *s, const uint8_t *rgb, const uint16_t *raw, const uint8_
                 const FrameParams &fp, bool clear_keys, hipStream_t st = nullptr)
 {
     const int tiles = ((s->W + 31) / 32) * ((s->H + 31) / 32);
+    // the frame's tile skip flags for the one-pass surfel kernel: a few extra workgroups (128 tiles each per round)
+    TilePrep tp;
+    memset(&tp, 0, sizeof tp);
+    s->n_prep_blocks = 0;
+    if (clear_keys && s->want_list) {
+        const uint64_t ntl = ((uint64_t)s->count_bound + TILE - 1) / TILE;
+        tp.nfb = (uint32_t)std::min<uint64_t>(std::max<uint64_t>((ntl + 127) / 128, 1), 64);
+        tp.st = s->d_state; tp.tb = s->d_tb; tp.tile_flags = s->d_tile_flags; tp.wave_cnt = s->d_wave_cnt; tp.prep_part = s->d_prep_part;
+        s->n_prep_blocks = tp.nfb;
+    }
     // a frame's k_prep (clear_keys) also zeroes the conflict sub-counters of that frame (set chosen by begin_frame)
-    hipLaunchKernelGGL(k_prep, dim3(tiles), dim3(1024), 0, st ? st : s->stream, rgb, raw, sem, dm, s->d_depthT, s->d_rgbsT,
-                       clear_keys ? s->d_keyT : nullptr, fp, s->d_dcT, clear_keys ? s->d_conf_sub + 64 * s->conf_sub_set : nullptr);
+    hipLaunchKernelGGL(k_prep, dim3(tiles + tp.nfb), dim3(1024), 0, st ? st : s->stream, rgb, raw, sem, dm, s->d_depthT, s->d_rgbsT,
+                       clear_keys ? s->d_keyT : nullptr, fp, s->d_dcT, clear_keys ? s->d_conf_sub + 64 * s->conf_sub_set : nullptr, tp);
     HIPCK(hipGetLastError());
     return SM_OK;
 }
@@ -409,19 +427,27 @@ int launch_cull_lazy_frame(sm_ctx *s, const FrameParams &fp, bool timed)
 // conflict test + cull (marks only) + splat in ONE pass over the surfels, then the publisher / cap fixup kernel
 int launch_surfel_pass(sm_ctx *s, const FrameParams &fp, bool timed)
 {
+    const bool ready = s->n_prep_blocks != 0;        // k_prep evaluated the tile flags
     const int grid = grid_surfels(s);
+    const int fgrid = std::min(grid, s->fix_grid);
     s->n_conf_part = (uint32_t)grid;
     s->n_compact_part = (uint32_t)grid;
     s->lazy_part_live = true;
     s->fix_part_live = true;
+    s->n_fix_part = (uint32_t)fgrid;
     uint32_t *sub = s->d_conf_sub + 64 * s->conf_sub_set;
-    hipLaunchKernelGGL(k_surfel_pass, dim3(grid), dim3(256), 0, s->stream, s->M, s->d_state, fp, s->d_dcT, s->d_cm, s->d_dm /* km */,
-                       s->d_wave_cnt, s->d_tb, s->d_tile_flags, s->d_lazy_part, s->d_alive, s->d_tile_dead, sub, s->d_keyT, s->d_undo);
+    const uint32_t tile_bound = (uint32_t)std::max<uint64_t>(((uint64_t)s->count_bound + TILE - 1) / TILE, 1);
+#define SM_LAUNCH_PASS(R, NWV)                                                                                                             \
+    hipLaunchKernelGGL((k_surfel_pass<R, NWV>), dim3(grid), dim3(256), 0, s->stream, s->M, s->d_state, fp, s->d_dcT, s->d_cm, s->d_dm /* km */, \
+                       s->d_wave_cnt, s->d_tb, s->d_tile_flags, s->d_lazy_part, s->d_alive, s->d_tile_dead, sub, s->d_keyT, s->d_undo, tile_bound)
+    if (ready) { if (s->pass_nw == 1) SM_LAUNCH_PASS(true, 1); else if (s->pass_nw == 2) SM_LAUNCH_PASS(true, 2); else SM_LAUNCH_PASS(true, 4); }
+    else       { if (s->pass_nw == 1) SM_LAUNCH_PASS(false, 1); else if (s->pass_nw == 2) SM_LAUNCH_PASS(false, 2); else SM_LAUNCH_PASS(false, 4); }
+#undef SM_LAUNCH_PASS
     HIPCK(hipGetLastError());
     if (mark(s, 2, timed) || mark(s, 3, timed)) return SM_E_HIP;
-    hipLaunchKernelGGL(k_pass_fixup, dim3(grid + 1), dim3(256), 0, s->stream, s->M, s->d_state, fp, s->d_cm, s->d_dm /* km */, s->d_wave_cnt,
+    hipLaunchKernelGGL(k_pass_fixup, dim3(fgrid + 1), dim3(256), 0, s->stream, s->M, s->d_state, fp, s->d_cm, s->d_dm /* km */, s->d_wave_cnt,
                        s->d_tile_flags, s->d_lazy_part, (uint32_t)grid, s->d_fix_part, s->d_alive, s->d_tile_dead, sub, s->d_keyT, s->d_undo,
-                       s->d_stat);
+                       s->d_stat, s->d_prep_part, ready ? s->n_prep_blocks : 0u);
     HIPCK(hipGetLastError());
     if (mark(s, 4, timed)) return SM_E_HIP;
     return SM_OK;
@@ -606,7 +632,7 @@ int launch_associate(sm_ctx *s, const FrameParams &fp, bool timed)
         hipLaunchKernelGGL(k_append_scan, dim3(s->n_pix_blocks), dim3(PIX_BLOCK), 0, s->stream, s->M, s->d_state, fp, s->d_depthT,
                            s->d_rgbsT, s->d_xs, s->d_ys, s->d_validmask, s->d_fusedmask, s->d_blk_cnt, s->d_log, s->d_tb, s->d_compact_part,
                            s->n_compact_part, s->d_alive, s->d_tile_dead, s->d_stat, s->lazy_part_live ? s->d_lazy_part : nullptr,
-                           (s->lazy_part_live && s->fix_part_live) ? s->d_fix_part : nullptr);
+                           (s->lazy_part_live && s->fix_part_live) ? s->d_fix_part : nullptr, s->n_fix_part);
         s->lazy_part_live = false;
         s->fix_part_live = false;
         s->frames_enq++;
@@ -761,9 +787,15 @@ int enqueue_frame(sm_ctx *s, const uint8_t *d_rgb, const uint16_t *d_raw, const 
 {
     if (s->sh_world > 1) { g_err = "context is configured for sharding: use the sm_shard_* entry points"; return SM_E_ARG; }
     FrameParams fp;
+    // the cull's kind is decided first: a frame whose cull only marks the dead lets k_prep evaluate the tile skip flags for
+    // the one-pass surfel kernel (not when k_prep runs ahead of the previous frame on the second stream)
+    const bool fusing = s->ref_set && s->tick != 0 && !s->pending_cull;
+    const bool compact_now = fusing ? decide_compact(s) : true;
+    s->want_list = fusing && !compact_now && s->one_pass && s->use_list && !s->use_fused_assoc && !s->overlap;
     int rc = begin_frame(s, d_rgb, d_raw, d_sem, pose, &fp);
+    s->want_list = false;
     if (rc <= 0) return rc;
-    fp.compact_now = decide_compact(s) ? 1u : 0u;
+    fp.compact_now = compact_now ? 1u : 0u;
     note_cull(s, fp.compact_now != 0u);
     s->keys_are_slots = fp.compact_now == 0u;      // this frame's splat writes slot numbers iff nothing moves
     if (s->ev_ok) s->ev_compacted[s->ev_frames % EV_RING] = fp.compact_now != 0u;
@@ -937,6 +969,7 @@ sm_ctx *sm_create(const sm_config *c)
     ok = ok && dalloc(&s->d_conf_part, (size_t)MAX_GRID * 4) == SM_OK && dalloc(&s->d_compact_part, (size_t)MAX_GRID) == SM_OK &&
          dalloc(&s->d_lazy_part, (size_t)MAX_GRID) == SM_OK && dalloc(&s->d_fix_part, (size_t)MAX_GRID) == SM_OK &&
          dalloc(&s->d_wave_cnt, ntiles) == SM_OK && dalloc(&s->d_undo, cap + TILE) == SM_OK && dalloc(&s->d_conf_sub, (size_t)128) == SM_OK &&
+         dalloc(&s->d_prep_part, (size_t)64) == SM_OK &&
          hipMemset(s->d_conf_sub, 0, 512) == hipSuccess;
     ok = ok && dalloc(&s->d_tb, (size_t)s->tb_tiles * 8) == SM_OK && dalloc(&s->d_tile_flags, (size_t)s->tb_tiles) == SM_OK &&
          hipMemset(s->d_tile_flags, 0, s->tb_tiles) == hipSuccess;
@@ -1011,6 +1044,8 @@ sm_ctx *sm_create(const sm_config *c)
         s->use_fused_assoc = std::getenv("SM_FUSED_ASSOC") != nullptr;
         s->merged_finalize = std::getenv("SM_NO_MERGED_FINALIZE") == nullptr;
         if (const char *e = std::getenv("SM_ONE_PASS")) s->one_pass = e[0] != '0';
+        if (const char *e = std::getenv("SM_TILE_FLAGS_IN_PREP")) s->use_list = e[0] != '0';
+        if (const char *e = std::getenv("SM_PASS_NW")) { const int v = std::atoi(e); if (v == 1 || v == 2 || v == 4) s->pass_nw = v; }
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess && cus > 0 &&
             hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_compact<true>, 256, 0) == hipSuccess && per_cu > 0) {
             // the occupancy API can over-report by one block per CU (MI355X_MICROARCH.md): stay at <= 4 and below it
@@ -1051,7 +1086,7 @@ void sm_destroy(sm_ctx *s)
     (void)hipFree(s->d_rgb); (void)hipFree(s->d_sem); (void)hipFree(s->d_depth_raw); (void)hipFree(s->d_depth_f32);
     (void)hipFree(s->d_xs); (void)hipFree(s->d_ys); (void)hipFree(s->d_wtab);
     (void)hipFree(s->d_cm); (void)hipFree(s->d_dm); (void)hipFree(s->d_zm); (void)hipFree(s->d_alive); (void)hipFree(s->d_tile_dead);
-    (void)hipFree(s->d_tile_cnt); (void)hipFree(s->d_tile_allow); (void)hipFree(s->d_tile_keep); (void)hipFree(s->d_tile_flag); (void)hipFree(s->d_group_tot); (void)hipFree(s->d_group_base); (void)hipFree(s->d_tb); (void)hipFree(s->d_tile_flags); (void)hipFree(s->d_conf_part); (void)hipFree(s->d_compact_part); (void)hipFree(s->d_lazy_part); (void)hipFree(s->d_conf_sub); (void)hipFree(s->d_fix_part); (void)hipFree(s->d_wave_cnt); (void)hipFree(s->d_undo);
+    (void)hipFree(s->d_tile_cnt); (void)hipFree(s->d_tile_allow); (void)hipFree(s->d_tile_keep); (void)hipFree(s->d_tile_flag); (void)hipFree(s->d_group_tot); (void)hipFree(s->d_group_base); (void)hipFree(s->d_tb); (void)hipFree(s->d_tile_flags); (void)hipFree(s->d_conf_part); (void)hipFree(s->d_compact_part); (void)hipFree(s->d_lazy_part); (void)hipFree(s->d_conf_sub); (void)hipFree(s->d_fix_part); (void)hipFree(s->d_wave_cnt); (void)hipFree(s->d_undo); (void)hipFree(s->d_prep_part);
     (void)hipFree(s->d_validmask); (void)hipFree(s->d_fusedmask); (void)hipFree(s->d_blk_prefix); (void)hipFree(s->d_desc); (void)hipFree(s->d_blk_cnt);
     (void)hipFree(s->d_seg_lstart); (void)hipFree(s->d_seg_gbase); (void)hipFree(s->d_gseg_base); (void)hipFree(s->d_seg_keep);
     if (s->d_export) (void)hipFree(s->d_export);
@@ -1314,9 +1349,11 @@ int sm_set_frame(sm_ctx *s, const uint8_t *rgb, const float *depth_metric, const
     FrameParams fp = make_params(s, s->curr_pose);
     // re-pack every plane from the staged inputs; depth only when given (else keep depthT)
     const int tiles = ((s->W + 31) / 32) * ((s->H + 31) / 32);
+    TilePrep tp;
+    memset(&tp, 0, sizeof tp);
     hipLaunchKernelGGL(k_prep, dim3(tiles), dim3(1024), 0, s->stream, s->d_rgb, (const uint16_t *)nullptr, s->d_sem,
                        depth_metric ? s->d_depth_f32 : nullptr, depth_metric ? s->d_depthT : nullptr, s->d_rgbsT,
-                       (uint64_t *)nullptr, fp, s->d_dcT, (uint32_t *)nullptr);
+                       (uint64_t *)nullptr, fp, s->d_dcT, (uint32_t *)nullptr, tp);
     HIPCK(hipGetLastError());
     HIPCK(hipStreamSynchronize(s->stream));
     return SM_OK;

@@ -107,6 +107,82 @@ __device__ __forceinline__ void tile_flags_batch(uint32_t first, uint32_t stride
 }
 
 // ---------------------------------------------------------------------------------------------
+// The tile skip flags of a frame, evaluated by a few extra workgroups of k_prep: the pose is known when the frame's images
+// are prepared and the tile bounds are final by then (the previous frame's append precedes k_prep in stream order), so the
+// one-pass surfel kernel finds one byte per tile ready (loaded together with DevState) instead of opening with a round
+// of bounds loads + box tests + barriers on its critical path.  Tiles the conflict test skips get their (zero) conflict
+// counts here.  (A compacted list of the active tiles was tried: the returning atomic and the block scan it needs cost
+// k_prep 3 us at KITTI size and 10 us at 20 M surfels, and the list's extra load per tile cost the surfel kernel more
+// than the even sharing saved.)
+// ---------------------------------------------------------------------------------------------
+struct TilePrep {
+    const DevState *st;
+    const uint32_t *tb;
+    uint8_t *tile_flags;
+    uint4 *wave_cnt;
+    uint2 *prep_part;         // [nfb] (conflict-skipped, splat-skipped) surfels
+    uint32_t nfb;             // workgroups of k_prep that do this (0: none)
+};
+
+__device__ __forceinline__ void tile_prep_block(const FrameParams &fp, const TilePrep &tp)
+{
+    __shared__ uint32_t s_sk[2][16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane >> 3, c = lane & 7;                       // tile within the wave's 8, box corner
+    const uint32_t N = tp.st->count;
+    const uint32_t ntiles = (N + TILE - 1) / TILE;
+    uint32_t cskip = 0, sskip = 0;                               // lane c == 0 of every tile accumulates
+    for (uint32_t base = blockIdx.x * 128u; base < ntiles; base += tp.nfb * 128u) {   // workgroup-uniform
+        const uint32_t t = base + (uint32_t)wave * 8u + (uint32_t)j;
+        const bool in = t < ntiles;
+        const uint32_t *bd = tp.tb + (size_t)(in ? t : 0u) * 8;
+        const uint32_t b0 = bd[0], b1 = bd[1], b2 = bd[2], b3 = bd[3], b4 = bd[4], b5 = bd[5], b6 = bd[6], b7 = bd[7];
+        const float3 p = xform3(fp.t_inv, (c & 1) ? ord2f(b4) : ord2f(~b0), (c & 2) ? ord2f(b5) : ord2f(~b1),
+                                (c & 4) ? ord2f(b6) : ord2f(~b2));
+        const bool fin = (p.x - p.x == 0.0f) && (p.y - p.y == 0.0f) && (p.z - p.z == 0.0f);
+        const bool r_ = fp.fx * p.x + (fp.cx - fp.cols - 2.0f) * p.z > 0.0f;
+        const bool lc = fp.fx * p.x + (fp.cx - fp.stereo_border + 2.0f) * p.z < 0.0f;
+        const bool ls = fp.fx * p.x + (fp.cx + 2.0f) * p.z < 0.0f;
+        const bool be = fp.fy * p.y + (fp.cy - fp.rows - 2.0f) * p.z > 0.0f;
+        const bool ab = fp.fy * p.y + (fp.cy + 2.0f) * p.z < 0.0f;
+        float zmin = p.z, zmax = p.z;
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) { zmin = fminf(zmin, __shfl_xor(zmin, o)); zmax = fmaxf(zmax, __shfl_xor(zmax, o)); }
+        const int sh = j * 8;                                      // "all 8 corners" = the tile's byte of the ballot is 0xFF
+        const bool finite = ((__ballot(fin) >> sh) & 0xFFull) == 0xFFull;
+        const bool right = ((__ballot(r_) >> sh) & 0xFFull) == 0xFFull, left_c = ((__ballot(lc) >> sh) & 0xFFull) == 0xFFull;
+        const bool left_s = ((__ballot(ls) >> sh) & 0xFFull) == 0xFFull, below = ((__ballot(be) >> sh) & 0xFFull) == 0xFFull;
+        const bool above = ((__ballot(ab) >> sh) & 0xFFull) == 0xFFull;
+        uint32_t f = 0;
+        if (fp.use_bounds && b3 == 0u) {
+            if (b0 == 0u && b4 == 0u) {
+                f = 3u;                                            // no surfel recorded at all
+            } else if (finite) {
+                const bool front = zmin > 1.0e-3f;
+                if (zmax < fp.min_depth - 0.01f || zmin > fp.max_depth + 0.01f || (front && (right || left_c || below || above))) f |= 1u;
+                if (zmax < -0.01f || zmin > fp.depth_cutoff + 0.01f || (front && (right || left_s || below || above)) ||
+                    (float)fp.time - ord2f(b7) > (float)fp.time_delta)
+                    f |= 2u;
+            }
+        }
+        if (in && c == 0) {
+            const uint32_t tn = min((uint32_t)TILE, N - t * TILE);
+            tp.tile_flags[t] = (uint8_t)f;
+            if (f & 1u) { tp.wave_cnt[t] = make_uint4(0u, 0u, 0u, 0u); cskip += tn; }
+            if (f & 2u) sskip += tn;
+        }
+    }
+    cskip = wave_sum_u32(cskip); sskip = wave_sum_u32(sskip);
+    if (lane == 0) { s_sk[0][wave] = cskip; s_sk[1][wave] = sskip; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t a = 0, b = 0;
+        for (int w = 0; w < 16; ++w) { a += s_sk[0][w]; b += s_sk[1][w]; }
+        tp.prep_part[blockIdx.x] = make_uint2(a, b);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // p0a metricise (depth_metric.frag:15-35) + u8 RGB/semantic pack + LDS-tiled transpose to the
 // column-major frame layout + key-map clear.  32x32 pixel tile per 1024-thread workgroup.
 // ---------------------------------------------------------------------------------------------
@@ -117,14 +193,17 @@ __global__ __launch_bounds__(1024) void k_prep(const uint8_t *__restrict__ rgb,
                                                float *__restrict__ depthT, uint32_t *__restrict__ rgbsT,
                                                uint64_t *__restrict__ keyT, FrameParams fp,
                                                uint2 *__restrict__ dcT /* (depth bits, rgbs) per pixel: one 8-byte gather for the conflict test */,
-                                               uint32_t *__restrict__ conf_sub /* this frame's 64 conflict sub-counters, or null */)
+                                               uint32_t *__restrict__ conf_sub /* this frame's 64 conflict sub-counters, or null */,
+                                               TilePrep tp /* the first tp.nfb workgroups build the frame's tile flags + active-tile list */)
 {
+    if (blockIdx.x < tp.nfb) { tile_prep_block(fp, tp); return; }       // workgroup-uniform
+    const uint32_t bid = blockIdx.x - tp.nfb;
     __shared__ float s_d[32][33];
-    if (conf_sub && blockIdx.x == 0 && threadIdx.x < 64) conf_sub[threadIdx.x] = 0u;
+    if (conf_sub && bid == 0 && threadIdx.x < 64) conf_sub[threadIdx.x] = 0u;
     __shared__ uint32_t s_c[32][33];
     const int W = fp.W, H = fp.H;
     const int tiles_x = (W + 31) >> 5;
-    const int i0 = (blockIdx.x % tiles_x) << 5, j0 = (blockIdx.x / tiles_x) << 5;
+    const int i0 = (bid % tiles_x) << 5, j0 = (bid / tiles_x) << 5;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     {
         const int i = i0 + tx, j = j0 + ty;          // read: lanes along the image row
@@ -1317,6 +1396,149 @@ __global__ __launch_bounds__(256) void k_cull_lazy_frame(Model M, DevState *__re
 //                   not be exact for every float)
 // Each wave settles four consecutive 64-slot words on its own: no LDS, no barrier inside a tile.
 // ---------------------------------------------------------------------------------------------
+struct PassAcc { uint32_t vis, killed, nconf; };
+
+// NW consecutive 64-slot words (word0 ...) settled by one wave; sk0 / sk1: the tile's skip flags (conflict volume / index
+// map), any_dead: the tile holds slots killed by earlier frames.  Returns the conflicts found.
+template <int NW>
+__device__ __forceinline__ uint32_t pass_words(const SurfelSet &set, DevState *__restrict__ st, const FrameParams &fp,
+                                               const uint2 *__restrict__ dcT, uint64_t *__restrict__ cm, uint64_t *__restrict__ km,
+                                               uint64_t *__restrict__ alive, uint64_t *__restrict__ keyT, float *__restrict__ undo,
+                                               uint32_t N, uint32_t exempt, uint32_t word0, bool sk0, bool sk1,
+                                               bool any_dead, int lane, PassAcc &acc)
+{
+    float4 *__restrict__ pc = set.pos_conf;
+    // phase 1: the wave's 16-byte loads (and the times) in flight together
+    float4 v[NW];
+    float pt[NW];
+    uint64_t valid[NW];
+#pragma unroll
+    for (int r = 0; r < NW; ++r) {
+        const uint32_t k = (word0 + r) * 64u + lane;
+        const uint32_t kc = min(k, N - 1u);
+        v[r] = pc[kc];
+        pt[r] = sk1 ? 0.0f : set.time[kc];
+    }
+#pragma unroll
+    for (int r = 0; r < NW; ++r) {
+        const uint64_t base = (uint64_t)(word0 + r) * 64u;
+        uint64_t range = 0ull;
+        if (base < N) { const uint64_t rem = (uint64_t)N - base; range = rem >= 64 ? ~0ull : ((1ull << rem) - 1ull); }
+        valid[r] = range & (any_dead ? alive[word0 + r] : ~0ull);
+    }
+    uint64_t cw[NW], kw[NW], keep[NW];
+#pragma unroll
+    for (int r = 0; r < NW; ++r) { cw[r] = 0ull; kw[r] = 0ull; }
+    if (!sk0) {
+        // phase 2: projection + view test (conflict.vert:25-49); phase 3: the dependent (depth, class) gathers together
+        float zc[NW], lam[NW];
+        uint32_t qq[NW];
+        bool inview[NW];
+#pragma unroll
+        for (int r = 0; r < NW; ++r) {
+            inview[r] = false; zc[r] = 0.f; lam[r] = 0.f; qq[r] = 0u;
+            if ((valid[r] >> lane) & 1ull) {
+                const float3 ph = xform3(fp.t_inv, v[r].x, v[r].y, v[r].z);
+                if (!(ph.z <= fp.min_depth || ph.z >= fp.max_depth)) {
+                    const float xl = ph.x / ph.z;
+                    const float yl = ph.y / ph.z;
+                    const float u = fp.fx * xl + fp.cx;
+                    const float vv = fp.fy * yl + fp.cy;
+                    if (!(u < fp.stereo_border || u > fp.cols || vv < 0.0f || vv > fp.rows)) {
+                        const int ti = tex_idx(u / fp.cols, fp.W), tj = tex_idx(vv / fp.rows, fp.H);
+                        qq[r] = (uint32_t)(ti * fp.H + tj);
+                        lam[r] = sqrtf((xl * xl + yl * yl) + 1.0f);
+                        zc[r] = ph.z;
+                        inview[r] = true;
+                    }
+                }
+            }
+        }
+        uint2 g[NW];
+#pragma unroll
+        for (int r = 0; r < NW; ++r) g[r] = dcT[qq[r]];     // unconditional (pixel 0 for out-of-view lanes)
+        // phase 4: conflict rule (conflict.vert:51-73), ballots, the cull decision
+#pragma unroll
+        for (int r = 0; r < NW; ++r) {
+            const uint32_t k = (word0 + r) * 64u + lane;
+            bool conflict = false;
+            if (inview[r]) {
+                float depth = __uint_as_float(g[r].x);
+                if ((g[r].y >> 24) == 10u) depth = fp.max_depth + 1.0f;
+                if (fp.is_clean == 0 && depth == 0.0f) depth = fp.max_depth + 20.0f;
+                conflict = (depth * lam[r] - zc[r] * lam[r] > fp.conflict_thresh * zc[r]) && (k != exempt);
+            }
+            const bool isv = (valid[r] >> lane) & 1ull;
+            const bool dies = isv && !(v[r].w - 1.0f > 0.0f);
+            const bool dead = isv && !(v[r].w > 0.0f);
+            const uint64_t c = __ballot(conflict), d = __ballot(dies), z = __ballot(dead);
+            cw[r] = c;
+            kw[r] = c & d & ~z;                        // killed by the conflict (and only by it)
+            keep[r] = valid[r] & ~(z | (c & d));
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < NW; ++r) keep[r] = valid[r];   // a tile outside the conflict volume holds no dead surfel either
+    }
+#pragma unroll
+    for (int r = 0; r < NW; ++r) {
+        const uint32_t word = word0 + r;
+        const uint32_t k = word * 64u + lane;
+        const bool kp = (keep[r] >> lane) & 1ull;
+        if (keep[r] != valid[r]) {
+            const uint64_t base = (uint64_t)word * 64u;
+            const uint64_t rem = (uint64_t)N - base;   // base < N here: valid[r] != 0
+            const uint64_t range = rem >= 64 ? ~0ull : ((1ull << rem) - 1ull);
+            if (lane == 0) alive[word] = keep[r] | ~range;                  // the dead keep their slots
+            acc.killed += (uint32_t)__popcll(valid[r] ^ keep[r]);
+            if (k == exempt && ((valid[r] >> lane) & 1ull) && !kp) st->fl_dirty = 1u;   // "id 0" died: the fixup searches its successor
+        }
+        if (kp && ((cw[r] >> lane) & 1ull)) {
+            undo[k] = v[r].w;
+            pc[k].w = v[r].w - 1.0f;                                         // conflict.vert:72
+        }
+        if (!sk1) {                                                          // wave-uniform
+            bool drew = false;
+            if (kp) drew = splat_one(fp, v[r].x, v[r].y, v[r].z, pt[r], k, keyT);
+            acc.vis += (uint32_t)__popcll(__ballot(drew));
+        }
+    }
+    uint32_t cwave = 0;
+    if (!sk0) {
+        // the wave's 2 x NW mask words in one store instruction (lanes 0 .. 2 NW - 1)
+        uint64_t mw = 0ull;
+#pragma unroll
+        for (int r = 0; r < NW; ++r) { if (lane == r) mw = cw[r]; if (lane == NW + r) mw = kw[r]; cwave += (uint32_t)__popcll(cw[r]); }
+        if (lane < 2 * NW) (lane >= NW ? km : cm)[word0 + (uint32_t)(lane >= NW ? lane - NW : lane)] = mw;
+    }
+    return cwave;
+}
+
+// one quarter tile (4 x 64 slots, word0 = tile * 16 + quarter * 4) settled by one wave, NW words at a time
+template <int NW>
+__device__ __forceinline__ void pass_quarter(const SurfelSet &set, DevState *__restrict__ st, const FrameParams &fp,
+                                             const uint2 *__restrict__ dcT, uint64_t *__restrict__ cm, uint64_t *__restrict__ km,
+                                             uint4 *__restrict__ wave_cnt, uint64_t *__restrict__ alive,
+                                             uint32_t *__restrict__ tile_dead, uint64_t *__restrict__ keyT, float *__restrict__ undo,
+                                             uint32_t N, uint32_t exempt, uint32_t tile, uint32_t quarter, bool sk0, bool sk1,
+                                             bool any_dead, int lane, PassAcc &acc)
+{
+    const uint32_t word0 = tile * TILE_WORDS + quarter * 4u;
+    const uint32_t k0 = acc.killed;
+    uint32_t cwave = 0;
+#pragma unroll 1
+    for (int h = 0; h < 4; h += NW)
+        cwave += pass_words<NW>(set, st, fp, dcT, cm, km, alive, keyT, undo, N, exempt, word0 + (uint32_t)h, sk0, sk1, any_dead, lane, acc);
+    if (lane == 0) reinterpret_cast<uint32_t *>(wave_cnt)[(size_t)tile * 4 + quarter] = cwave;
+    const uint32_t killed = acc.killed - k0;
+    if (killed && lane == 0) atomicAdd(&tile_dead[tile], killed);
+    acc.nconf += cwave;
+}
+
+// READY = true: k_prep evaluated the tile skip flags of the frame (one byte per tile, loaded together with DevState);
+// READY = false: the kernel evaluates them itself (frames whose k_prep ran before the previous frame had finished: the
+// depth filter chain on the second stream).  Workgroup <-> tile round-robin, wave <-> quarter tile.
+template <bool READY, int NW>
 __global__ __launch_bounds__(256) void k_surfel_pass(Model M, DevState *__restrict__ st, FrameParams fp,
                                                      const uint2 *__restrict__ dcT, uint64_t *__restrict__ cm,
                                                      uint64_t *__restrict__ km, uint4 *__restrict__ wave_cnt,
@@ -1324,155 +1546,63 @@ __global__ __launch_bounds__(256) void k_surfel_pass(Model M, DevState *__restri
                                                      uint4 *__restrict__ part /* [grid] (visible, splat-skipped, killed, conflict-skipped) */,
                                                      uint64_t *__restrict__ alive, uint32_t *__restrict__ tile_dead,
                                                      uint32_t *__restrict__ conf_sub, uint64_t *__restrict__ keyT,
-                                                     float *__restrict__ undo)
+                                                     float *__restrict__ undo,
+                                                     uint32_t tile_bound /* host upper bound of the number of tiles (>= 1) */)
 {
     __shared__ uint8_t s_flags[64];
     __shared__ uint32_t s_a[4], s_b[4], s_c[4];
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    // flags and dead counts of this workgroup's first 64 tiles: addresses known without DevState, issued with it
+    uint32_t m_flag = 0, m_dead = 0;
+    if (READY) {
+        const uint64_t tl = min((uint64_t)blockIdx.x + (uint64_t)lane * gridDim.x, (uint64_t)tile_bound - 1u);
+        m_flag = tile_flags[tl];
+        m_dead = tile_dead[tl];
+    }
     const uint32_t N = st->count;
-    const bool has_dead = st->garbage != 0u;
     const uint32_t exempt = st->first_live;            // the surfel the reference addresses as id 0
+    const bool has_dead = st->garbage != 0u;
     const SurfelSet set = M.s[st->cur];
-    float4 *__restrict__ pc = set.pos_conf;
+    PassAcc acc = {0u, 0u, 0u};
+    uint32_t sskip = 0, cskip = 0;
     const uint32_t ntiles = (N + TILE - 1) / TILE;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t vis = 0, sskip = 0, cskip = 0, killed_w = 0, nconf_w = 0, iter = 0;
     uint64_t skip0 = 0, skip1 = 0;
-    uint32_t m_dead = 0;
+    uint32_t iter = 0;
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x, ++iter) {
         if ((iter & 63u) == 0u) {
-            __syncthreads();
-            tile_flags_batch(tile, gridDim.x, ntiles, fp, tb, s_flags);
-            __syncthreads();
             const uint64_t tl = (uint64_t)tile + (uint64_t)lane * gridDim.x;
-            const uint32_t f = s_flags[lane];
-            if (wave == 0 && tl < ntiles) tile_flags[tl] = (uint8_t)f;      // bit 1 is read again by the fixup's repair
+            uint32_t f;
+            if (READY) {
+                if (iter) { m_flag = tile_flags[min(tl, (uint64_t)ntiles - 1u)]; m_dead = tile_dead[min(tl, (uint64_t)ntiles - 1u)]; }
+                f = tl < ntiles ? m_flag : 3u;
+            } else {
+                __syncthreads();
+                tile_flags_batch(tile, gridDim.x, ntiles, fp, tb, s_flags);
+                __syncthreads();
+                f = s_flags[lane];
+                if (wave == 0 && tl < ntiles) tile_flags[tl] = (uint8_t)f;      // bit 1 is read again by the fixup's repair
+                m_dead = (has_dead && tl < ntiles) ? tile_dead[tl] : 0u;
+            }
             skip0 = __ballot((f & 1u) != 0u);
             skip1 = __ballot((f & 2u) != 0u);
-            m_dead = (has_dead && tl < ntiles) ? tile_dead[tl] : 0u;
         }
         const int sl = (int)(iter & 63u);
         const bool sk0 = (skip0 >> sl) & 1ull, sk1 = (skip1 >> sl) & 1ull;   // workgroup-uniform
-        const uint32_t tn = min((uint32_t)TILE, N - tile * TILE);
-        if (sk0) cskip += tn;
-        if (sk1) sskip += tn;
+        if (!READY) {
+            const uint32_t tn = min((uint32_t)TILE, N - tile * TILE);
+            if (sk0) cskip += tn;
+            if (sk1) sskip += tn;
+        }
         if (sk0 && sk1) {                       // the bulk of the map once the camera has passed: not even read
-            if (threadIdx.x == 0) wave_cnt[tile] = make_uint4(0u, 0u, 0u, 0u);
+            if (!READY && threadIdx.x == 0) wave_cnt[tile] = make_uint4(0u, 0u, 0u, 0u);
             continue;
         }
-        const uint32_t tdead = lane_bcast(m_dead, sl);
-        const uint32_t word0 = tile * TILE_WORDS + (uint32_t)wave * 4u;
-        // phase 1: the wave's four 16-byte loads (and the four times) in flight together
-        float4 v[4];
-        float pt[4];
-        uint64_t valid[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const uint32_t k = (word0 + r) * 64u + lane;
-            const uint32_t kc = min(k, N - 1u);
-            v[r] = pc[kc];
-            pt[r] = sk1 ? 0.0f : set.time[kc];
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const uint64_t base = (uint64_t)(word0 + r) * 64u;
-            uint64_t range = 0ull;
-            if (base < N) { const uint64_t rem = (uint64_t)N - base; range = rem >= 64 ? ~0ull : ((1ull << rem) - 1ull); }
-            valid[r] = range & ((tdead != 0u) ? alive[word0 + r] : ~0ull);
-        }
-        uint64_t cw[4] = {0ull, 0ull, 0ull, 0ull}, kw[4] = {0ull, 0ull, 0ull, 0ull}, keep[4];
-        if (!sk0) {
-            // phase 2: projection + view test (conflict.vert:25-49); phase 3: the dependent (depth, class) gathers together
-            float zc[4], lam[4];
-            uint32_t qq[4];
-            bool inview[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                inview[r] = false; zc[r] = 0.f; lam[r] = 0.f; qq[r] = 0u;
-                if ((valid[r] >> lane) & 1ull) {
-                    const float3 ph = xform3(fp.t_inv, v[r].x, v[r].y, v[r].z);
-                    if (!(ph.z <= fp.min_depth || ph.z >= fp.max_depth)) {
-                        const float xl = ph.x / ph.z;
-                        const float yl = ph.y / ph.z;
-                        const float u = fp.fx * xl + fp.cx;
-                        const float vv = fp.fy * yl + fp.cy;
-                        if (!(u < fp.stereo_border || u > fp.cols || vv < 0.0f || vv > fp.rows)) {
-                            const int ti = tex_idx(u / fp.cols, fp.W), tj = tex_idx(vv / fp.rows, fp.H);
-                            qq[r] = (uint32_t)(ti * fp.H + tj);
-                            lam[r] = sqrtf((xl * xl + yl * yl) + 1.0f);
-                            zc[r] = ph.z;
-                            inview[r] = true;
-                        }
-                    }
-                }
-            }
-            uint2 g[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) g[r] = dcT[qq[r]];     // unconditional (pixel 0 for out-of-view lanes)
-            // phase 4: conflict rule (conflict.vert:51-73), ballots, the cull decision
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const uint32_t k = (word0 + r) * 64u + lane;
-                bool conflict = false;
-                if (inview[r]) {
-                    float depth = __uint_as_float(g[r].x);
-                    if ((g[r].y >> 24) == 10u) depth = fp.max_depth + 1.0f;
-                    if (fp.is_clean == 0 && depth == 0.0f) depth = fp.max_depth + 20.0f;
-                    conflict = (depth * lam[r] - zc[r] * lam[r] > fp.conflict_thresh * zc[r]) && (k != exempt);
-                }
-                const bool isv = (valid[r] >> lane) & 1ull;
-                const bool dies = isv && !(v[r].w - 1.0f > 0.0f);
-                const bool dead = isv && !(v[r].w > 0.0f);
-                const uint64_t c = __ballot(conflict), d = __ballot(dies), z = __ballot(dead);
-                cw[r] = c;
-                kw[r] = c & d & ~z;                        // killed by the conflict (and only by it)
-                keep[r] = valid[r] & ~(z | (c & d));
-                nconf_w += (uint32_t)__popcll(c);
-            }
-        } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) keep[r] = valid[r];   // a tile outside the conflict volume holds no dead surfel either
-        }
-        uint32_t killed = 0;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const uint32_t word = word0 + r;
-            const uint32_t k = word * 64u + lane;
-            const bool kp = (keep[r] >> lane) & 1ull;
-            if (keep[r] != valid[r]) {
-                const uint64_t base = (uint64_t)word * 64u;
-                const uint64_t rem = (uint64_t)N - base;   // base < N here: valid[r] != 0
-                const uint64_t range = rem >= 64 ? ~0ull : ((1ull << rem) - 1ull);
-                if (lane == 0) alive[word] = keep[r] | ~range;                  // the dead keep their slots
-                killed += (uint32_t)__popcll(valid[r] ^ keep[r]);
-                if (k == exempt && ((valid[r] >> lane) & 1ull) && !kp) st->fl_dirty = 1u;   // "id 0" died: the fixup searches its successor
-            }
-            if (kp && ((cw[r] >> lane) & 1ull)) {
-                undo[k] = v[r].w;
-                pc[k].w = v[r].w - 1.0f;                                         // conflict.vert:72
-            }
-            if (!sk1) {                                                          // workgroup-uniform
-                bool drew = false;
-                if (kp) drew = splat_one(fp, v[r].x, v[r].y, v[r].z, pt[r], k, keyT);
-                vis += (uint32_t)__popcll(__ballot(drew));
-            }
-        }
-        if (!sk0) {
-            // the wave's 2 x 4 mask words in one store instruction (lanes 0..7), its conflict count in another
-            const uint64_t mw = (lane & 4) ? ((lane & 3) == 0 ? kw[0] : (lane & 3) == 1 ? kw[1] : (lane & 3) == 2 ? kw[2] : kw[3])
-                                           : ((lane & 3) == 0 ? cw[0] : (lane & 3) == 1 ? cw[1] : (lane & 3) == 2 ? cw[2] : cw[3]);
-            if (lane < 8) ((lane & 4) ? km : cm)[word0 + (lane & 3)] = mw;
-            uint32_t cwave = 0;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) cwave += (uint32_t)__popcll(cw[r]);
-            if (lane == 0) reinterpret_cast<uint32_t *>(wave_cnt)[(size_t)tile * 4 + wave] = cwave;
-        } else if (lane == 0) {
-            reinterpret_cast<uint32_t *>(wave_cnt)[(size_t)tile * 4 + wave] = 0u;
-        }
-        if (killed && lane == 0) atomicAdd(&tile_dead[tile], killed);
-        killed_w += killed;
+        pass_quarter<NW>(set, st, fp, dcT, cm, km, wave_cnt, alive, tile_dead, keyT, undo, N, exempt, tile, wave, sk0, sk1,
+                         has_dead && lane_bcast(m_dead, sl) != 0u, lane, acc);
     }
     __syncthreads();
-    if (lane == 0) { s_a[wave] = vis; s_b[wave] = killed_w; s_c[wave] = nconf_w; }
+    if (lane == 0) { s_a[wave] = acc.vis; s_b[wave] = acc.killed; s_c[wave] = acc.nconf; }
     __syncthreads();
     if (threadIdx.x == 0) {
         part[blockIdx.x] = make_uint4(s_a[0] + s_a[1] + s_a[2] + s_a[3], sskip, s_b[0] + s_b[1] + s_b[2] + s_b[3], cskip);
@@ -1503,7 +1633,8 @@ __global__ __launch_bounds__(256) void k_pass_fixup(Model M, DevState *__restric
                                                     uint2 *__restrict__ fix_part /* [workers] (visible added, resurrected) */,
                                                     uint64_t *__restrict__ alive, uint32_t *__restrict__ tile_dead,
                                                     const uint32_t *__restrict__ conf_sub, uint64_t *__restrict__ keyT,
-                                                    const float *__restrict__ undo, unsigned long long *__restrict__ host_stat)
+                                                    const float *__restrict__ undo, unsigned long long *__restrict__ host_stat,
+                                                    const uint2 *__restrict__ prep_part, uint32_t n_prep /* k_prep's skip statistics (it evaluated the tile flags), or 0 */)
 {
     __shared__ uint32_t s_a[4], s_b[4], s_c[4];
     __shared__ uint32_t s_fl;
@@ -1517,13 +1648,14 @@ __global__ __launch_bounds__(256) void k_pass_fixup(Model M, DevState *__restric
     if (blockIdx.x == 0u) {
         const uint32_t g0 = st->garbage, old_first = st->first_live;
         const bool dirty = st->fl_dirty != 0u;
-        uint32_t cskip = 0;
-        for (uint32_t b = threadIdx.x; b < n_part; b += 256u) cskip += part[b].w;
-        cskip = wave_sum_u32(cskip);
-        if (lane == 0) s_a[wave] = cskip;
+        uint32_t cskip = 0, sskip = 0;
+        if (n_prep) for (uint32_t b = threadIdx.x; b < n_prep; b += 256u) { const uint2 c = prep_part[b]; cskip += c.x; sskip += c.y; }
+        else for (uint32_t b = threadIdx.x; b < n_part; b += 256u) { const uint4 c = part[b]; cskip += c.w; sskip += c.y; }
+        cskip = wave_sum_u32(cskip); sskip = wave_sum_u32(sskip);
+        if (lane == 0) { s_a[wave] = cskip; s_b[wave] = sskip; }
         if (threadIdx.x == 0) s_fl = 0xFFFFFFFFu;
         __syncthreads();
-        const uint32_t cskip_tot = s_a[0] + s_a[1] + s_a[2] + s_a[3];
+        const uint32_t cskip_tot = s_a[0] + s_a[1] + s_a[2] + s_a[3], sskip_tot = s_b[0] + s_b[1] + s_b[2] + s_b[3];
         uint32_t first_live = old_first;
         if (dirty) {
             // The surfel that was id 0 died in the pass (conf <= 0: only an uploaded model holds such surfels).  Its
@@ -1567,6 +1699,7 @@ __global__ __launch_bounds__(256) void k_pass_fixup(Model M, DevState *__restric
         }
         if (threadIdx.x == 0) {
             st->n_conf_skipped = cskip_tot;
+            st->n_splat_skipped = sskip_tot;
             st->n_static = N;
             st->conflict_count = min(ctotal, cap);
             if (fp.splat_follows) st->visible_count = 0;
@@ -2117,7 +2250,8 @@ __global__ __launch_bounds__(PIX_BLOCK) void k_append_scan(Model M, DevState *__
                                                            uint32_t *__restrict__ tile_dead,
                                                            unsigned long long *__restrict__ host_stat,
                                                            const uint4 *__restrict__ lazy_part /* k_cull_lazy_frame's / k_surfel_pass's partials (then compact_part is unused) */,
-                                                           const uint2 *__restrict__ fix_part /* k_pass_fixup's (visible added, resurrected), read when the cap bound; or null */)
+                                                           const uint2 *__restrict__ fix_part /* k_pass_fixup's (visible added, resurrected), read when the cap bound; or null */,
+                                                           uint32_t n_fix_part)
 {
     __shared__ uint32_t s_red[2][4];
     __shared__ uint32_t s_cp[3][4];
@@ -2143,7 +2277,7 @@ __global__ __launch_bounds__(PIX_BLOCK) void k_append_scan(Model M, DevState *__
         if (lazy_part) {
             for (uint32_t b = threadIdx.x; b < n_compact_part; b += PIX_BLOCK) { const uint4 c = lazy_part[b]; cv += c.x; cs += c.y; ck += c.z; }
             if (fix_part && st->cap_binds)         // the conflict cap bound: the fixup resurrected surfels (and drew them)
-                for (uint32_t b = threadIdx.x; b < n_compact_part; b += PIX_BLOCK) { const uint2 c = fix_part[b]; cv += c.x; ck -= c.y; }
+                for (uint32_t b = threadIdx.x; b < n_fix_part; b += PIX_BLOCK) { const uint2 c = fix_part[b]; cv += c.x; ck -= c.y; }
         } else
             for (uint32_t b = threadIdx.x; b < n_compact_part; b += PIX_BLOCK) { const uint2 c = compact_part[b]; cv += c.x; cs += c.y; }
         cv = wave_sum_u32(cv); cs = wave_sum_u32(cs); ck = wave_sum_u32(ck);
@@ -2160,7 +2294,7 @@ __global__ __launch_bounds__(PIX_BLOCK) void k_append_scan(Model M, DevState *__
         const uint32_t ftot = s_red[1][0] + s_red[1][1] + s_red[1][2] + s_red[1][3];
         if (n_compact_part) {
             st->visible_count = s_cp[0][0] + s_cp[0][1] + s_cp[0][2] + s_cp[0][3];
-            st->n_splat_skipped = s_cp[1][0] + s_cp[1][1] + s_cp[1][2] + s_cp[1][3];
+            if (!fix_part) st->n_splat_skipped = s_cp[1][0] + s_cp[1][1] + s_cp[1][2] + s_cp[1][3];   // (k_pass_fixup published it already)
         }
         uint32_t garbage_now = garbage;
         if (lazy_part) {                          // the cull folded its finalize step in: complete the kill bookkeeping

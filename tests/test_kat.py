@@ -408,3 +408,106 @@ def test_remove_movings_rule():
     assert np.all(out[8:16, 8:16] == 0) and out[0, 0] == 6.0
     sem[:] = 0                                         # static classes are never removed
     assert np.array_equal(ol.remove_movings(cfg, d, sem, last2, IDENT), d)
+
+
+# ---------------------------------------------------------------- K14/K15 data.vert:177-208 (both fuse branches, by hand)
+def _f32(x):
+    return np.float32(x)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_k14_k15_fuse_branches_hand_derived(backend):
+    """Two surfels sit exactly on the rays of two checkerboard pixels of a fronto-parallel plane (identity pose, same
+    depth => |z_o*lambda - z*lambda| = 0 <= fuseThresh 0, normals equal => acos(1) = 0 < 0.5): both associate.
+    K14 data.vert:177-194 (radii_n < 1.5 r_o): confidence-weighted average of position and normal, colour := the NEW
+      colour through the sic average ((c_n*color_n + c_o*color_n)/w, :183), conf = c_n + c_o, radius = min, initTime
+      kept, time = tick.
+    K15 data.vert:195-208 (radii_n >= 1.5 r_o): geometry, colour and radius of the OLD surfel are kept, conf += 0.9,
+      time = tick.
+    Expected values are worked out below in float32 from the shader lines, not taken from either implementation."""
+    cfg, o = mk(backend)                       # 160 x 96, fx = fy = 100, cx = 79.5, cy = 47.5
+    z = _f32(4.0)
+    inv_f = _f32(1.0 / 100.0)                  # cam.z = 1/fx as float (src/GlobalModel.cpp:273-276)
+
+    def ray_point(i, j):                       # getVertex geometry.glsl:5-9 at pixel centre (i+0.5, j+0.5)
+        return np.array([(_f32(i + 0.5) - _f32(cfg.cx)) * z * inv_f, (_f32(j + 0.5) - _f32(cfg.cy)) * z * inv_f, z], np.float32)
+
+    pa, pb = ray_point(100, 51), ray_point(40, 21)       # (i + j) odd: candidate pixels
+    r_n = (z / ((_f32(1.0) / inv_f + _f32(1.0) / inv_f) / _f32(2.0))) * _f32(1.41421356237)     # surfels.glsl:19-32, n_z = 1
+    c_o_a, c_o_b = _f32(1.8), _f32(2.7)
+    r_a, r_b = _f32(0.05), _f32(0.03)
+    assert r_n < _f32(1.5) * r_a and not (r_n < _f32(1.5) * r_b)
+    model = np.stack([
+        surfel(0.0, 0.0, 9.0),                                                        # id 0: never associates (A5)
+        surfel(*pa, conf=c_o_a, sem=7, rgb=(10, 20, 30), t0=2.0, t1=3.0, r=r_a),      # K14
+        surfel(*pb, conf=c_o_b, sem=7, rgb=(10, 20, 30), t0=2.0, t1=3.0, r=r_b),      # K15
+    ])
+    o.upload_model(model)
+    o.set_tick(5)
+    rgb, depth, sem = plane_frame(cfg, 4000, sem_val=7)                               # colour (200, 100, 50)
+    o.process_frame(rgb, depth, sem, IDENT)
+    c = o.counts()
+    assert c["fused_count"] == 2 and c["conflict_count"] == 0 and c["offset"] == 3
+    m = o.download_model()
+    c_n = _f32(0.9)
+    # ---- K14
+    w = c_n + c_o_a
+    exp_pos = ((c_n * pa) + (c_o_a * pa)) / w                                         # :179, identity pose
+    np.testing.assert_array_equal(m[1, 0:3], exp_pos)
+    assert m[1, 3] == w
+    col = [_f32(v) / _f32(255.0) for v in (200, 100, 50)]
+    avg = [((c_n * cn) + (c_o_a * cn)) / w for cn in col]                             # :183 multiplies color_n twice
+    enc = [int(np.floor(np.float64(a * _f32(255.0)) + 0.5)) for a in avg]             # color.glsl:21-24 round()
+    assert enc == [200, 100, 50]                                                      # i.e. the new colour survives the average
+    assert bits(m[1, 4]) == (7 << 24 | 200 << 16 | 100 << 8 | 50)
+    assert m[1, 5] == 0.0 and m[1, 6] == 2.0 and m[1, 7] == 5.0                       # initTime kept, time = tick
+    nz = ((c_n * _f32(1.0)) + (c_o_a * _f32(1.0))) / w
+    np.testing.assert_array_equal(m[1, 8:11], np.float32([0.0, 0.0, nz / np.sqrt(nz * nz)]))
+    assert m[1, 11] == r_a                                                            # min(radii_n, r_o), :191
+    # ---- K15
+    np.testing.assert_array_equal(m[2, 0:3], pb)                                      # old position (identity pose)
+    assert m[2, 3] == c_n + c_o_b
+    assert bits(m[2, 4]) == (7 << 24 | 10 << 16 | 20 << 8 | 30)                       # old colour
+    assert m[2, 6] == 2.0 and m[2, 7] == 5.0
+    np.testing.assert_array_equal(m[2, 8:11], np.float32([0.0, 0.0, 1.0]))
+    assert m[2, 11] == r_b
+    np.testing.assert_array_equal(m[0], model[0])
+
+
+# ---------------------------------------------------------------- K16 src/GlobalModel.cpp:54-57 (conflictVbo = W*H records)
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("cap", [1, 0])
+def test_k16_first_wh_conflicts_only_hand_derived(backend, cap):
+    """150 surfels in view, all measured farther => every one but id 0 conflicts (conflict.vert:64-73, conflict.geom:15).
+    conflictVbo holds W*H = 128 records and transform feedback stops writing when it is full: ids
+    1..128 are decremented (0.9 - 1 <= 0 => culled by back_map.geom:17), ids 129..149 keep their confidence 0.9
+    untouched, conflictCount = 128.  With the cap off all 149 are culled.  Both the per-pass API and processFrame."""
+    W, H = 16, 8
+    _, o = mk(backend, W=W, H=H, conflict_cap=cap, max_sqrt_vertices=64)
+    fx, cxx, cyy = 100.0, W / 2 - 0.5, H / 2 - 0.5
+    n = 150
+    model = np.stack([surfel(((k % W) + 0.5 - cxx) * 5.0 / fx, (((k // W) % H) + 0.5 - cyy) * 5.0 / fx, 5.0, conf=0.9) for k in range(n)])
+    dm = np.full((H, W), 20.0, np.float32)
+    o.upload_model(model)
+    o.set_frame(depth_metric=dm, sem=np.zeros((H, W), np.uint8))
+    o.stage_process_conflict(IDENT, 1.0, 30.0, 0.0, 0)
+    assert o.counts()["conflict_count"] == (128 if cap else 149)
+    o.stage_update_conflict(); o.stage_back_mapping(); o.stage_build_model_map()
+    m = o.download_model()
+    if cap:
+        assert m.shape[0] == 1 + (149 - 128)
+        np.testing.assert_array_equal(m[0], model[0])
+        np.testing.assert_array_equal(m[1:], model[129:])              # untouched: confidence still 0.9
+    else:
+        assert m.shape[0] == 1
+    # the same through processFrame (frame path: conflict + cull + splat + associate + append)
+    _, o2 = mk(backend, W=W, H=H, conflict_cap=cap, max_sqrt_vertices=64)
+    o2.upload_model(model)
+    o2.set_tick(3)
+    rgb = np.zeros((H, W, 3), np.uint8)
+    o2.process_frame(rgb, np.full((H, W), 20000, np.uint16), np.zeros((H, W), np.uint8), IDENT)
+    c = o2.counts()
+    assert c["conflict_count"] == (128 if cap else 149)
+    assert c["offset"] == (22 if cap else 1)
+    m2 = o2.download_model()
+    np.testing.assert_array_equal(m2[:c["offset"]], m)
