@@ -198,6 +198,13 @@ struct sm_ctx {
     uint32_t n_prep_blocks = 0;        // flag workgroups the frame's k_prep ran (0: the pass kernel evaluates the flags itself)
     bool want_list = false;            // set by enqueue_frame before begin_frame launches k_prep
     int fix_grid = 128;
+    // direct append (k_associate_direct): candidate counts per association block / per group, group prefixes
+    bool direct = true;                // SM_DIRECT_APPEND=0: k_associate + k_append_scan on every frame
+    uint32_t *d_blk_cand = nullptr, *d_grp_cand = nullptr;
+    uint32_t *d_frame_sub = nullptr;   // 4 x 64 sub-counters: visible, killed (k_surfel_pass), new, fused (k_associate_direct)
+    uint32_t n_grp = 0;
+    bool pend_finalize = false;        // the last frame's statistics are completed by the next k_pass_fixup or by k_frame_finalize
+    int fix_set = 0;                   // k_pass_fixup's partials alternate between two sets (the previous frame's are read one frame later)
     int pass_nw = 2;                   // 64-slot words a wave of k_surfel_pass settles at a time (SM_PASS_NW = 1, 2, 4)
     bool merged_finalize = true;       // SM_NO_MERGED_FINALIZE=1: keep k_cull_finalize + k_cull_lazy as separate launches
     uint32_t *d_conf_sub = nullptr;    // 2 x 64 conflict sub-counters (one set per frame parity: zeroed by that frame's k_prep)
@@ -321,14 +328,28 @@ int push_state(sm_ctx *s)
     return SM_OK;
 }
 
+// a direct-append frame leaves its new / fused totals, the dead-slot total and its log entry to be completed by the next
+// frame's k_pass_fixup; everything else that reads them asks for the completion first
+int finalize_if_pending(sm_ctx *s)
+{
+    if (!s->pend_finalize) return SM_OK;
+    s->pend_finalize = false;
+    hipLaunchKernelGGL(k_frame_finalize, dim3(1), dim3(256), 0, s->stream, s->d_state, s->d_frame_sub,
+                       s->d_fix_part + (size_t)s->fix_set * MAX_GRID, s->n_fix_part, s->d_log);
+    HIPCK(hipGetLastError());
+    return SM_OK;
+}
+
 int pull_state(sm_ctx *s)
 {
+    int rcf = finalize_if_pending(s);
+    if (rcf) return rcf;
     HIPCK(hipMemcpyAsync(s->h_state, s->d_state, sizeof(DevState), hipMemcpyDeviceToHost, s->stream));
     HIPCK(hipStreamSynchronize(s->stream));
     s->idle_hint = true;
     const DevState &d = *s->h_state;
     s->counts.count = s->pending_cull ? s->count_before_cull : d.count - d.garbage;   // dead slots are not surfels
-    s->counts.offset = d.offset - d.garbage;
+    s->counts.offset = d.offset - (d.garbage - d.holes_last);   // (empty slots of fused candidates lie above `offset`)
     s->counts.data_count = d.data_count;
     s->counts.conflict_count = d.conflict_count;
     s->counts.unstable_count = d.unstable_count;
@@ -370,7 +391,7 @@ int launch_prep(sm_ctx *s, const uint8_t *rgb, const uint16_t *raw, const uint8_
     }
     // a frame's k_prep (clear_keys) also zeroes the conflict sub-counters of that frame (set chosen by begin_frame)
     hipLaunchKernelGGL(k_prep, dim3(tiles + tp.nfb), dim3(1024), 0, st ? st : s->stream, rgb, raw, sem, dm, s->d_depthT, s->d_rgbsT,
-                       clear_keys ? s->d_keyT : nullptr, fp, s->d_dcT, clear_keys ? s->d_conf_sub + 64 * s->conf_sub_set : nullptr, tp);
+                       clear_keys ? s->d_keyT : nullptr, fp, s->d_dcT, clear_keys ? s->d_conf_sub + SUB_SET * s->conf_sub_set : nullptr, tp);
     HIPCK(hipGetLastError());
     return SM_OK;
 }
@@ -383,10 +404,11 @@ int mark(sm_ctx *s, int which, bool timed)
 
 int launch_conflict(sm_ctx *s, const FrameParams &fp, bool timed = false, bool fold_finalize = false)
 {
+    if (finalize_if_pending(s)) return SM_E_HIP;
     s->n_conf_part = (uint32_t)grid_surfels(s);
     hipLaunchKernelGGL(k_conflict, dim3(s->n_conf_part), dim3(256), 0, s->stream, s->M, s->d_state, fp, s->d_dcT,
                        s->d_cm, s->d_dm, s->d_zm, s->d_tile_cnt, s->d_tb, s->d_tile_flags, s->d_conf_part, s->d_alive,
-                       s->d_conf_sub + 64 * s->conf_sub_set);
+                       s->d_conf_sub + SUB_SET * s->conf_sub_set);
     HIPCK(hipGetLastError());
     if (mark(s, 2, timed)) return SM_E_HIP;
     if (fold_finalize) {            // k_cull_lazy_frame does the finalize step itself
@@ -418,38 +440,71 @@ int launch_cull_lazy_frame(sm_ctx *s, const FrameParams &fp, bool timed)
     s->fix_part_live = false;
     hipLaunchKernelGGL(k_cull_lazy_frame, dim3(grid + 1), dim3(256), 0, s->stream, s->M, s->d_state, fp, s->d_cm, s->d_dm, s->d_zm,
                        s->d_tile_cnt, s->d_keyT, s->d_tile_flags, s->d_lazy_part, s->d_alive, s->d_tile_dead, s->d_conf_part,
-                       s->n_conf_part, s->d_conf_sub + 64 * s->conf_sub_set, s->d_stat);
+                       s->n_conf_part, s->d_conf_sub + SUB_SET * s->conf_sub_set, s->d_stat);
     HIPCK(hipGetLastError());
     if (mark(s, 4, timed)) return SM_E_HIP;
     return SM_OK;
 }
 
-// conflict test + cull (marks only) + splat in ONE pass over the surfels, then the publisher / cap fixup kernel
-int launch_surfel_pass(sm_ctx *s, const FrameParams &fp, bool timed)
+// conflict test + cull (marks only) + splat in ONE pass over the surfels, then the publisher / cap fixup kernel.
+// direct: the frame appends directly (k_associate_direct follows): the pass also counts the candidate pixels, the fixup
+// publishes their group prefixes and the new count.
+int launch_surfel_pass(sm_ctx *s, const FrameParams &fp, bool timed, bool direct)
 {
     const bool ready = s->n_prep_blocks != 0;        // k_prep evaluated the tile flags
     const int grid = grid_surfels(s);
-    const int fgrid = std::min(grid, s->fix_grid);
+    // fixup workers: the cap repair strides over the tiles; with direct append they first count the frame's candidate pixels, one group each
+    const int fgrid = direct ? std::max(std::min(grid, s->fix_grid), (int)std::min<uint32_t>(s->n_grp, MAX_GRID)) : std::min(grid, s->fix_grid);
+    const uint32_t n_fix_prev = s->n_fix_part;
+    const uint2 *fix_prev = s->d_fix_part + (size_t)s->fix_set * MAX_GRID;
+    s->fix_set ^= 1;
+    uint2 *fix_cur = s->d_fix_part + (size_t)s->fix_set * MAX_GRID;
     s->n_conf_part = (uint32_t)grid;
     s->n_compact_part = (uint32_t)grid;
     s->lazy_part_live = true;
     s->fix_part_live = true;
     s->n_fix_part = (uint32_t)fgrid;
-    uint32_t *sub = s->d_conf_sub + 64 * s->conf_sub_set;
+    uint32_t *sub = s->d_conf_sub + SUB_SET * s->conf_sub_set;
     const uint32_t tile_bound = (uint32_t)std::max<uint64_t>(((uint64_t)s->count_bound + TILE - 1) / TILE, 1);
 #define SM_LAUNCH_PASS(R, NWV)                                                                                                             \
     hipLaunchKernelGGL((k_surfel_pass<R, NWV>), dim3(grid), dim3(256), 0, s->stream, s->M, s->d_state, fp, s->d_dcT, s->d_cm, s->d_dm /* km */, \
-                       s->d_wave_cnt, s->d_tb, s->d_tile_flags, s->d_lazy_part, s->d_alive, s->d_tile_dead, sub, s->d_keyT, s->d_undo, tile_bound)
+                       s->d_wave_cnt, s->d_tb, s->d_tile_flags, s->d_lazy_part, s->d_alive, s->d_tile_dead, sub, s->d_keyT, s->d_undo, tile_bound,       \
+                       s->d_frame_sub)
     if (ready) { if (s->pass_nw == 1) SM_LAUNCH_PASS(true, 1); else if (s->pass_nw == 2) SM_LAUNCH_PASS(true, 2); else SM_LAUNCH_PASS(true, 4); }
     else       { if (s->pass_nw == 1) SM_LAUNCH_PASS(false, 1); else if (s->pass_nw == 2) SM_LAUNCH_PASS(false, 2); else SM_LAUNCH_PASS(false, 4); }
 #undef SM_LAUNCH_PASS
     HIPCK(hipGetLastError());
     if (mark(s, 2, timed) || mark(s, 3, timed)) return SM_E_HIP;
+    DirectArgs da;
+    memset(&da, 0, sizeof da);
+    da.on = direct ? 1 : 0;
+    da.blk_cand = s->d_blk_cand; da.grp_cand = s->d_grp_cand; da.n_grp = s->n_grp; da.n_pix_blocks = s->n_pix_blocks;
+    da.depthT = s->d_depthT; da.xs = s->d_xs; da.ys = s->d_ys;
+    da.frame_sub = s->d_frame_sub;
+    // (the previous frame's fixup partials: only if it appended directly and nothing has completed its statistics since)
+    da.fix_prev = fix_prev; da.n_fix_prev = s->pend_finalize ? n_fix_prev : 0u;
+    da.log = s->d_log;
+    s->pend_finalize = false;            // the fixup's publisher completes the previous frame's statistics first
     hipLaunchKernelGGL(k_pass_fixup, dim3(fgrid + 1), dim3(256), 0, s->stream, s->M, s->d_state, fp, s->d_cm, s->d_dm /* km */, s->d_wave_cnt,
-                       s->d_tile_flags, s->d_lazy_part, (uint32_t)grid, s->d_fix_part, s->d_alive, s->d_tile_dead, sub, s->d_keyT, s->d_undo,
-                       s->d_stat, s->d_prep_part, ready ? s->n_prep_blocks : 0u);
+                       s->d_tile_flags, s->d_lazy_part, (uint32_t)grid, fix_cur, s->d_alive, s->d_tile_dead, sub, s->d_keyT, s->d_undo,
+                       s->d_stat, s->d_prep_part, ready ? s->n_prep_blocks : 0u, da);
     HIPCK(hipGetLastError());
     if (mark(s, 4, timed)) return SM_E_HIP;
+    return SM_OK;
+}
+
+// association + in-place fuse + direct append (the frame's last kernel; its statistics are completed later)
+int launch_associate_direct(sm_ctx *s, const FrameParams &fp, bool timed)
+{
+    hipLaunchKernelGGL(k_associate_direct, dim3(s->n_pix_blocks), dim3(PIX_BLOCK), 0, s->stream, s->M, s->d_state, fp, s->d_depthT, s->d_rgbsT,
+                       s->d_keyT, s->d_xs, s->d_ys, s->d_blk_cand, s->d_grp_cand, s->d_frame_sub, s->d_tb, s->d_alive, s->d_tile_dead, s->n_grp,
+                       s->d_stat);
+    HIPCK(hipGetLastError());
+    s->lazy_part_live = false;
+    s->fix_part_live = false;
+    s->pend_finalize = true;
+    s->frames_enq++;
+    if (mark(s, 5, timed) || mark(s, 6, timed) || mark(s, 7, timed)) return SM_E_HIP;
     return SM_OK;
 }
 
@@ -544,6 +599,7 @@ int launch_post_fill(sm_ctx *s)
 // empty conflict masks, then the regular scan + in-place compaction, with the key map's ids translated on the way.
 int ensure_compact(sm_ctx *s)
 {
+    if (finalize_if_pending(s)) return SM_E_HIP;
     if (!s->maybe_garbage) return SM_OK;
     if (s->pending_cull) { g_err = "internal: deferred compaction with a pending per-pass cull"; return SM_E_ARG; }
     FrameParams fp = make_params(s, s->curr_pose);
@@ -632,7 +688,7 @@ int launch_associate(sm_ctx *s, const FrameParams &fp, bool timed)
         hipLaunchKernelGGL(k_append_scan, dim3(s->n_pix_blocks), dim3(PIX_BLOCK), 0, s->stream, s->M, s->d_state, fp, s->d_depthT,
                            s->d_rgbsT, s->d_xs, s->d_ys, s->d_validmask, s->d_fusedmask, s->d_blk_cnt, s->d_log, s->d_tb, s->d_compact_part,
                            s->n_compact_part, s->d_alive, s->d_tile_dead, s->d_stat, s->lazy_part_live ? s->d_lazy_part : nullptr,
-                           (s->lazy_part_live && s->fix_part_live) ? s->d_fix_part : nullptr, s->n_fix_part);
+                           (s->lazy_part_live && s->fix_part_live) ? s->d_fix_part + (size_t)s->fix_set * MAX_GRID : nullptr, s->n_fix_part);
         s->lazy_part_live = false;
         s->fix_part_live = false;
         s->frames_enq++;
@@ -805,8 +861,17 @@ int enqueue_frame(sm_ctx *s, const uint8_t *d_rgb, const uint16_t *d_raw, const 
     // ... and, by default, does the conflict test in the same pass over the surfels (k_surfel_pass + k_pass_fixup)
     const bool one_pass = !fp.compact_now && s->one_pass && !s->use_fused_assoc;
     if (s->ev_ok) s->ev_one_pass[s->ev_frames % EV_RING] = one_pass;
-    if (one_pass) { if ((rc = launch_surfel_pass(s, fp, true))) return rc; }    // :178-197
-    else {
+    // ... and the association appends the new surfels directly (no append kernel) when k_prep ran after the previous frame
+    const bool direct = one_pass && s->direct && s->n_prep_blocks != 0;
+    if (one_pass) {
+        if ((rc = launch_surfel_pass(s, fp, true, direct))) return rc;      // :178-197
+        if (direct) {
+            if ((rc = launch_associate_direct(s, fp, true))) return rc;     // :212-239
+            bump_bound(s);
+            end_frame(s);
+            return SM_OK;
+        }
+    } else {
         if ((rc = launch_conflict(s, fp, true, fold))) return rc;    // :178-187
         if (fold) { if ((rc = launch_cull_lazy_frame(s, fp, true))) return rc; }
         else if ((rc = launch_compact(s, fp, true, true))) return rc;   // :189-197 (cull + mirror + index map)
@@ -967,14 +1032,17 @@ sm_ctx *sm_create(const sm_config *c)
          dalloc(&s->d_group_tot, (ntiles / GROUP + 2) * 4) == SM_OK && dalloc(&s->d_group_base, ntiles / GROUP + 2) == SM_OK;
     s->tb_tiles = (uint32_t)(ntiles + P / 2 / TILE + 8);
     ok = ok && dalloc(&s->d_conf_part, (size_t)MAX_GRID * 4) == SM_OK && dalloc(&s->d_compact_part, (size_t)MAX_GRID) == SM_OK &&
-         dalloc(&s->d_lazy_part, (size_t)MAX_GRID) == SM_OK && dalloc(&s->d_fix_part, (size_t)MAX_GRID) == SM_OK &&
-         dalloc(&s->d_wave_cnt, ntiles) == SM_OK && dalloc(&s->d_undo, cap + TILE) == SM_OK && dalloc(&s->d_conf_sub, (size_t)128) == SM_OK &&
+         dalloc(&s->d_lazy_part, (size_t)MAX_GRID) == SM_OK && dalloc(&s->d_fix_part, (size_t)MAX_GRID * 2 + 2) == SM_OK &&
+         dalloc(&s->d_wave_cnt, ntiles) == SM_OK && dalloc(&s->d_undo, cap + TILE) == SM_OK && dalloc(&s->d_conf_sub, (size_t)2 * SUB_SET) == SM_OK &&
          dalloc(&s->d_prep_part, (size_t)64) == SM_OK &&
-         hipMemset(s->d_conf_sub, 0, 512) == hipSuccess;
+         hipMemset(s->d_conf_sub, 0, (size_t)2 * SUB_SET * 4) == hipSuccess;
     ok = ok && dalloc(&s->d_tb, (size_t)s->tb_tiles * 8) == SM_OK && dalloc(&s->d_tile_flags, (size_t)s->tb_tiles) == SM_OK &&
          hipMemset(s->d_tile_flags, 0, s->tb_tiles) == hipSuccess;
     ok = ok && dalloc(&s->d_validmask, (P + 63) / 64 + 4) == SM_OK && dalloc(&s->d_fusedmask, (P + 63) / 64 + 4) == SM_OK;
     ok = ok && dalloc(&s->d_blk_cnt, (size_t)s->n_pix_blocks) == SM_OK;
+    s->n_grp = (uint32_t)((s->n_pix_blocks + CAND_GROUP - 1) / CAND_GROUP);
+    ok = ok && dalloc(&s->d_blk_cand, (size_t)s->n_grp * CAND_GROUP) == SM_OK && dalloc(&s->d_grp_cand, (size_t)s->n_grp) == SM_OK &&
+         dalloc(&s->d_frame_sub, (size_t)4 * SUB_SET) == SM_OK && hipMemset(s->d_frame_sub, 0, (size_t)4 * SUB_SET * 4) == hipSuccess;
     ok = ok && dalloc(&s->d_blk_prefix, (size_t)s->n_pix_blocks) == SM_OK && dalloc(&s->d_desc, (size_t)s->n_pix_blocks) == SM_OK &&
          hipMemset(s->d_desc, 0, (size_t)s->n_pix_blocks * 8) == hipSuccess;
     if (!ok) { if (g_err.empty()) g_err = "sm_create: allocation failed"; sm_destroy(s); return nullptr; }
@@ -1045,6 +1113,7 @@ sm_ctx *sm_create(const sm_config *c)
         s->merged_finalize = std::getenv("SM_NO_MERGED_FINALIZE") == nullptr;
         if (const char *e = std::getenv("SM_ONE_PASS")) s->one_pass = e[0] != '0';
         if (const char *e = std::getenv("SM_TILE_FLAGS_IN_PREP")) s->use_list = e[0] != '0';
+        if (const char *e = std::getenv("SM_DIRECT_APPEND")) s->direct = e[0] != '0';
         if (const char *e = std::getenv("SM_PASS_NW")) { const int v = std::atoi(e); if (v == 1 || v == 2 || v == 4) s->pass_nw = v; }
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess && cus > 0 &&
             hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_compact<true>, 256, 0) == hipSuccess && per_cu > 0) {
@@ -1086,7 +1155,7 @@ void sm_destroy(sm_ctx *s)
     (void)hipFree(s->d_rgb); (void)hipFree(s->d_sem); (void)hipFree(s->d_depth_raw); (void)hipFree(s->d_depth_f32);
     (void)hipFree(s->d_xs); (void)hipFree(s->d_ys); (void)hipFree(s->d_wtab);
     (void)hipFree(s->d_cm); (void)hipFree(s->d_dm); (void)hipFree(s->d_zm); (void)hipFree(s->d_alive); (void)hipFree(s->d_tile_dead);
-    (void)hipFree(s->d_tile_cnt); (void)hipFree(s->d_tile_allow); (void)hipFree(s->d_tile_keep); (void)hipFree(s->d_tile_flag); (void)hipFree(s->d_group_tot); (void)hipFree(s->d_group_base); (void)hipFree(s->d_tb); (void)hipFree(s->d_tile_flags); (void)hipFree(s->d_conf_part); (void)hipFree(s->d_compact_part); (void)hipFree(s->d_lazy_part); (void)hipFree(s->d_conf_sub); (void)hipFree(s->d_fix_part); (void)hipFree(s->d_wave_cnt); (void)hipFree(s->d_undo); (void)hipFree(s->d_prep_part);
+    (void)hipFree(s->d_tile_cnt); (void)hipFree(s->d_tile_allow); (void)hipFree(s->d_tile_keep); (void)hipFree(s->d_tile_flag); (void)hipFree(s->d_group_tot); (void)hipFree(s->d_group_base); (void)hipFree(s->d_tb); (void)hipFree(s->d_tile_flags); (void)hipFree(s->d_conf_part); (void)hipFree(s->d_compact_part); (void)hipFree(s->d_lazy_part); (void)hipFree(s->d_conf_sub); (void)hipFree(s->d_fix_part); (void)hipFree(s->d_blk_cand); (void)hipFree(s->d_grp_cand); (void)hipFree(s->d_frame_sub); (void)hipFree(s->d_wave_cnt); (void)hipFree(s->d_undo); (void)hipFree(s->d_prep_part);
     (void)hipFree(s->d_validmask); (void)hipFree(s->d_fusedmask); (void)hipFree(s->d_blk_prefix); (void)hipFree(s->d_desc); (void)hipFree(s->d_blk_cnt);
     (void)hipFree(s->d_seg_lstart); (void)hipFree(s->d_seg_gbase); (void)hipFree(s->d_gseg_base); (void)hipFree(s->d_seg_keep);
     if (s->d_export) (void)hipFree(s->d_export);

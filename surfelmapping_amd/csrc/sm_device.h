@@ -18,6 +18,10 @@ constexpr uint64_t KEY_EMPTY = 0x7FFFFFFFFFFFFFFFull;  // positive as int64 too 
 constexpr int TILE = 1024;                             // surfels per cull tile (16 ballot words)
 constexpr int TILE_WORDS = TILE / 64;
 constexpr int PIX_BLOCK = 256;                         // pixels per association block (4 ballot words)
+// Sub-counters (64 per sum, <= 32 adders each, read with one load per lane): one 128-byte line each -- memory-side atomics
+// on one line serialise (64 counters packed into two lines cost the association 3 us at KITTI size)
+constexpr int SUB_STRIDE = 32;                         // words between two sub-counters
+constexpr int SUB_SET = 64 * SUB_STRIDE;               // words of one set of 64 sub-counters
 
 // One SoA surfel set: 44 B / surfel (the reference's AoS slot [5] "standby" is always 0
 // in the stored model: back_map.geom:23, unstable.vert:32).
@@ -61,6 +65,11 @@ struct DevState {
     uint32_t stat_frames;     // frames whose append has completed (tag of the host-visible slot statistic)
     uint32_t first_live;      // slot of the first live surfel = the reference's surfel id 0 (conflict.geom:15, data.vert:142)
     uint32_t fl_dirty;        // k_surfel_pass saw that surfel die: k_pass_fixup looks for its successor
+    // ---- direct append (k_associate_direct): the frame's statistics are completed one kernel later
+    uint32_t pend;            // 1: the last frame's new / fused counts, dead-slot total and log entry are still to be completed
+                              //    (by the next frame's k_pass_fixup, or by k_frame_finalize before anything else reads them)
+    uint32_t pend_tick;       // time stamp of that frame
+    uint32_t holes_last;      // slots of the last frame's appended range that stayed empty (candidate pixels that fused instead)
 };
 
 struct FrameLog { uint32_t tick, n_before, n_after_cull, n_kill, conflict_count, visible_count, fused_count, unstable_count, n_static, n_conf_skipped, n_splat_skipped, n_slots; };

@@ -199,7 +199,7 @@ __global__ __launch_bounds__(1024) void k_prep(const uint8_t *__restrict__ rgb,
     if (blockIdx.x < tp.nfb) { tile_prep_block(fp, tp); return; }       // workgroup-uniform
     const uint32_t bid = blockIdx.x - tp.nfb;
     __shared__ float s_d[32][33];
-    if (conf_sub && bid == 0 && threadIdx.x < 64) conf_sub[threadIdx.x] = 0u;
+    if (conf_sub && bid == 0 && threadIdx.x < 64) conf_sub[threadIdx.x * SUB_STRIDE] = 0u;
     __shared__ uint32_t s_c[32][33];
     const int W = fp.W, H = fp.H;
     const int tiles_x = (W + 31) >> 5;
@@ -529,7 +529,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SM_CONFLICT
     if (threadIdx.x == 0) {
         blk_part[blockIdx.x * 4] = skipped;
         // the conflict total in a form the next kernel can read in one instruction: 64 counters, <= 32 adders each
-        if (acc) atomicAdd(&conf_sub[blockIdx.x & 63u], acc);
+        if (acc) atomicAdd(&conf_sub[(blockIdx.x & 63u) * SUB_STRIDE], acc);
     }
 }
 
@@ -618,6 +618,7 @@ __global__ __launch_bounds__(1024) void k_cull_finalize(DevState *__restrict__ s
     const uint32_t N = st->count;                     // occupied slots
     const uint32_t g0 = st->garbage;                  // dead ones among them
     const uint32_t old_first = st->first_live, old_offset = st->offset;
+    const uint32_t holes = st->holes_last;            // dead slots ABOVE old_offset (k_associate_direct: candidates that fused)
     const uint32_t ntiles = (N + TILE - 1) / TILE;
     const uint32_t ngroups = (ntiles + GROUP - 1) / GROUP;
     const uint32_t cap = fp.conflict_cap;
@@ -759,9 +760,10 @@ __global__ __launch_bounds__(1024) void k_cull_finalize(DevState *__restrict__ s
         st->first_moving = (compact && s_first != 0xFFFFFFFFu) ? min(s_first, ntiles) : ntiles;
         st->compact_ticket = 0u;
         st->first_live = first_live;
+        st->holes_last = 0u;
         if (compact) {
             st->count = kept;                             // src/GlobalModel.cpp:575
-            st->offset = fp.maintenance ? old_offset - g0 : kept;
+            st->offset = fp.maintenance ? old_offset - (g0 - holes) : kept;
             st->garbage = 0;
         } else {
             st->count = N;                                // the dead keep their slots until the next compaction
@@ -1199,7 +1201,7 @@ __global__ __launch_bounds__(256) void k_cull_lazy_frame(Model M, DevState *__re
     const uint32_t nwg = gridDim.x - 1u;               // workers; workgroup 0 (dispatched first) publishes
     const bool publisher = blockIdx.x == 0u;
     const uint32_t wi = blockIdx.x - 1u;               // worker index
-    const uint32_t ctotal = wave_sum_u32(conf_sub[lane]);
+    const uint32_t ctotal = wave_sum_u32(conf_sub[lane * SUB_STRIDE]);
     const uint32_t N = st->count;                      // occupied slots: unchanged by this cull
     const SurfelSet set = M.s[st->cur];
     const uint32_t ntiles = (N + TILE - 1) / TILE;
@@ -1280,6 +1282,7 @@ __global__ __launch_bounds__(256) void k_cull_lazy_frame(Model M, DevState *__re
             st->cap_binds = cap_binds ? 1u : 0u;
             st->do_compact = 0u;
             st->first_live = first_live;
+            st->holes_last = 0u;
             st->offset = N;                             // the dead keep their slots until the next compaction
             if (host_stat)
                 __hip_atomic_store(host_stat, ((unsigned long long)st->stat_frames << 32) | (unsigned long long)N, __ATOMIC_RELAXED,
@@ -1396,6 +1399,60 @@ __global__ __launch_bounds__(256) void k_cull_lazy_frame(Model M, DevState *__re
 //                   not be exact for every float)
 // Each wave settles four consecutive 64-slot words on its own: no LDS, no barrier inside a tile.
 // ---------------------------------------------------------------------------------------------
+// data.vert:33-52,87-88: is pixel q a candidate (a valid measurement on the checkerboard)?  Exactly the tests local_surfel
+// applies before it does any arithmetic (frame path, i.e. not the raw cloud of the frame after reset()).
+__device__ __forceinline__ bool candidate_pixel(int q, const FrameParams &fp, const float *__restrict__ depthT,
+                                                const float *__restrict__ xs, const float *__restrict__ ys)
+{
+    // branch-free, every load unconditional (q is in range): a caller's unrolled loop keeps all of them in flight
+    const int H = fp.H, W = fp.W;
+    const int i = q / H, j = q - i * H;
+    const float z = depthT[q];
+    const float zl = depthT[i > 0 ? q - H : q];
+    const float zu = depthT[j > 0 ? q - 1 : q];
+    const float zr = depthT[i < W - 1 ? q + H : q];
+    const float zd = depthT[j < H - 1 ? q + 1 : q];
+    const int par = ((int)xs[i] + (int)ys[j]) % 2;
+    return (zl != 0.0f) & (zu != 0.0f) & (zr != 0.0f) & (zd != 0.0f) & (z > fp.min_depth) & (z < fp.max_depth) & (par == 1);
+}
+
+// Candidate pixels per association block (256 pixels) and per group of CAND_GROUP blocks, counted by the otherwise idle
+// worker workgroups of k_pass_fixup (they only depend on the frame).  (Inside k_surfel_pass, as extra workgroups, the
+// counting cost that kernel its register allocation: 194 v_readlane SGPR spills, 16.5 -> 19.5 us.)  With them every
+// candidate pixel owns a model slot before the association runs: slot = offset + (candidates before it in pixel order).
+// k_associate_direct writes new surfels straight there -- the order of the reference's append (src/GlobalModel.cpp:67-74,
+// unstable.vert) with no count that depends on the association itself -- and marks the slots of pixels that fuse instead
+// as dead, which the deferred compaction squeezes out like any other dead slot.
+constexpr int CAND_GROUP = 16;      // association blocks per counting workgroup (16 pixels per thread, all loads in flight together)
+
+__device__ __forceinline__ void cand_count_block(uint32_t cg, const FrameParams &fp, const float *__restrict__ depthT,
+                                                 const float *__restrict__ xs, const float *__restrict__ ys, int nblocks,
+                                                 uint32_t *__restrict__ blk_cand, uint32_t *__restrict__ grp_cand)
+{
+    __shared__ uint32_t s_w[CAND_GROUP][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    bool c[CAND_GROUP];
+#pragma unroll
+    for (int k = 0; k < CAND_GROUP; ++k) {
+        const int q = ((int)cg * CAND_GROUP + k) * PIX_BLOCK + (int)threadIdx.x;
+        c[k] = candidate_pixel(min(q, fp.P - 1), fp, depthT, xs, ys) & (q < fp.P);
+    }
+#pragma unroll
+    for (int k = 0; k < CAND_GROUP; ++k) {
+        const uint64_t m = __ballot(c[k]);
+        if (lane == 0) s_w[k][wave] = (uint32_t)__popcll(m);
+    }
+    __syncthreads();
+    if (wave == 0) {
+        uint32_t v = 0;
+        const int b = (int)cg * CAND_GROUP + lane;
+        if (lane < CAND_GROUP) v = s_w[lane][0] + s_w[lane][1] + s_w[lane][2] + s_w[lane][3];
+        if (lane < CAND_GROUP && b < nblocks) blk_cand[b] = v;
+        v = wave_sum_u32(v);
+        if (lane == 0) grp_cand[cg] = v;
+    }
+}
+
 struct PassAcc { uint32_t vis, killed, nconf; };
 
 // NW consecutive 64-slot words (word0 ...) settled by one wave; sk0 / sk1: the tile's skip flags (conflict volume / index
@@ -1547,8 +1604,10 @@ __global__ __launch_bounds__(256) void k_surfel_pass(Model M, DevState *__restri
                                                      uint64_t *__restrict__ alive, uint32_t *__restrict__ tile_dead,
                                                      uint32_t *__restrict__ conf_sub, uint64_t *__restrict__ keyT,
                                                      float *__restrict__ undo,
-                                                     uint32_t tile_bound /* host upper bound of the number of tiles (>= 1) */)
+                                                     uint32_t tile_bound /* host upper bound of the number of tiles (>= 1) */,
+                                                     uint32_t *__restrict__ frame_sub /* sets 0, 1: visible, killed -- sub-counters like conf_sub */)
 {
+    const uint32_t bid = blockIdx.x, tile_grid = gridDim.x;
     __shared__ uint8_t s_flags[64];
     __shared__ uint32_t s_a[4], s_b[4], s_c[4];
     const int lane = threadIdx.x & 63;
@@ -1556,33 +1615,32 @@ __global__ __launch_bounds__(256) void k_surfel_pass(Model M, DevState *__restri
     // flags and dead counts of this workgroup's first 64 tiles: addresses known without DevState, issued with it
     uint32_t m_flag = 0, m_dead = 0;
     if (READY) {
-        const uint64_t tl = min((uint64_t)blockIdx.x + (uint64_t)lane * gridDim.x, (uint64_t)tile_bound - 1u);
+        const uint64_t tl = min((uint64_t)bid + (uint64_t)lane * tile_grid, (uint64_t)tile_bound - 1u);
         m_flag = tile_flags[tl];
         m_dead = tile_dead[tl];
     }
     const uint32_t N = st->count;
     const uint32_t exempt = st->first_live;            // the surfel the reference addresses as id 0
-    const bool has_dead = st->garbage != 0u;
     const SurfelSet set = M.s[st->cur];
     PassAcc acc = {0u, 0u, 0u};
     uint32_t sskip = 0, cskip = 0;
     const uint32_t ntiles = (N + TILE - 1) / TILE;
     uint64_t skip0 = 0, skip1 = 0;
     uint32_t iter = 0;
-    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x, ++iter) {
+    for (uint32_t tile = bid; tile < ntiles; tile += tile_grid, ++iter) {
         if ((iter & 63u) == 0u) {
-            const uint64_t tl = (uint64_t)tile + (uint64_t)lane * gridDim.x;
+            const uint64_t tl = (uint64_t)tile + (uint64_t)lane * tile_grid;
             uint32_t f;
             if (READY) {
                 if (iter) { m_flag = tile_flags[min(tl, (uint64_t)ntiles - 1u)]; m_dead = tile_dead[min(tl, (uint64_t)ntiles - 1u)]; }
                 f = tl < ntiles ? m_flag : 3u;
             } else {
                 __syncthreads();
-                tile_flags_batch(tile, gridDim.x, ntiles, fp, tb, s_flags);
+                tile_flags_batch(tile, tile_grid, ntiles, fp, tb, s_flags);
                 __syncthreads();
                 f = s_flags[lane];
                 if (wave == 0 && tl < ntiles) tile_flags[tl] = (uint8_t)f;      // bit 1 is read again by the fixup's repair
-                m_dead = (has_dead && tl < ntiles) ? tile_dead[tl] : 0u;
+                m_dead = tl < ntiles ? tile_dead[tl] : 0u;
             }
             skip0 = __ballot((f & 1u) != 0u);
             skip1 = __ballot((f & 2u) != 0u);
@@ -1599,15 +1657,18 @@ __global__ __launch_bounds__(256) void k_surfel_pass(Model M, DevState *__restri
             continue;
         }
         pass_quarter<NW>(set, st, fp, dcT, cm, km, wave_cnt, alive, tile_dead, keyT, undo, N, exempt, tile, wave, sk0, sk1,
-                         has_dead && lane_bcast(m_dead, sl) != 0u, lane, acc);
+                         lane_bcast(m_dead, sl) != 0u, lane, acc);
     }
     __syncthreads();
     if (lane == 0) { s_a[wave] = acc.vis; s_b[wave] = acc.killed; s_c[wave] = acc.nconf; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        part[blockIdx.x] = make_uint4(s_a[0] + s_a[1] + s_a[2] + s_a[3], sskip, s_b[0] + s_b[1] + s_b[2] + s_b[3], cskip);
+        const uint32_t nv = s_a[0] + s_a[1] + s_a[2] + s_a[3], nk = s_b[0] + s_b[1] + s_b[2] + s_b[3];
+        part[bid] = make_uint4(nv, sskip, nk, cskip);
         const uint32_t nc = s_c[0] + s_c[1] + s_c[2] + s_c[3];
-        if (nc) atomicAdd(&conf_sub[blockIdx.x & 63u], nc);      // 64 counters, <= 32 adders each: one load per lane to read the total
+        if (nc) atomicAdd(&conf_sub[(bid & 63u) * SUB_STRIDE], nc);      // 64 counters, <= 32 adders each: one load per lane to read the total
+        if (nv) atomicAdd(&frame_sub[(bid & 63u) * SUB_STRIDE], nv);
+        if (nk) atomicAdd(&frame_sub[SUB_SET + (bid & 63u) * SUB_STRIDE], nk);
     }
 }
 
@@ -1617,6 +1678,91 @@ __device__ __forceinline__ uint64_t ineffective_conflicts(uint64_t c, uint32_t b
 {
     if (before >= cap) return c;
     return c & ~first_n_bits(c, cap - before);
+}
+
+// Arguments of the direct-append frame form (k_associate_direct), handed to k_pass_fixup's publisher
+struct DirectArgs {
+    int on;                              // 1: this frame appends directly (k_associate_direct follows; no k_append_scan)
+    uint32_t *blk_cand, *grp_cand;       // out: candidate pixels per association block / per group of CAND_GROUP blocks (this frame)
+    uint32_t n_grp;
+    int n_pix_blocks;
+    const float *depthT, *xs, *ys;
+    uint32_t *frame_sub;                 // 4 x 64 sub-counters: visible, killed (this frame's pass); new, fused (the PREVIOUS frame's association)
+    const uint2 *fix_prev;               // the previous frame's k_pass_fixup partials (read if its conflict cap bound)
+    uint32_t n_fix_prev;
+    FrameLog *log;
+};
+
+// DevState fields of the pending frame, loaded before the reductions so that completing it costs no further round trip
+struct PendFields { uint32_t cull_n, garbage_prev, n_kill, visible, conflict, n_static, conf_skipped, splat_skipped, tick, frames_logged; };
+
+__device__ __forceinline__ void finalize_write(DevState *__restrict__ st, FrameLog *__restrict__ log, const PendFields &pf, uint32_t U,
+                                               uint32_t F, uint32_t vadd, uint32_t res);
+
+// Completes the statistics of a direct-append frame once its association has finished: new / fused totals from the
+// per-block counts, the fixup's corrections if the conflict cap bound, the dead-slot total (culled + fused candidates'
+// empty slots), the frame-log entry.  Executed by one 256-thread workgroup; no-op unless DevState::pend is set.
+__device__ __forceinline__ void finalize_frame(DevState *__restrict__ st, uint32_t *__restrict__ frame_sub,
+                                               const uint2 *__restrict__ fix_prev, uint32_t n_fix_prev, FrameLog *__restrict__ log,
+                                               uint32_t *s_red /* 16 words of LDS */)
+{
+    if (st->pend == 0u) return;                         // workgroup-uniform
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t un = 0, fu = 0, va = 0, rs = 0;
+    if (wave == 0) {
+        uint32_t *a = frame_sub + 2 * SUB_SET + lane * SUB_STRIDE, *b = frame_sub + 3 * SUB_SET + lane * SUB_STRIDE;
+        un = *a; fu = *b; *a = 0u; *b = 0u;
+    }
+    if (st->cap_binds)
+        for (uint32_t b = threadIdx.x; b < n_fix_prev; b += 256u) { const uint2 c = fix_prev[b]; va += c.x; rs += c.y; }
+    un = wave_sum_u32(un); fu = wave_sum_u32(fu); va = wave_sum_u32(va); rs = wave_sum_u32(rs);
+    __syncthreads();
+    if (lane == 0) { s_red[wave] = un; s_red[4 + wave] = fu; s_red[8 + wave] = va; s_red[12 + wave] = rs; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t U = s_red[0] + s_red[1] + s_red[2] + s_red[3], F = s_red[4] + s_red[5] + s_red[6] + s_red[7];
+        const uint32_t vadd = s_red[8] + s_red[9] + s_red[10] + s_red[11], res = s_red[12] + s_red[13] + s_red[14] + s_red[15];
+        PendFields pf;
+        pf.cull_n = st->cull_n; pf.garbage_prev = st->garbage_prev; pf.n_kill = st->n_kill; pf.visible = st->visible_count;
+        pf.conflict = st->conflict_count; pf.n_static = st->n_static; pf.conf_skipped = st->n_conf_skipped;
+        pf.splat_skipped = st->n_splat_skipped; pf.tick = st->pend_tick; pf.frames_logged = st->frames_logged;
+        finalize_write(st, log, pf, U, F, vadd, res);
+    }
+    __syncthreads();
+}
+
+// (one thread) the pending frame's totals into DevState and the frame log
+__device__ __forceinline__ void finalize_write(DevState *__restrict__ st, FrameLog *__restrict__ log, const PendFields &pf, uint32_t U,
+                                               uint32_t F, uint32_t vadd, uint32_t res)
+{
+    const uint32_t n_slots = pf.cull_n, g_prev = pf.garbage_prev;
+    const uint32_t n_kill = pf.n_kill - res, vis = pf.visible + vadd;
+    const uint32_t g_cull = g_prev + n_kill;
+    st->n_kill = n_kill;
+    st->visible_count = vis;
+    st->garbage = g_cull + F;                       // the slots of candidate pixels that fused stay empty
+    st->holes_last = F;
+    st->unstable_count = U;
+    st->fused_count = F;
+    st->data_count = U + F;
+    st->append_n = U;
+    if (log) {
+        FrameLog e;
+        e.tick = pf.tick; e.n_before = n_slots - g_prev; e.n_after_cull = n_slots - g_cull; e.n_kill = n_kill;
+        e.conflict_count = pf.conflict; e.visible_count = vis; e.fused_count = F; e.unstable_count = U;
+        e.n_static = pf.n_static; e.n_conf_skipped = pf.conf_skipped; e.n_splat_skipped = pf.splat_skipped; e.n_slots = n_slots;
+        log[pf.frames_logged % FRAME_LOG_LEN] = e;
+        st->frames_logged = pf.frames_logged + 1;
+    }
+    st->n_conf_skipped = 0;
+    st->pend = 0u;
+}
+
+__global__ __launch_bounds__(256) void k_frame_finalize(DevState *__restrict__ st, uint32_t *__restrict__ frame_sub,
+                                                        const uint2 *__restrict__ fix_prev, uint32_t n_fix_prev, FrameLog *__restrict__ log)
+{
+    __shared__ uint32_t s_red[16];
+    finalize_frame(st, frame_sub, fix_prev, n_fix_prev, log, s_red);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1634,28 +1780,59 @@ __global__ __launch_bounds__(256) void k_pass_fixup(Model M, DevState *__restric
                                                     uint64_t *__restrict__ alive, uint32_t *__restrict__ tile_dead,
                                                     const uint32_t *__restrict__ conf_sub, uint64_t *__restrict__ keyT,
                                                     const float *__restrict__ undo, unsigned long long *__restrict__ host_stat,
-                                                    const uint2 *__restrict__ prep_part, uint32_t n_prep /* k_prep's skip statistics (it evaluated the tile flags), or 0 */)
+                                                    const uint2 *__restrict__ prep_part, uint32_t n_prep /* k_prep's skip statistics (it evaluated the tile flags), or 0 */,
+                                                    DirectArgs da)
 {
     __shared__ uint32_t s_a[4], s_b[4], s_c[4];
     __shared__ uint32_t s_fl;
+    __shared__ uint32_t s_red9[9][4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t nwg = gridDim.x - 1u;               // workers; workgroup 0 (dispatched first) publishes
-    const uint32_t ctotal = wave_sum_u32(conf_sub[lane]);
+    const uint32_t ctotal = wave_sum_u32(conf_sub[lane * SUB_STRIDE]);
     const uint32_t cap = fp.conflict_cap;
     const bool cap_binds = ctotal > cap;
     const uint32_t N = st->count;                      // occupied slots: unchanged by a cull that only marks the dead
     const uint32_t ntiles = (N + TILE - 1) / TILE;
     if (blockIdx.x == 0u) {
-        const uint32_t g0 = st->garbage, old_first = st->first_live;
+        // ---- every load the publisher needs, issued together (each dependent round trip costs ~1 us on this single workgroup)
+        const uint32_t pend = st->pend, cap_prev = st->cap_binds, g_in = st->garbage, old_first = st->first_live;
         const bool dirty = st->fl_dirty != 0u;
-        uint32_t cskip = 0, sskip = 0;
-        if (n_prep) for (uint32_t b = threadIdx.x; b < n_prep; b += 256u) { const uint2 c = prep_part[b]; cskip += c.x; sskip += c.y; }
-        else for (uint32_t b = threadIdx.x; b < n_part; b += 256u) { const uint4 c = part[b]; cskip += c.w; sskip += c.y; }
-        cskip = wave_sum_u32(cskip); sskip = wave_sum_u32(sskip);
-        if (lane == 0) { s_a[wave] = cskip; s_b[wave] = sskip; }
+        PendFields pf;
+        pf.cull_n = st->cull_n; pf.garbage_prev = st->garbage_prev; pf.n_kill = st->n_kill; pf.visible = st->visible_count;
+        pf.conflict = st->conflict_count; pf.n_static = st->n_static; pf.conf_skipped = st->n_conf_skipped;
+        pf.splat_skipped = st->n_splat_skipped; pf.tick = st->pend_tick; pf.frames_logged = st->frames_logged;
+        uint32_t red[9] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};  // new, fused, vis+, resurrected (previous frame) | conf-skip, splat-skip, visible, killed | candidates
+        // the sums the pass / the previous association left in 64 sub-counters each (one load per lane; consumed: zeroed)
+        if (wave == 0) {
+            uint32_t *c = da.frame_sub + lane * SUB_STRIDE;
+            red[6] = c[0]; red[7] = c[SUB_SET]; red[0] = c[2 * SUB_SET]; red[1] = c[3 * SUB_SET];
+            c[0] = 0u; c[SUB_SET] = 0u; c[2 * SUB_SET] = 0u; c[3 * SUB_SET] = 0u;
+        }
+        // (the fixup partials of the previous frame are only meaningful if its conflict cap bound: masked after the
+        //  reduction, so that no load waits for DevState)
+        for (uint32_t b = threadIdx.x; b < da.n_fix_prev; b += 256u) { const uint2 c = da.fix_prev[b]; red[2] += c.x; red[3] += c.y; }
+        if (n_prep) for (uint32_t b = threadIdx.x; b < n_prep; b += 256u) { const uint2 c = prep_part[b]; red[4] += c.x; red[5] += c.y; }
+        else for (uint32_t b = threadIdx.x; b < n_part; b += 256u) { const uint4 c = part[b]; red[4] += c.w; red[5] += c.y; }
+        // ---- one round of reductions
+#pragma unroll
+        for (int x = 0; x < 9; ++x) red[x] = wave_sum_u32(red[x]);
+        if (lane == 0) {
+#pragma unroll
+            for (int x = 0; x < 9; ++x) s_red9[x][wave] = red[x];
+        }
         if (threadIdx.x == 0) s_fl = 0xFFFFFFFFu;
         __syncthreads();
-        const uint32_t cskip_tot = s_a[0] + s_a[1] + s_a[2] + s_a[3], sskip_tot = s_b[0] + s_b[1] + s_b[2] + s_b[3];
+        uint32_t tot[9];
+#pragma unroll
+        for (int x = 0; x < 9; ++x) tot[x] = s_red9[x][0] + s_red9[x][1] + s_red9[x][2] + s_red9[x][3];
+        if (!cap_prev || !pend) { tot[2] = 0u; tot[3] = 0u; }
+        // the previous frame appended directly: its statistics (incl. the dead-slot total used below) are completed first
+        uint32_t g0 = g_in;
+        if (pend) {
+            g0 = pf.garbage_prev + (pf.n_kill - tot[3]) + tot[1];
+            if (threadIdx.x == 0) finalize_write(st, da.log, pf, tot[0], tot[1], tot[2], tot[3]);
+        }
+        const uint32_t cskip_tot = tot[4], sskip_tot = tot[5], vis_tot = tot[6], kill_tot = tot[7];
         uint32_t first_live = old_first;
         if (dirty) {
             // The surfel that was id 0 died in the pass (conf <= 0: only an uploaded model holds such surfels).  Its
@@ -1712,15 +1889,27 @@ __global__ __launch_bounds__(256) void k_pass_fixup(Model M, DevState *__restric
             st->first_live = first_live;
             st->fl_dirty = 0u;
             st->offset = N;                             // the dead keep their slots until the next compaction
+            st->holes_last = 0u;
+            if (da.on) {
+                // provisional totals of the pass (k_associate_direct's first block publishes the new count; the statistics
+                // are completed by finalize_frame / finalize_write once the association is through)
+                st->visible_count = vis_tot;
+                st->n_kill = kill_tot;
+                st->pend = 1u;
+                st->pend_tick = (uint32_t)fp.time;
+            }
             if (host_stat)
                 __hip_atomic_store(host_stat, ((unsigned long long)st->stat_frames << 32) | (unsigned long long)N, __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_SYSTEM);
         }
         return;
     }
+    const uint32_t wi = blockIdx.x - 1u;
+    // ---- direct append: the candidate pixels of the frame, per association block and per group (workgroup-uniform loop)
+    if (da.on)
+        for (uint32_t g = wi; g < da.n_grp; g += nwg) cand_count_block(g, fp, da.depthT, da.xs, da.ys, da.n_pix_blocks, da.blk_cand, da.grp_cand);
     if (!cap_binds) return;
     // ---- the cap binds: take the conflicts beyond the first `cap` back
-    const uint32_t wi = blockIdx.x - 1u;
     const SurfelSet set = M.s[st->cur];
     uint32_t cpre = 0;                                  // conflicts in all tiles below this workgroup's current one
     {
@@ -2009,6 +2198,78 @@ __global__ __launch_bounds__(PIX_BLOCK) void k_associate(Model M, const DevState
     }
     __syncthreads();
     if (threadIdx.x == 0) blk_cnt[blockIdx.x] = make_uint2(s_n[0] + s_n[1] + s_n[2] + s_n[3], s_f[0] + s_f[1] + s_f[2] + s_f[3]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Direct-append form of p8..p11 (the default on frames whose cull only marks the dead): association + in-place fuse, and
+// every NEW surfel written straight to its final slot = offset + (candidate pixels before it in pixel order) -- the
+// candidate counts per block and per group come from k_surfel_pass's extra workgroups (cand_count_block), so nothing here waits for another block and no append kernel follows.  A candidate pixel that fuses
+// leaves its slot empty: marked dead (alive bit, per-tile dead count) like a culled surfel.  Survivor order and new-
+// surfel order are the reference's (stable cull; column-major append, src/GlobalModel.cpp:67-74), ids handed out by
+// the API are positions among the live surfels as with any deferred compaction.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(PIX_BLOCK) void k_associate_direct(Model M, DevState *__restrict__ st, FrameParams fp,
+                                                                const float *__restrict__ depthT,
+                                                                const uint32_t *__restrict__ rgbsT,
+                                                                const uint64_t *__restrict__ keyT,
+                                                                const float *__restrict__ xs, const float *__restrict__ ys,
+                                                                const uint32_t *__restrict__ blk_cand /* candidate pixels per block ... */,
+                                                                const uint32_t *__restrict__ grp_cand /* ... and per group of CAND_GROUP blocks */,
+                                                                uint32_t *__restrict__ frame_sub /* sets 2, 3: new, fused -- 64 sub-counters each */,
+                                                                uint32_t *__restrict__ tb, uint64_t *__restrict__ alive,
+                                                                uint32_t *__restrict__ tile_dead, uint32_t n_grp,
+                                                                unsigned long long *__restrict__ host_stat)
+{
+    __shared__ uint32_t s_v[4], s_n[4], s_f[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // candidates before this block = the groups before its group + the blocks of its group before it: a few loads per lane,
+    // issued together with DevState, one wave reduction (every wave computes it for itself)
+    const uint32_t grp = blockIdx.x / CAND_GROUP, in_grp = blockIdx.x % CAND_GROUP;
+    uint32_t pre = (lane < (int)in_grp) ? blk_cand[grp * CAND_GROUP + lane] : 0u;
+    for (uint32_t g = lane; g < grp; g += 64u) pre += grp_cand[g];
+    const SurfelSet cur = M.s[st->cur];
+    const uint32_t offset = st->offset;
+    const int q = blockIdx.x * PIX_BLOCK + threadIdx.x;
+    bool is_valid, is_fused;
+    LocalSurfel L;
+    associate_pixel(q, cur, fp, depthT, rgbsT, keyT, xs, ys, nullptr, nullptr, L, is_valid, is_fused, tb, st->first_live);
+    const uint64_t vw = __ballot(is_valid), fw = __ballot(is_fused);
+    if (lane == 0) { s_v[wave] = (uint32_t)__popcll(vw); s_n[wave] = (uint32_t)__popcll(vw & ~fw); s_f[wave] = (uint32_t)__popcll(fw); }
+    pre = wave_sum_u32(pre);
+    __syncthreads();
+    if (blockIdx.x == 0 && wave == 0) {
+        // every candidate pixel of the frame owns a slot: the new count (the host never lets a frame of this form start
+        // without room for all of them), published for the next frame's kernels and for the host's capacity bound
+        uint32_t d = 0;
+        for (uint32_t g = lane; g < n_grp; g += 64u) d += grp_cand[g];
+        d = wave_sum_u32(d);
+        if (lane == 0) {
+            st->count = offset + d;
+            const uint32_t fr = st->stat_frames + 1u;
+            st->stat_frames = fr;
+            if (host_stat)
+                __hip_atomic_store(host_stat, ((unsigned long long)fr << 32) | (unsigned long long)(offset + d), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+    if (threadIdx.x == 0) {
+        const uint32_t nn = s_n[0] + s_n[1] + s_n[2] + s_n[3], nf = s_f[0] + s_f[1] + s_f[2] + s_f[3];
+        if (nn) atomicAdd(&frame_sub[2 * SUB_SET + (blockIdx.x & 63u) * SUB_STRIDE], nn);
+        if (nf) atomicAdd(&frame_sub[3 * SUB_SET + (blockIdx.x & 63u) * SUB_STRIDE], nf);
+    }
+    uint32_t rank = (uint32_t)__popcll(vw & ((1ull << lane) - 1ull));
+    for (int w = 0; w < wave; ++w) rank += s_v[w];
+    const uint32_t slot = offset + pre + rank;
+    const bool room = (uint64_t)slot < (uint64_t)fp.max_vertices;       // always, by the host's capacity rule for this frame form
+    const bool wr = is_valid && !is_fused && room;
+    float3 pw = make_float3(0.f, 0.f, 0.f);
+    if (wr) pw = write_new_surfel(cur, slot, L, fp);
+    bounds_expand_wave(tb, wr, slot / (uint32_t)TILE, pw.x, pw.y, pw.z, (float)fp.time, false);
+    if (is_fused && room) {                                               // the slot this pixel owned stays empty
+        atomicAnd((unsigned long long *)&alive[slot >> 6], ~(1ull << (slot & 63u)));
+        atomicAdd(&tile_dead[slot / (uint32_t)TILE], 1u);
+    }
+    if (is_valid && !room) st->error = -2;
 }
 
 // ---------------------------------------------------------------------------------------------
