@@ -61,7 +61,8 @@ def make_frames(cam_kw, n, seed, noise, workers, rank=0, world=1):
 
 def kernel_bytes(log):
     """Algorithmic HBM bytes per launch of each kernel from the per-frame counters
-    (DESIGN.md "Measurement"; SoA surfel = 44 B, key = 8 B)."""
+    (DESIGN.md "Measurement"; SoA surfel = 44 B, key = 8 B).  Every entry is an array over the timed frames; a kernel
+    that runs only on some frames is averaged over those frames by the caller."""
     P = log["P"]
     N, Np, V, F, U, Ns, Cs, Ss, Sl = (log[k].astype(np.float64) for k in
                                       ("n_before", "n_after_cull", "visible_count", "fused_count", "unstable_count", "n_static",
@@ -71,13 +72,79 @@ def kernel_bytes(log):
     # splat (pos_conf 16 + time 4) unless their tile's bounding box is out of view (then not at all); on a compacting
     # frame the rest is read in full (44) and its survivors rewritten (44); every drawn surfel costs one 8-byte key atomic
     compact = 20.0 * np.maximum(Ns - Ss, 0.0) + 44.0 * np.maximum(Sl - Ns, 0.0) + 44.0 * np.maximum(Np - Ns, 0.0) + 8.0 * V
+    # one-pass frames: pos_conf (16) of every slot whose tile is not skipped by BOTH tests (>= Sl - min(Cs, Ss): the
+    # exact count is not logged, this is the lower bound), the time (4) of the slots whose tile reaches the index map,
+    # one key atomic per drawn surfel
+    one_pass = 16.0 * np.maximum(Sl - np.minimum(Cs, Ss), 0.0) + 4.0 * np.maximum(Sl - Ss, 0.0) + 8.0 * V
     return {
         "k_prep": np.full_like(N, 6.0 * P + 24.0 * P),          # u8x3+u16+u8 in, f32+u32+u64+(f32,u32) out
         "k_conflict": 16.0 * np.maximum(Sl - Cs, 0.0),            # tiles skipped by their bounds are not read
         "k_compact": compact,
+        "k_surfel_pass": one_pass,
+        "k_pass_fixup": np.full_like(N, 4.0 * P),                 # the candidate count reads the depth plane once
         "k_associate": 16.0 * P + 84.0 * F,                       # depth+rgbs+key per pixel, gather 44 + scatter 40 per fuse
         "k_append": 8.0 * (P / 64.0) + 44.0 * U,
+        "k_associate_direct": 16.0 * P + 84.0 * F + 44.0 * U,     # ... and the new surfels written in place
     }
+
+
+def kernel_table(log, tim, P, K, args, workload=None):
+    """Per-kernel launches, average duration (HIP events), algorithmic bytes and GB/s of the timed frames, and the
+    roofline entry of the kernel the run spends most time in.  The frame forms: a frame whose cull only
+    marks the dead runs k_surfel_pass + k_pass_fixup (+ k_associate_direct when it appends directly), the others
+    k_conflict + k_scan_cull/k_cull_finalize + k_compact (or k_cull_lazy) and k_associate + k_append_scan."""
+    logd = {k: log[k] for k in log.dtype.names}
+    logd["P"] = P
+    kb = kernel_bytes(logd)
+    n_op, n_dir, n_comp = int(tim.get("frames_one_pass", 0)), int(tim.get("frames_direct", 0)), int(tim.get("frames_compact", 0))
+    moved = log["n_static"] < log["n_slots"] if len(log) else np.zeros(0, bool)      # frames that compacted
+    # (one-pass <=> not compacted on the default path; direct <=> one-pass and k_prep evaluated the tile flags)
+    sel_op = ~moved if n_op else np.zeros(len(log), bool)
+    sel_dir = sel_op if n_dir == n_op else np.zeros(len(log), bool)
+    rows = [("k_prep", tim["k_prep"], np.ones(len(log), bool), K),
+            ("k_surfel_pass", tim.get("k_surfel_pass", 0.0), sel_op, n_op),
+            ("k_pass_fixup", tim.get("k_pass_fixup", 0.0), sel_op, n_op),
+            ("k_associate_direct", tim.get("k_associate_direct", 0.0), sel_dir, n_dir),
+            ("k_conflict", tim.get("k_conflict_own", 0.0), ~sel_op, K - n_op),
+            ("k_compact", tim.get("k_compact_own", 0.0), moved, n_comp),
+            ("k_associate", tim.get("k_associate_own", 0.0), ~sel_dir, K - n_dir),
+            ("k_append", tim.get("k_append_own", 0.0), ~sel_dir, K - n_dir)]
+    if K - n_op - n_comp > 0:      # lazy culls outside the one-pass form (SM_ONE_PASS=0, or the depth filter chain on the second stream)
+        rows.append(("k_cull_lazy", tim.get("k_cull_lazy", 0.0), ~moved & ~sel_op, K - n_op - n_comp))
+    kern, launches = {}, {}
+    for name, ms, sel, n in rows:
+        if n <= 0:
+            continue
+        b = kb["k_compact" if name == "k_cull_lazy" else name]
+        mb = float(b[sel].mean()) / 1e6 if len(log) and sel.any() else 0.0
+        kern[name] = {"ms": ms, "MB": mb, "GBs": (mb / 1e3) / (ms * 1e-3) if ms > 0 else None, "launches": n}
+        launches[name] = n
+    if K - n_op > 0:
+        kern["k_scan_cull+k_cull_finalize"] = {"ms": tim["k_scan_cull"] * K / max(K - n_op, 1), "MB": None, "GBs": None, "launches": K - n_op}
+    # dominant kernel = the one the run spends most time in (average duration x launches)
+    dom = max(launches.keys(), key=lambda n: kern[n]["ms"] * launches[n])
+    achieved = kern[dom]["GBs"] or 0.0
+    traffic, valu = None, None
+    wl = workload or args.workload
+    for tpath in (os.path.join(ROOT, "profiles", f"traffic_{wl}_s{K}_w{max(args.warmup, 2)}.json"), os.path.join(ROOT, "profiles", f"traffic_{wl}.json")):
+        if not os.path.exists(tpath):
+            continue
+        # HBM bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this very
+        # command (profiles/README.md), gfx950-corrected per kernel by tools/prof_summary.py
+        tj = json.load(open(tpath))
+        if tj.get("steps") == K and tj.get("warmup") == max(args.warmup, 2) and tj.get("compact_period", 8) == args.compact_period:
+            traffic = tj.get("kernels", {}).get(dom, {}).get("hbm_bytes_per_launch")
+            valu = tj.get("kernels", {}).get(dom, {}).get("valu_issue_util")
+            break
+    roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "ms_per_launch": kern[dom]["ms"], "alg_bytes_per_launch": kern[dom]["MB"] * 1e6,
+                "launches": launches[dom],
+                "valu_issue_util": valu,
+                "note": "not byte-bound: a frame touches ~60 MB; the surfel kernel is limited by instruction issue "
+                        "(IEEE-exact fp32: ~350 VALU instructions per surfel for conflict test + splat, correctly rounded / and sqrt) "
+                        "and by the chain of dependent round trips of a launch that owns ~1 tile per workgroup (DESIGN.md 4)"}
+    return kern, launches, roofline
 
 
 def bench_sharded(args, dist, torch, capi, cam, frames, rank, world, local_rank, K, Wm, t_gen):
@@ -117,6 +184,46 @@ def bench_sharded(args, dist, torch, capi, cam, frames, rank, world, local_rank,
         "surfels_fused_per_sec": fused / elapsed, "roofline": None, "cpu_baseline": None, "gen_seconds": t_gen}))
 
 
+def run_simple_leg(capi, cam, frames, K, Wm, cfg_kw, args):
+    """One single-GPU leg: stage the frames in HBM, time K frames after Wm on an un-instrumented context, replay them on
+    a context with HIP events for the per-kernel durations.  Returns (frames/s, ms/step, frame log, counts, timings)."""
+    P = cam["width"] * cam["height"]
+
+    def stage(sm):
+        out = []
+        for rgb, depth, sem, pose in frames:
+            dr, dd, ds = sm.device_alloc(P * 3), sm.device_alloc(P * 2), sm.device_alloc(P)
+            sm.device_upload(dr, rgb); sm.device_upload(dd, depth); sm.device_upload(ds, sem)
+            out.append((dr, dd, ds, pose))
+        return out
+
+    sm = capi.SurfelMap(capi.make_config(**cam, **cfg_kw, enable_timing=0))
+    dptr = stage(sm)
+    for k in range(Wm):
+        sm.process_frame_device(*dptr[k])
+    sm.sync()
+    t0 = time.perf_counter()
+    for k in range(Wm, Wm + K):
+        sm.process_frame_device(*dptr[k])
+    sm.sync()
+    el = time.perf_counter() - t0
+    log, counts = sm.read_frame_log(K), sm.counts()
+    sm.close()
+    tim = None
+    if not args.no_events:
+        sm = capi.SurfelMap(capi.make_config(**cam, **cfg_kw, enable_timing=1))
+        dptr = stage(sm)
+        for k in range(Wm):
+            sm.process_frame_device(*dptr[k])
+        sm.sync(); sm.timings()
+        for k in range(Wm, Wm + K):
+            sm.process_frame_device(*dptr[k])
+        sm.sync()
+        tim = sm.timings()
+        sm.close()
+    return K / el, el / K * 1e3, log, counts, tim
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -138,6 +245,8 @@ def main():
     ap.add_argument("--force-dist", action="store_true", help="rehearse the multi-GPU code path with WORLD_SIZE=1")
     ap.add_argument("--compact-period", type=int, default=8,
                     help="deferred compaction: culled surfels keep their slots, every Nth cull squeezes them out (1: every frame)")
+    ap.add_argument("--no-fuse-leg", action="store_true",
+                    help="skip the second, labelled leg (same trajectory, depth noise 4 mm, fuse_thresh 0.05: frames that actually fuse)")
     ap.add_argument("--sync-every-frame", action="store_true",
                     help="reference semantics: host waits for the counters after every frame")
     args = ap.parse_args()
@@ -261,63 +370,39 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t[0])
-        fu = torch.tensor([float(log["fused_count"].sum() + log["unstable_count"].sum())], dtype=torch.float64, device=dev)
+        fu = torch.tensor([float(log["fused_count"].sum()), float(log["unstable_count"].sum())], dtype=torch.float64, device=dev)
         dist.all_reduce(fu, op=dist.ReduceOp.SUM)
-        fused_total = float(fu[0])
+        F_total, U_total = float(fu[0]), float(fu[1])
         dist.destroy_process_group()
     else:
-        fused_total = float(log["fused_count"].sum() + log["unstable_count"].sum())
+        F_total, U_total = float(log["fused_count"].sum()), float(log["unstable_count"].sum())
+    fused_total = F_total + U_total
 
     if rank != 0:
         return
 
     # ---- roofline of the dominant kernel (live HIP-event durations, algorithmic bytes)
-    logd = {k: log[k] for k in log.dtype.names}
-    logd["P"] = P
-    kb = kernel_bytes(logd)
-    kern, launches = {}, {}
-    for name, b in kb.items():
-        ms = tim[name]
-        kern[name] = {"ms": ms, "MB": float(b.mean()) / 1e6,
-                      "GBs": (float(b.mean()) / 1e9) / (ms * 1e-3) if ms > 0 else None}
-        launches[name] = K
-    # the cull slot holds one of two kernels: k_compact on the frames that compact, k_cull_lazy on the others
-    # (deferred compaction); each is averaged over its own frames.  "Moved" frames in the log: n_static < n_slots.
-    cull_b = kb.pop("k_compact")
-    del kern["k_compact"], launches["k_compact"]
-    moved = log["n_static"] < log["n_slots"] if len(log) else np.zeros(0, bool)
-    n_comp = int(tim.get("frames_compact", 0)) if sm_ev is not None else int(moved.sum())
-    for name, ms, sel, n in (("k_compact", tim.get("k_compact_own", 0.0), moved, n_comp),
-                             # (the lazy cull runs with its finalize step folded in unless the depth filter chain is on)
-                             ("k_cull_lazy" if args.preprocess else "k_cull_lazy_frame", tim.get("k_cull_lazy", 0.0), ~moved, K - n_comp)):
-        mb = float(cull_b[sel].mean()) / 1e6 if sel.any() else 0.0
-        kern[name] = {"ms": ms, "MB": mb, "GBs": (mb / 1e3) / (ms * 1e-3) if ms > 0 else None, "launches": n}
-        launches[name] = n
-    for name in ("k_scan_cull", "k_scan_new"):
-        kern[name] = {"ms": tim[name], "MB": None, "GBs": None}
-    # dominant kernel = the one the run spends most time in (average duration x launches)
-    dom = max(launches.keys(), key=lambda n: kern[n]["ms"] * launches[n])
-    achieved = kern[dom]["GBs"] or 0.0
-    traffic, valu = None, None
-    tpath = os.path.join(ROOT, "profiles", f"traffic_{args.workload}.json")
-    if os.path.exists(tpath):
-        # HBM bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this very
-        # command (profiles/README.md), gfx950-corrected by tools/prof_summary.py
-        tj = json.load(open(tpath))
-        if tj.get("steps") == K and tj.get("warmup") == Wm and tj.get("compact_period", 8) == args.compact_period:
-            traffic = tj.get("kernels", {}).get(dom, {}).get("hbm_bytes_per_launch")
-            valu = tj.get("kernels", {}).get(dom, {}).get("valu_issue_util")
-    roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "ms_per_launch": kern[dom]["ms"], "alg_bytes_per_launch": kern[dom]["MB"] * 1e6,
-                "launches": launches[dom],
-                "valu_issue_util": valu,
-                "note": "not byte-bound: a frame touches ~100 MB; the surfel kernels are limited by instruction issue "
-                        "(IEEE-exact fp32: ~200 VALU instructions per surfel, correctly rounded / and sqrt) and by the "
-                        "chain of dependent round trips of a launch that owns ~1 tile per workgroup (DESIGN.md 4)"}
+    kern, launches, roofline = kernel_table(log, tim, P, K, args)
+
+    # ---- second, labelled leg: the same trajectory with 4 mm depth noise and fuse_thresh = 0.05, so that the in-place
+    # integration (depth/colour/normal/radius update, data.vert:177-208) is timed with F > 0; `value` stays the default config
+    fuse_leg = None
+    if not hd and dist is None and not args.no_fuse_leg:
+        ff = make_frames(cam, n_frames, args.seed, 4.0, workers)
+        fv, fms, flog, fcounts, ftim = run_simple_leg(capi, cam, ff, K, Wm, dict(preprocess=args.preprocess, device=local_rank, conflict_cap=1,
+                                                                                 fuse_thresh=0.05, compact_period=args.compact_period), args)
+        fuse_leg = {"config": "same KITTI trajectory and scene, depth noise 4 mm, fuse_thresh 0.05 (Config::surfelFuseDistanceThreshFactor)",
+                    "value": fv, "unit": "frames/s", "ms_per_step": fms,
+                    "fused_F_per_frame": float(flog["fused_count"].mean()), "new_U_per_frame": float(flog["unstable_count"].mean()),
+                    "fused_F_per_sec": float(flog["fused_count"].sum()) / (fms * 1e-3 * K),
+                    "conflicts_per_frame": float(flog["conflict_count"].mean()), "surfels_end": int(fcounts["count"])}
+        if ftim is not None:
+            fk, _, froof = kernel_table(flog, ftim, P, K, args, workload="kitti_fuse")
+            fuse_leg["kernels"] = fk
+            fuse_leg["roofline"] = {k: froof[k] for k in ("kernel", "achieved", "frac", "ms_per_launch", "alg_bytes_per_launch")}
 
     # ---- CPU baseline: the oracle over the very same frames (rank 0, N=1 only)
-    cpu = None
+    cpu, cpu_all = None, None
     if not args.no_cpu_baseline and dist is None:
         import oracle_lib as ol                  # checker / baseline only
         o = ol.Oracle(ol.make_config(**cam, preprocess=args.preprocess, conflict_cap=0 if hd else 1,
@@ -334,6 +419,29 @@ def main():
         c_el = time.perf_counter() - c0
         oc = o.counts()
         same = (Kc == K) and all(oc[k] == counts[k] for k in ("count", "offset", "unstable_count", "fused_count", "conflict_count"))
+        # all cores: the OpenMP build of the same oracle source (bit-identical results: tests/test_oracle_omp.py), on the
+        # CPU share of one GPU of this box (16 hardware threads of 256), same frames
+        cpu_all = None
+        try:
+            nthr = max(1, min(os.cpu_count() or 1, int(os.environ.get("SM_BENCH_CPU_THREADS", "16"))))
+            os.environ["OMP_NUM_THREADS"] = str(nthr)
+            oa = ol.Oracle(ol.make_config(**cam, preprocess=args.preprocess, conflict_cap=0 if hd else 1,
+                                          max_sqrt_vertices=10000 if hd else 5000), libpath=ol.OMP_LIB_PATH)
+            if hd:
+                oa.upload_model(seed_model); oa.set_tick(300)
+            for k in range(Wm):
+                oa.process_frame(*frames[k])
+            a0 = time.perf_counter()
+            for k in range(Wm, Wm + Kc):
+                oa.process_frame(*frames[k])
+            a_el = time.perf_counter() - a0
+            oac = oa.counts()
+            cpu_all = {"value": Kc / a_el, "unit": "frames/s", "cores": nthr, "kind": "port",
+                       "sample": f"the same {Kc} frames, oracle/libsmo_omp.so (OpenMP build of the same source), {nthr} threads",
+                       "final_counts_match_1_thread": all(oac[k] == oc[k] for k in oc)}
+            oa.close()
+        except Exception as e:               # the baseline is a report, never a reason to lose the GPU line
+            cpu_all = {"error": repr(e)}
         cpu = {"value": Kc / c_el, "unit": "frames/s", "cores": 1, "kind": "port",
                "sample": f"the first {Kc} of the same {K} frames (after the same {Wm} warm-up frames), oracle/libsmo.so, 1 thread, "
                          f"host {os.cpu_count()} logical CPUs", "final_counts_match_gpu": bool(same) if Kc == K else None}
@@ -364,8 +472,16 @@ def main():
                                  if args.compact_period > 1 else "every frame",
                    "surfels_start": int(log["n_before"][0]) if len(log) else 0, "surfels_end": int(counts["count"])},
         "surfels_fused_per_sec": fused_total / elapsed,
+        # F (measurements integrated into an existing surfel) and U (new surfels) separately.  With the reference's
+        # default fuse threshold 0.0 only bit-equal ray depths associate, so on a moving camera F ~ 0 and the figure above is
+        # append throughput; `fuse_leg` below times the integration path with F > 0.
+        "fused_F": {"total": F_total, "per_sec": F_total / elapsed, "per_frame": F_total / (K * world)},
+        "new_U": {"total": U_total, "per_sec": U_total / elapsed, "per_frame": U_total / (K * world)},
+        "conflicts_per_frame": float(log["conflict_count"].mean()) if len(log) else 0.0,
+        "fuse_leg": fuse_leg,
         "roofline": roofline,
         "cpu_baseline": cpu,
+        "cpu_baseline_all_cores": cpu_all if cpu is not None else None,
         "kernels": kern,
         "frame_ms_gpu_events": tim["run"],
         "host_enqueue_ms_per_step": t_enq / K * 1e3,

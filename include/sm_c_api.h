@@ -89,6 +89,13 @@ typedef struct sm_timings {
     float k_compact_own;      /* k_compact, averaged over the frames that compacted */
     float k_cull_lazy;        /* k_cull_lazy, averaged over the frames that only marked the dead */
     uint32_t frames_compact;  /* how many of `frames` compacted */
+    /* the frame forms of the default path, each kernel averaged over the frames that ran it:
+     * one-pass frames (the cull only marks the dead): k_surfel_pass (conflict + cull + splat) and k_pass_fixup;
+     * direct-append frames: k_associate_direct (association + fuse + append); the other frames run k_conflict
+     * (+ k_scan_cull + k_cull_finalize + k_compact) and k_associate + k_append_scan */
+    float k_surfel_pass, k_pass_fixup, k_conflict_own;
+    float k_associate_direct, k_associate_own, k_append_own;
+    uint32_t frames_one_pass, frames_direct;
 } sm_timings;
 
 /* Per-frame counters written by the device at the end of every fusing frame (ring of

@@ -17,6 +17,12 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+/* All-core build (oracle/Makefile: libsmo_omp.so, -fopenmp): the per-surfel / per-pixel loops run in parallel, every
+ * ordered output (conflict records, compactions, data records) is produced through flags + prefix sums so that the
+ * result is bit-identical to the serial build (tests/test_oracle_omp.py).  Used for bench.py's all-core CPU baseline. */
+#include <omp.h>
+#endif
 
 #define SURFEL_F 12
 
@@ -62,6 +68,11 @@ struct smo_ctx {
     float curr_pose[16], last_pose[16];
     int32_t exempt_id;        /* surfel that never fuses / conflicts: id 0 (A5); shard tests move it */
     int32_t *data_pix;        /* column-major pixel index of every dataVbo record */
+#ifdef _OPENMP
+    uint8_t *omp_flag; uint32_t omp_flag_cap;   /* per-surfel flags of the parallel passes */
+    uint64_t *omp_key;                          /* per-pixel (d24 << 32 | id) keys of the parallel index-map splat */
+    uint32_t *omp_col;                          /* per-column record counts / offsets of the parallel association */
+#endif
 };
 
 int smo_end_frame(smo_ctx *s);
@@ -339,6 +350,9 @@ void smo_destroy(smo_ctx *s)
     free(s->model); free(s->mvc); free(s->mct); free(s->mnr);
     free(s->data); free(s->unstable); free(s->conflict);
     free(s->idx); free(s->zbuf); free(s->data_pix); free(s->ivc); free(s->ict); free(s->inr);
+#ifdef _OPENMP
+    free(s->omp_flag); free(s->omp_key); free(s->omp_col);
+#endif
     free(s);
 }
 
@@ -383,6 +397,9 @@ void smo_metricise(const smo_config *c, const uint16_t *raw, float *out)
     int W = c->width, H = c->height;
     uint32_t lo = (uint32_t)(c->near_clip * 1000.0f);
     uint32_t hi = (uint32_t)((c->far_clip - 0.001f) * 1000.0f);
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
     for (int j = 0; j < H; ++j)
         for (int i = 0; i < W; ++i) {
             uint32_t v = raw[(size_t)j * W + i];
@@ -401,6 +418,9 @@ void smo_filter_depth(const smo_config *c, const float *d, const uint8_t *sem, f
 {
     int W = c->width, H = c->height;
     float minD = c->near_clip, maxD = 100.0f;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
     for (int j = 0; j < H; ++j)
         for (int i = 0; i < W; ++i) {
             size_t p = (size_t)j * W + i;
@@ -440,6 +460,9 @@ void smo_smooth_depth(const smo_config *c, const float *d, const uint8_t *sem, f
             wtab[iy + 6][ix + 6] = smo_expf(-(sd2 * sigPix));
         }
     int border = (int)ceilf(c->stereo_border - 0.5f); /* texX < border/cols  <=>  i+0.5 < border */
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
     for (int j = 0; j < H; ++j)
         for (int i = 0; i < W; ++i) {
             size_t p = (size_t)j * W + i;
@@ -475,6 +498,9 @@ void smo_remove_movings(const smo_config *c, const float *d, const uint8_t *sem,
     float cols = (float)W, rows = (float)H;
     float minD = c->near_clip, maxD = 100.0f, moveThresh = 0.5f;
     float fx = c->fx, fy = c->fy, cx = c->cx, cy = c->cy;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
     for (int j = 0; j < H; ++j)
         for (int i = 0; i < W; ++i) {
             size_t p = (size_t)j * W + i;
@@ -505,10 +531,39 @@ void smo_remove_movings(const smo_config *c, const float *d, const uint8_t *sem,
 static void upload_rgb(smo_ctx *s, const uint8_t *rgb)
 {
     size_t n = (size_t)s->P * 3;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
     for (size_t k = 0; k < n; ++k) s->rgb[k] = (float)rgb[k] / 255.0f;
 }
 
 /* ------------------------------------------------------------------ p2: conflict */
+
+/* conflict.vert:25-73 for surfel k: does the measured depth lie behind it along the ray? */
+static int conflict_test(const smo_ctx *s, const float *t_inv, uint32_t k, float min_depth, float max_depth,
+                         float fuse_thresh, int is_clean)
+{
+    const smo_config *c = &s->c;
+    int W = c->width, H = c->height;
+    float cols = (float)W, rows = (float)H;
+    const float *v = s->model + (size_t)k * SURFEL_F;
+    float ph[4];
+    xform(t_inv, v[0], v[1], v[2], ph);
+    float xl = fdiv(ph[0], ph[2]);
+    float yl = fdiv(ph[1], ph[2]);
+    float u = c->fx * xl + c->cx;
+    float vv = c->fy * yl + c->cy;
+    if (u < c->stereo_border || u > cols || vv < 0.0f || vv > rows || ph[2] <= min_depth ||
+        ph[2] >= max_depth)
+        return 0;   /* conf_id = -10 */
+    float lambda = sqrtf((xl * xl + yl * yl) + 1.0f);
+    int ti = tex_idx(fdiv(u, cols), W), tj = tex_idx(fdiv(vv, rows), H);
+    float depth = s->depth_metric[(size_t)tj * W + ti];
+    uint32_t sem = s->sem[(size_t)tj * W + ti];
+    if (sem == 10u) depth = max_depth + 1.0f;
+    if (is_clean == 0 && depth == 0.0f) depth = max_depth + 20.0f;
+    return depth * lambda - ph[2] * lambda > fuse_thresh * ph[2];
+}
 
 /* GlobalModel::processConflict (src/GlobalModel.cpp:396-476), conflict.vert:25-83,
  * conflict.geom:13-24.  Writes records (idbits, x, y, z, conf-1); A13: transform feedback
@@ -517,8 +572,6 @@ int smo_stage_process_conflict(smo_ctx *s, const float *pose, float min_depth, f
                                float fuse_thresh, int is_clean)
 {
     const smo_config *c = &s->c;
-    int W = c->width, H = c->height;
-    float cols = (float)W, rows = (float)H;
     float t_inv[16];
     smo_invert4(pose, t_inv);
     uint32_t cap = c->conflict_cap ? (uint32_t)s->P : s->count;
@@ -528,35 +581,40 @@ int smo_stage_process_conflict(smo_ctx *s, const float *pose, float min_depth, f
         s->conflict_cap = cap;
     }
     uint32_t n = 0;
+#ifdef _OPENMP
+    /* parallel: the conflict test of every surfel (flag); serial: the records in surfel order, capped */
+    if (s->count > s->omp_flag_cap) {
+        s->omp_flag = realloc(s->omp_flag, s->count);
+        if (!s->omp_flag) abort();
+        s->omp_flag_cap = s->count;
+    }
+#pragma omp parallel for schedule(static)
+    for (uint32_t k = 0; k < s->count; ++k)
+        s->omp_flag[k] = (uint8_t)conflict_test(s, t_inv, k, min_depth, max_depth, fuse_thresh, is_clean);
     for (uint32_t k = 0; k < s->count; ++k) {
+        if (!s->omp_flag[k] || (int32_t)k == s->exempt_id || n >= cap) continue;
         const float *v = s->model + (size_t)k * SURFEL_F;
-        float ph[4];
-        xform(t_inv, v[0], v[1], v[2], ph);
-        float xl = fdiv(ph[0], ph[2]);
-        float yl = fdiv(ph[1], ph[2]);
-        float u = c->fx * xl + c->cx;
-        float vv = c->fy * yl + c->cy;
-        if (u < c->stereo_border || u > cols || vv < 0.0f || vv > rows || ph[2] <= min_depth ||
-            ph[2] >= max_depth)
-            continue;   /* conf_id = -10 */
-        float lambda = sqrtf((xl * xl + yl * yl) + 1.0f);
-        int ti = tex_idx(fdiv(u, cols), W), tj = tex_idx(fdiv(vv, rows), H);
-        float depth = s->depth_metric[(size_t)tj * W + ti];
-        uint32_t sem = s->sem[(size_t)tj * W + ti];
-        if (sem == 10u) depth = max_depth + 1.0f;
-        if (is_clean == 0 && depth == 0.0f) depth = max_depth + 20.0f;
-        if (depth * lambda - ph[2] * lambda > fuse_thresh * ph[2]) {
-            if ((int32_t)k != s->exempt_id) {    /* conflict.geom:15: conf_id > 0, i.e. every id but 0 */
-                if (n < cap) {
-                    float *r = s->conflict + (size_t)n * 5;
-                    r[0] = u2f(k);
-                    r[1] = v[0]; r[2] = v[1]; r[3] = v[2];
-                    r[4] = v[3] - 1.0f;          /* conflict.vert:72 */
-                    n++;
-                }
+        float *r = s->conflict + (size_t)n * 5;
+        r[0] = u2f(k);
+        r[1] = v[0]; r[2] = v[1]; r[3] = v[2];
+        r[4] = v[3] - 1.0f;
+        n++;
+    }
+#else
+    for (uint32_t k = 0; k < s->count; ++k) {
+        if (!conflict_test(s, t_inv, k, min_depth, max_depth, fuse_thresh, is_clean)) continue;
+        if ((int32_t)k != s->exempt_id) {    /* conflict.geom:15: conf_id > 0, i.e. every id but 0 */
+            if (n < cap) {
+                const float *v = s->model + (size_t)k * SURFEL_F;
+                float *r = s->conflict + (size_t)n * 5;
+                r[0] = u2f(k);
+                r[1] = v[0]; r[2] = v[1]; r[3] = v[2];
+                r[4] = v[3] - 1.0f;          /* conflict.vert:72 */
+                n++;
             }
         }
     }
+#endif
     s->conflict_count = n;
     return SMO_OK;
 }
@@ -564,6 +622,9 @@ int smo_stage_process_conflict(smo_ctx *s, const float *pose, float min_depth, f
 /* GlobalModel::updateConflict (src/GlobalModel.cpp:478-515), update_conf.vert:11-27 */
 int smo_stage_update_conflict(smo_ctx *s)
 {
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)      /* every record addresses its own texel (ids are unique) */
+#endif
     for (uint32_t q = 0; q < s->conflict_count; ++q) {
         const float *r = s->conflict + (size_t)q * 5;
         uint32_t id = f2u(r[0]);
@@ -579,6 +640,43 @@ int smo_stage_back_mapping(smo_ctx *s)
     uint32_t n = 0;
     ensure_mirror(s, s->count);
     ensure_model(s, s->count);
+#ifdef _OPENMP
+    {   /* stable compaction in parallel: survivors per chunk, exclusive prefix, every chunk copies to its own range */
+        enum { MAXT = 256 };
+        uint32_t cnt[MAXT + 1];
+        int nt = omp_get_max_threads();
+        if (nt > MAXT) nt = MAXT;
+        const uint32_t N = s->count, per = (N + (uint32_t)nt - 1) / (uint32_t)nt;
+#pragma omp parallel num_threads(nt)
+        {
+            const int t = omp_get_thread_num();
+            const uint32_t k0 = (uint32_t)t * per < N ? (uint32_t)t * per : N, k1 = k0 + per < N ? k0 + per : N;
+            uint32_t c = 0;
+            for (uint32_t k = k0; k < k1; ++k) c += s->mvc[(size_t)k * 4 + 3] > 0.0f;
+            cnt[t] = c;
+#pragma omp barrier
+#pragma omp single
+            {
+                uint32_t run = 0;
+                for (int x = 0; x < nt; ++x) { const uint32_t y = cnt[x]; cnt[x] = run; run += y; }
+                cnt[nt] = run;
+            }
+            uint32_t w = cnt[t];
+            for (uint32_t k = k0; k < k1; ++k) {
+                const float *vc = s->mvc + (size_t)k * 4;
+                if (vc[3] > 0.0f) {
+                    float *o = s->model + (size_t)w * SURFEL_F;
+                    memcpy(o, vc, 16);
+                    memcpy(o + 4, s->mct + (size_t)k * 4, 16);
+                    memcpy(o + 8, s->mnr + (size_t)k * 4, 16);
+                    o[5] = 0.0f;
+                    w++;
+                }
+            }
+        }
+        n = cnt[nt];
+    }
+#else
     for (uint32_t k = 0; k < s->count; ++k) {
         const float *vc = s->mvc + (size_t)k * 4;
         if (vc[3] > 0.0f) {
@@ -590,6 +688,7 @@ int smo_stage_back_mapping(smo_ctx *s)
             n++;
         }
     }
+#endif
     s->offset = n;
     s->count = n;                                /* src/GlobalModel.cpp:575 */
     return SMO_OK;
@@ -604,6 +703,9 @@ int smo_stage_build_model_map(smo_ctx *s)
     memset(s->mvc, 0, (size_t)clr * 16);
     memset(s->mct, 0, (size_t)clr * 16);
     memset(s->mnr, 0, (size_t)clr * 16);
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
     for (uint32_t k = 0; k < s->count; ++k) {
         const float *v = s->model + (size_t)k * SURFEL_F;
         memcpy(s->mvc + (size_t)k * 4, v, 16);
@@ -619,58 +721,103 @@ int smo_stage_build_model_map(smo_ctx *s)
 
 /* IndexMap::predictIndices (src/IndexMap.cpp:138-198), index_map.vert:38-64,
  * index_map.frag:31-37; rasterisation/depth rules A3/A4. */
-int smo_stage_predict_indices(smo_ctx *s, const float *pose, int time, float depth_cutoff,
-                              int time_delta)
+/* index_map.vert:38-64 for surfel k: camera-frame position ph, target pixel p (row-major), 24-bit depth.
+ * Returns 0 if the surfel draws no fragment (view test, clipping, depth test against the clear value). */
+static int splat_project(const smo_ctx *s, const float *t_inv, uint32_t k, int time, float depth_cutoff, int time_delta,
+                         float *ph, size_t *pix, uint32_t *d24_out)
 {
     const smo_config *c = &s->c;
     int W = c->width, H = c->height;
-    size_t P = (size_t)s->P;
     float cols = (float)W, rows = (float)H;
+    const float *v = s->model + (size_t)k * SURFEL_F;
+    xform(t_inv, v[0], v[1], v[2], ph);
+    if (ph[2] >= depth_cutoff * 1.5f || ph[2] <= 0.0f ||
+        (float)time - v[7] > (float)time_delta)
+        return 0;                             /* index_map.vert:45-50 (clipped at -10,-10) */
+    float xn = fdiv((fdiv(c->fx * ph[0], ph[2]) + c->cx) - (cols * 0.5f), cols * 0.5f);
+    float yn = fdiv((fdiv(c->fy * ph[1], ph[2]) + c->cy) - (rows * 0.5f), rows * 0.5f);
+    float zn = fdiv(ph[2], depth_cutoff);
+    if (!(xn >= -1.0f && xn <= 1.0f && yn >= -1.0f && yn <= 1.0f && zn >= -1.0f && zn <= 1.0f))
+        return 0;                             /* clip volume */
+    float xw = (cols * 0.5f) * xn + (cols * 0.5f);
+    float yw = (rows * 0.5f) * yn + (rows * 0.5f);
+    float fxw = floorf(xw), fyw = floorf(yw);
+    if (!(fxw >= 0.0f && fxw < cols && fyw >= 0.0f && fyw < rows)) return 0;
+    int px = (int)fxw, py = (int)fyw;
+    float zw = 0.5f * zn + 0.5f;
+#ifdef SMO_VAR_D24_TRUNC
+    uint32_t d24 = (uint32_t)((double)zw * 16777215.0);
+#else
+    uint32_t d24 = (uint32_t)floor((double)zw * 16777215.0 + 0.5);
+#endif
+    if (d24 >= 16777215u) return 0;           /* fails GL_LESS against the clear value */
+    *pix = (size_t)py * W + px;
+    *d24_out = d24;
+    return 1;
+}
+
+/* the fragment of surfel k lands in pixel p: index_map.frag:31-37 outputs */
+static void splat_write(smo_ctx *s, const float *t_inv, uint32_t k, const float *ph, size_t p, uint32_t d24)
+{
+    const float *v = s->model + (size_t)k * SURFEL_F;
+    s->zbuf[p] = d24;
+    s->idx[p] = (int32_t)k;
+    float *o = s->ivc + p * 4;
+    o[0] = ph[0]; o[1] = ph[1]; o[2] = ph[2]; o[3] = v[3];
+    memcpy(s->ict + p * 4, v + 4, 16);
+    float n[3];
+    rot3(t_inv, v[8], v[9], v[10], n);
+    normalize3(n);
+    o = s->inr + p * 4;
+    o[0] = n[0]; o[1] = n[1]; o[2] = n[2]; o[3] = v[11];
+}
+
+int smo_stage_predict_indices(smo_ctx *s, const float *pose, int time, float depth_cutoff,
+                              int time_delta)
+{
+    size_t P = (size_t)s->P;
     float t_inv[16];
     smo_invert4(pose, t_inv);
     memset(s->idx, 0, P * 4);                     /* glClearColor(0,0,0,0) src/IndexMap.cpp:151 */
     memset(s->ivc, 0, P * 16); memset(s->ict, 0, P * 16); memset(s->inr, 0, P * 16);
-    for (size_t p = 0; p < P; ++p) s->zbuf[p] = 16777215u;   /* depth cleared to 1.0 */
     uint32_t vis = 0;
+#ifdef _OPENMP
+    /* parallel z-buffer: GL_LESS with draw order = lexicographic minimum of (d24, id), kept as one 64-bit key per pixel */
+    if (!s->omp_key) { s->omp_key = malloc(P * 8); if (!s->omp_key) abort(); }
+#pragma omp parallel for schedule(static)
+    for (size_t p = 0; p < P; ++p) { s->zbuf[p] = 16777215u; s->omp_key[p] = ~0ull; }
+#pragma omp parallel for schedule(static) reduction(+ : vis)
     for (uint32_t k = 0; k < s->count; ++k) {
-        const float *v = s->model + (size_t)k * SURFEL_F;
         float ph[4];
-        xform(t_inv, v[0], v[1], v[2], ph);
-        if (ph[2] >= depth_cutoff * 1.5f || ph[2] <= 0.0f ||
-            (float)time - v[7] > (float)time_delta)
-            continue;                             /* index_map.vert:45-50 (clipped at -10,-10) */
-        float xn = fdiv((fdiv(c->fx * ph[0], ph[2]) + c->cx) - (cols * 0.5f), cols * 0.5f);
-        float yn = fdiv((fdiv(c->fy * ph[1], ph[2]) + c->cy) - (rows * 0.5f), rows * 0.5f);
-        float zn = fdiv(ph[2], depth_cutoff);
-        if (!(xn >= -1.0f && xn <= 1.0f && yn >= -1.0f && yn <= 1.0f && zn >= -1.0f && zn <= 1.0f))
-            continue;                             /* clip volume */
-        float xw = (cols * 0.5f) * xn + (cols * 0.5f);
-        float yw = (rows * 0.5f) * yn + (rows * 0.5f);
-        float fxw = floorf(xw), fyw = floorf(yw);
-        if (!(fxw >= 0.0f && fxw < cols && fyw >= 0.0f && fyw < rows)) continue;
-        int px = (int)fxw, py = (int)fyw;
-        float zw = 0.5f * zn + 0.5f;
-#ifdef SMO_VAR_D24_TRUNC
-        uint32_t d24 = (uint32_t)((double)zw * 16777215.0);
-#else
-        uint32_t d24 = (uint32_t)floor((double)zw * 16777215.0 + 0.5);
-#endif
-        if (d24 >= 16777215u) continue;           /* fails GL_LESS against the clear value */
+        size_t p;
+        uint32_t d24;
+        if (!splat_project(s, t_inv, k, time, depth_cutoff, time_delta, ph, &p, &d24)) continue;
         vis++;
-        size_t p = (size_t)py * W + px;
-        if (d24 < s->zbuf[p]) {                   /* GL_LESS: earlier (lower id) wins ties */
-            s->zbuf[p] = d24;
-            s->idx[p] = (int32_t)k;
-            float *o = s->ivc + p * 4;
-            o[0] = ph[0]; o[1] = ph[1]; o[2] = ph[2]; o[3] = v[3];
-            memcpy(s->ict + p * 4, v + 4, 16);
-            float n[3];
-            rot3(t_inv, v[8], v[9], v[10], n);
-            normalize3(n);
-            o = s->inr + p * 4;
-            o[0] = n[0]; o[1] = n[1]; o[2] = n[2]; o[3] = v[11];
-        }
+        const uint64_t key = ((uint64_t)d24 << 32) | k;
+        uint64_t cur = __atomic_load_n(&s->omp_key[p], __ATOMIC_RELAXED);
+        while (key < cur && !__atomic_compare_exchange_n(&s->omp_key[p], &cur, key, 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
     }
+#pragma omp parallel for schedule(static)
+    for (size_t p = 0; p < P; ++p) {
+        const uint64_t key = s->omp_key[p];
+        if (key == ~0ull) continue;
+        float ph[4];
+        size_t p2;
+        uint32_t d24;
+        splat_project(s, t_inv, (uint32_t)key, time, depth_cutoff, time_delta, ph, &p2, &d24);
+        splat_write(s, t_inv, (uint32_t)key, ph, p, d24);
+    }
+#else
+    for (size_t p = 0; p < P; ++p) s->zbuf[p] = 16777215u;   /* depth cleared to 1.0 */
+    for (uint32_t k = 0; k < s->count; ++k) {
+        float ph[4];
+        size_t p;
+        uint32_t d24;
+        if (!splat_project(s, t_inv, k, time, depth_cutoff, time_delta, ph, &p, &d24)) continue;
+        vis++;
+        if (d24 < s->zbuf[p]) splat_write(s, t_inv, k, ph, p, d24);   /* GL_LESS: earlier (lower id) wins ties */
+    }
+#endif
     s->visible_count = vis;
     return SMO_OK;
 }
@@ -687,145 +834,175 @@ static inline void get_vertex(const smo_ctx *s, int ti, int tj, float x, float y
     o[2] = z;
 }
 
+/* data.vert:59-234 + data.geom:32-45 for pixel (i, j): returns 0 if the vertex is dropped (tag -10), else writes the
+ * dataVbo record to o and returns 1 (new surfel, tag -1) or 2 (fused into surfel `tag`). */
+static int associate_one(const smo_ctx *s, const float *pose, float time, float depth_min, float depth_max, int i, int j,
+                         float *o)
+{
+    const smo_config *c = &s->c;
+    int W = c->width;
+    float camz = (float)(1.0 / (double)c->fx), camw = (float)(1.0 / (double)c->fy);
+    float fuseThresh = c->fuse_thresh;            /* src/GlobalModel.cpp:284 */
+    const float *D = s->depth_metric;
+    float x = s->xs[i], y = s->ys[j];
+    float xl = (x - c->cx) * camz;
+    float yl = (y - c->cy) * camw;
+    float ray[3] = {xl, yl, 1.0f};
+    float lambda = sqrtf((xl * xl + yl * yl) + 1.0f);
+    int ci = s->ixc[i], cj = s->iyc[j];
+    float value = D[(size_t)cj * W + ci];
+    /* checkNeighbours data.vert:33-52 */
+    if (D[(size_t)cj * W + s->ixm[i]] == 0.0f) return 0;
+    if (D[(size_t)s->iym[j] * W + ci] == 0.0f) return 0;
+    if (D[(size_t)cj * W + s->ixp[i]] == 0.0f) return 0;
+    if (D[(size_t)s->iyp[j] * W + ci] == 0.0f) return 0;
+    if (!(value > depth_min && value < depth_max)) return 0;
+    if (((int)x + (int)y) % 2 != 1) return 0;
+
+    float vPosLocal[3];
+    get_vertex(s, ci, cj, x, y, vPosLocal);
+    /* getNormal geometry.glsl:12-24 */
+    float xf[3], xb[3], yf[3], yb[3], del_x[3], del_y[3], vNormLocal[3];
+    get_vertex(s, s->ixp[i], cj, x + 1.0f, y, xf);
+    get_vertex(s, s->ixm[i], cj, x - 1.0f, y, xb);
+    get_vertex(s, ci, s->iyp[j], x, y + 1.0f, yf);
+    get_vertex(s, ci, s->iym[j], x, y - 1.0f, yb);
+    for (int q = 0; q < 3; ++q) { del_x[q] = xb[q] - xf[q]; del_y[q] = yb[q] - yf[q]; }
+    cross3(del_x, del_y, vNormLocal);
+    normalize3(vNormLocal);
+
+    float c_n = 0.9f;                     /* data.vert:104 */
+    size_t p = (size_t)cj * W + ci;
+    float color_n[3] = {s->rgb[p * 3], s->rgb[p * 3 + 1], s->rgb[p * 3 + 2]};
+    float radii_n = smo_get_radius(vPosLocal[2], vNormLocal[2], camz, camw);
+    uint32_t sem_n = s->sem[p];
+
+    int updateCounter = 0;
+    int bestID = 0;
+    float bestDist = 1000.0f;
+    float posLocal_o[3] = {0, 0, 0}, c_o = 0.0f, normRad_o[4] = {0, 0, 0, 0};
+    float color_o[3] = {0, 0, 0}, initTime_o = 0.0f;
+
+    /* window loop data.vert:126-172 with scale == IndexMap::FACTOR == 1: one lookup */
+    int currentID = s->idx[p];
+    /* data.vert:142 `currentID > 0`: a projection exists and it is not surfel 0 (the index
+     * texture is cleared to 0, A5); written via the depth buffer so that shard tests can
+     * move the exempt id */
+    if (s->zbuf[p] != 16777215u && currentID != s->exempt_id) {
+        const float *vertConf = s->ivc + p * 4;
+        const float *colorTime = s->ict + p * 4;
+        uint32_t sc = f2u(colorTime[0]);
+        uint32_t sem_o = (sc >> 24) & 0xFFu;
+        if (sem_n == sem_o &&
+            fabsf(vertConf[2] * lambda - vPosLocal[2] * lambda) <= fuseThresh) {
+            float cr[3];
+            cross3(ray, vertConf, cr);
+            float dist = fdiv(sqrtf(dot3(cr, cr)), sqrtf(dot3(ray, ray)));
+            const float *normRad = s->inr + p * 4;
+            float ang = smo_acosf(fdiv(dot3(normRad, vNormLocal),
+                                       sqrtf(dot3(normRad, normRad)) *
+                                       sqrtf(dot3(vNormLocal, vNormLocal))));
+            if (dist < bestDist && fabsf(ang) < 0.5f) {
+                updateCounter++;
+                bestDist = dist;
+                bestID = currentID;
+                memcpy(posLocal_o, vertConf, 12);
+                c_o = vertConf[3];
+                memcpy(normRad_o, normRad, 16);
+                color_o[0] = (float)((sc >> 16) & 0xFFu) / 255.0f;
+                color_o[1] = (float)((sc >> 8) & 0xFFu) / 255.0f;
+                color_o[2] = (float)(sc & 0xFFu) / 255.0f;
+                initTime_o = colorTime[2];
+            }
+        }
+    }
+
+    float t4[4], n3[3];
+    if (updateCounter > 0) {
+        if (radii_n < 1.5f * normRad_o[3]) {              /* data.vert:177-194 */
+            float w = c_n + c_o;
+            float pn[3];
+            for (int q = 0; q < 3; ++q)
+                pn[q] = fdiv((c_n * vPosLocal[q]) + (c_o * posLocal_o[q]), w);
+            xform(pose, pn[0], pn[1], pn[2], t4);
+            o[0] = t4[0]; o[1] = t4[1]; o[2] = t4[2]; o[3] = w;
+            float avg[3];
+            for (int q = 0; q < 3; ++q)
+                avg[q] = fdiv((c_n * color_n[q]) + (c_o * color_n[q]), w);   /* sic :183 */
+            o[4] = smo_encode_color(avg[0], avg[1], avg[2], sem_n);
+            o[5] = u2f((uint32_t)bestID);
+            o[6] = initTime_o;
+            o[7] = time;
+            float nr[4];
+            nr[0] = fdiv((c_n * vNormLocal[0]) + (c_o * normRad_o[0]), w);
+            nr[1] = fdiv((c_n * vNormLocal[1]) + (c_o * normRad_o[1]), w);
+            nr[2] = fdiv((c_n * vNormLocal[2]) + (c_o * normRad_o[2]), w);
+            rot3(pose, nr[0], nr[1], nr[2], n3);
+            normalize3(n3);
+            o[8] = n3[0]; o[9] = n3[1]; o[10] = n3[2];
+            o[11] = (radii_n > normRad_o[3]) ? normRad_o[3] : radii_n;
+        } else {                                          /* data.vert:195-208 */
+            xform(pose, posLocal_o[0], posLocal_o[1], posLocal_o[2], t4);
+            o[0] = t4[0]; o[1] = t4[1]; o[2] = t4[2]; o[3] = c_n + c_o;
+            o[4] = smo_encode_color(color_o[0], color_o[1], color_o[2], sem_n);
+            o[5] = u2f((uint32_t)bestID);
+            o[6] = initTime_o;
+            o[7] = time;
+            rot3(pose, normRad_o[0], normRad_o[1], normRad_o[2], n3);
+            normalize3(n3);
+            o[8] = n3[0]; o[9] = n3[1]; o[10] = n3[2];
+            o[11] = normRad_o[3];
+        }
+    } else {                                              /* data.vert:210-225 */
+        xform(pose, vPosLocal[0], vPosLocal[1], vPosLocal[2], t4);
+        o[0] = t4[0]; o[1] = t4[1]; o[2] = t4[2]; o[3] = c_n;
+        rot3(pose, vNormLocal[0], vNormLocal[1], vNormLocal[2], n3);
+        normalize3(n3);
+        o[8] = n3[0]; o[9] = n3[1]; o[10] = n3[2]; o[11] = radii_n;
+        o[4] = smo_encode_color(color_n[0], color_n[1], color_n[2], sem_n);
+        o[5] = -1.0f;
+        o[6] = time;
+        o[7] = time;
+    }
+    return updateCounter > 0 ? 2 : 1;
+}
+
 /* GlobalModel::dataAssociate (src/GlobalModel.cpp:246-346), data.vert:59-234, data.geom:32-45 */
 int smo_stage_data_associate(smo_ctx *s, const float *pose, int time_i, float depth_min,
                              float depth_max)
 {
     const smo_config *c = &s->c;
     int W = c->width, H = c->height;
-    float camz = (float)(1.0 / (double)c->fx), camw = (float)(1.0 / (double)c->fy);
     float time = (float)time_i;                   /* src/GlobalModel.cpp:271 */
-    float fuseThresh = c->fuse_thresh;            /* src/GlobalModel.cpp:284 */
-    const float *D = s->depth_metric;
     uint32_t n = 0, nf = 0;
-    for (int i = 0; i < W; ++i) {                 /* x-outer, y-inner: src/GlobalModel.cpp:67-74 */
+#ifdef _OPENMP
+    /* records are emitted in x-outer / y-inner order: count per column first (into a scratch record), then every column
+     * writes at its offset */
+    if (!s->omp_col) { s->omp_col = malloc(((size_t)W + 1) * 4); if (!s->omp_col) abort(); }
+#pragma omp parallel for schedule(dynamic, 8)
+    for (int i = 0; i < W; ++i) {
+        float tmp[SURFEL_F];
+        uint32_t cnt = 0;
+        for (int j = 0; j < H; ++j) cnt += associate_one(s, pose, time, depth_min, depth_max, i, j, tmp) != 0;
+        s->omp_col[i] = cnt;
+    }
+    for (int i = 0; i < W; ++i) { const uint32_t x = s->omp_col[i]; s->omp_col[i] = n; n += x; }
+#pragma omp parallel for schedule(dynamic, 8) reduction(+ : nf)
+    for (int i = 0; i < W; ++i) {
+        uint32_t w = s->omp_col[i];
         for (int j = 0; j < H; ++j) {
-            float x = s->xs[i], y = s->ys[j];
-            float xl = (x - c->cx) * camz;
-            float yl = (y - c->cy) * camw;
-            float ray[3] = {xl, yl, 1.0f};
-            float lambda = sqrtf((xl * xl + yl * yl) + 1.0f);
-            int ci = s->ixc[i], cj = s->iyc[j];
-            float value = D[(size_t)cj * W + ci];
-            /* checkNeighbours data.vert:33-52 */
-            if (D[(size_t)cj * W + s->ixm[i]] == 0.0f) continue;
-            if (D[(size_t)s->iym[j] * W + ci] == 0.0f) continue;
-            if (D[(size_t)cj * W + s->ixp[i]] == 0.0f) continue;
-            if (D[(size_t)s->iyp[j] * W + ci] == 0.0f) continue;
-            if (!(value > depth_min && value < depth_max)) continue;
-            if (((int)x + (int)y) % 2 != 1) continue;
-
-            float vPosLocal[3];
-            get_vertex(s, ci, cj, x, y, vPosLocal);
-            /* getNormal geometry.glsl:12-24 */
-            float xf[3], xb[3], yf[3], yb[3], del_x[3], del_y[3], vNormLocal[3];
-            get_vertex(s, s->ixp[i], cj, x + 1.0f, y, xf);
-            get_vertex(s, s->ixm[i], cj, x - 1.0f, y, xb);
-            get_vertex(s, ci, s->iyp[j], x, y + 1.0f, yf);
-            get_vertex(s, ci, s->iym[j], x, y - 1.0f, yb);
-            for (int q = 0; q < 3; ++q) { del_x[q] = xb[q] - xf[q]; del_y[q] = yb[q] - yf[q]; }
-            cross3(del_x, del_y, vNormLocal);
-            normalize3(vNormLocal);
-
-            float c_n = 0.9f;                     /* data.vert:104 */
-            size_t p = (size_t)cj * W + ci;
-            float color_n[3] = {s->rgb[p * 3], s->rgb[p * 3 + 1], s->rgb[p * 3 + 2]};
-            float radii_n = smo_get_radius(vPosLocal[2], vNormLocal[2], camz, camw);
-            uint32_t sem_n = s->sem[p];
-
-            int updateCounter = 0;
-            int bestID = 0;
-            float bestDist = 1000.0f;
-            float posLocal_o[3] = {0, 0, 0}, c_o = 0.0f, normRad_o[4] = {0, 0, 0, 0};
-            float color_o[3] = {0, 0, 0}, initTime_o = 0.0f;
-
-            /* window loop data.vert:126-172 with scale == IndexMap::FACTOR == 1: one lookup */
-            int currentID = s->idx[p];
-            /* data.vert:142 `currentID > 0`: a projection exists and it is not surfel 0 (the index
-             * texture is cleared to 0, A5); written via the depth buffer so that shard tests can
-             * move the exempt id */
-            if (s->zbuf[p] != 16777215u && currentID != s->exempt_id) {
-                const float *vertConf = s->ivc + p * 4;
-                const float *colorTime = s->ict + p * 4;
-                uint32_t sc = f2u(colorTime[0]);
-                uint32_t sem_o = (sc >> 24) & 0xFFu;
-                if (sem_n == sem_o &&
-                    fabsf(vertConf[2] * lambda - vPosLocal[2] * lambda) <= fuseThresh) {
-                    float cr[3];
-                    cross3(ray, vertConf, cr);
-                    float dist = fdiv(sqrtf(dot3(cr, cr)), sqrtf(dot3(ray, ray)));
-                    const float *normRad = s->inr + p * 4;
-                    float ang = smo_acosf(fdiv(dot3(normRad, vNormLocal),
-                                               sqrtf(dot3(normRad, normRad)) *
-                                               sqrtf(dot3(vNormLocal, vNormLocal))));
-                    if (dist < bestDist && fabsf(ang) < 0.5f) {
-                        updateCounter++;
-                        bestDist = dist;
-                        bestID = currentID;
-                        memcpy(posLocal_o, vertConf, 12);
-                        c_o = vertConf[3];
-                        memcpy(normRad_o, normRad, 16);
-                        color_o[0] = (float)((sc >> 16) & 0xFFu) / 255.0f;
-                        color_o[1] = (float)((sc >> 8) & 0xFFu) / 255.0f;
-                        color_o[2] = (float)(sc & 0xFFu) / 255.0f;
-                        initTime_o = colorTime[2];
-                    }
-                }
-            }
-
-            float *o = s->data + (size_t)n * SURFEL_F;
-            s->data_pix[n] = i * H + j;
-            float t4[4], n3[3];
-            if (updateCounter > 0) {
-                nf++;
-                if (radii_n < 1.5f * normRad_o[3]) {              /* data.vert:177-194 */
-                    float w = c_n + c_o;
-                    float pn[3];
-                    for (int q = 0; q < 3; ++q)
-                        pn[q] = fdiv((c_n * vPosLocal[q]) + (c_o * posLocal_o[q]), w);
-                    xform(pose, pn[0], pn[1], pn[2], t4);
-                    o[0] = t4[0]; o[1] = t4[1]; o[2] = t4[2]; o[3] = w;
-                    float avg[3];
-                    for (int q = 0; q < 3; ++q)
-                        avg[q] = fdiv((c_n * color_n[q]) + (c_o * color_n[q]), w);   /* sic :183 */
-                    o[4] = smo_encode_color(avg[0], avg[1], avg[2], sem_n);
-                    o[5] = u2f((uint32_t)bestID);
-                    o[6] = initTime_o;
-                    o[7] = time;
-                    float nr[4];
-                    nr[0] = fdiv((c_n * vNormLocal[0]) + (c_o * normRad_o[0]), w);
-                    nr[1] = fdiv((c_n * vNormLocal[1]) + (c_o * normRad_o[1]), w);
-                    nr[2] = fdiv((c_n * vNormLocal[2]) + (c_o * normRad_o[2]), w);
-                    rot3(pose, nr[0], nr[1], nr[2], n3);
-                    normalize3(n3);
-                    o[8] = n3[0]; o[9] = n3[1]; o[10] = n3[2];
-                    o[11] = (radii_n > normRad_o[3]) ? normRad_o[3] : radii_n;
-                } else {                                          /* data.vert:195-208 */
-                    xform(pose, posLocal_o[0], posLocal_o[1], posLocal_o[2], t4);
-                    o[0] = t4[0]; o[1] = t4[1]; o[2] = t4[2]; o[3] = c_n + c_o;
-                    o[4] = smo_encode_color(color_o[0], color_o[1], color_o[2], sem_n);
-                    o[5] = u2f((uint32_t)bestID);
-                    o[6] = initTime_o;
-                    o[7] = time;
-                    rot3(pose, normRad_o[0], normRad_o[1], normRad_o[2], n3);
-                    normalize3(n3);
-                    o[8] = n3[0]; o[9] = n3[1]; o[10] = n3[2];
-                    o[11] = normRad_o[3];
-                }
-            } else {                                              /* data.vert:210-225 */
-                xform(pose, vPosLocal[0], vPosLocal[1], vPosLocal[2], t4);
-                o[0] = t4[0]; o[1] = t4[1]; o[2] = t4[2]; o[3] = c_n;
-                rot3(pose, vNormLocal[0], vNormLocal[1], vNormLocal[2], n3);
-                normalize3(n3);
-                o[8] = n3[0]; o[9] = n3[1]; o[10] = n3[2]; o[11] = radii_n;
-                o[4] = smo_encode_color(color_n[0], color_n[1], color_n[2], sem_n);
-                o[5] = -1.0f;
-                o[6] = time;
-                o[7] = time;
-            }
-            n++;
+            const int r = associate_one(s, pose, time, depth_min, depth_max, i, j, s->data + (size_t)w * SURFEL_F);
+            if (r) { s->data_pix[w] = i * H + j; w++; nf += r == 2; }
         }
     }
+#else
+    for (int i = 0; i < W; ++i) {                 /* x-outer, y-inner: src/GlobalModel.cpp:67-74 */
+        for (int j = 0; j < H; ++j) {
+            const int r = associate_one(s, pose, time, depth_min, depth_max, i, j, s->data + (size_t)n * SURFEL_F);
+            if (r) { s->data_pix[n] = i * H + j; n++; nf += r == 2; }
+        }
+    }
+#endif
     s->data_count = n;
     s->fused_count = nf;
     return SMO_OK;
@@ -834,6 +1011,9 @@ int smo_stage_data_associate(smo_ctx *s, const float *pose, int time_i, float de
 /* GlobalModel::updateFuse (src/GlobalModel.cpp:348-394), fuse.vert:17-49 */
 int smo_stage_update_fuse(smo_ctx *s)
 {
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)      /* at most one record per surfel id */
+#endif
     for (uint32_t q = 0; q < s->data_count; ++q) {
         const float *d = s->data + (size_t)q * SURFEL_F;
         int32_t mark = (int32_t)f2u(d[5]);
@@ -851,6 +1031,41 @@ int smo_stage_update_fuse(smo_ctx *s)
 int smo_stage_concatenate(smo_ctx *s)
 {
     uint32_t n = 0;
+#ifdef _OPENMP
+    {   /* ordered compaction in parallel, as in smo_stage_back_mapping */
+        enum { MAXT = 256 };
+        uint32_t cnt[MAXT + 1];
+        int nt = omp_get_max_threads();
+        if (nt > MAXT) nt = MAXT;
+        const uint32_t N = s->data_count, per = (N + (uint32_t)nt - 1) / (uint32_t)nt;
+#pragma omp parallel num_threads(nt)
+        {
+            const int t = omp_get_thread_num();
+            const uint32_t q0 = (uint32_t)t * per < N ? (uint32_t)t * per : N, q1 = q0 + per < N ? q0 + per : N;
+            uint32_t c = 0;
+            for (uint32_t q = q0; q < q1; ++q) c += (int)roundf(s->data[(size_t)q * SURFEL_F + 5]) < 0;
+            cnt[t] = c;
+#pragma omp barrier
+#pragma omp single
+            {
+                uint32_t run = 0;
+                for (int x = 0; x < nt; ++x) { const uint32_t y = cnt[x]; cnt[x] = run; run += y; }
+                cnt[nt] = run;
+            }
+            uint32_t w = cnt[t];
+            for (uint32_t q = q0; q < q1; ++q) {
+                const float *d = s->data + (size_t)q * SURFEL_F;
+                if ((int)roundf(d[5]) < 0) {
+                    float *o = s->unstable + (size_t)w * SURFEL_F;
+                    memcpy(o, d, SURFEL_F * 4);
+                    o[5] = 0.0f;
+                    w++;
+                }
+            }
+        }
+        n = cnt[nt];
+    }
+#else
     for (uint32_t q = 0; q < s->data_count; ++q) {
         const float *d = s->data + (size_t)q * SURFEL_F;
         int mark = (int)roundf(d[5]);
@@ -861,6 +1076,7 @@ int smo_stage_concatenate(smo_ctx *s)
             n++;
         }
     }
+#endif
     s->unstable_count = n;
     /* A13: the reference does not check; the oracle reports the overflow instead of
      * reproducing undefined GL state. */

@@ -58,7 +58,9 @@ class SmTimings(C.Structure):
         "preprocess", "conflict", "index_map", "data_association", "concatenate", "run",
         "k_prep", "k_conflict", "k_scan_cull", "k_compact", "k_associate", "k_scan_new",
         "k_append")] + [("frames", C.c_uint32), ("event_overhead", C.c_float), ("k_compact_own", C.c_float),
-                        ("k_cull_lazy", C.c_float), ("frames_compact", C.c_uint32)]
+                        ("k_cull_lazy", C.c_float), ("frames_compact", C.c_uint32)] + [(n, C.c_float) for n in (
+        "k_surfel_pass", "k_pass_fixup", "k_conflict_own", "k_associate_direct", "k_associate_own", "k_append_own")] + [
+        ("frames_one_pass", C.c_uint32), ("frames_direct", C.c_uint32)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

@@ -193,6 +193,7 @@ struct sm_ctx {
     bool fix_part_live = false;        // the next append also folds d_fix_part in (when the cap bound)
     uint32_t n_fix_part = 0;           // worker workgroups of the last k_pass_fixup
     bool ev_one_pass[EV_RING] = {};    // which frames of the event ring ran the one-pass kernels
+    bool ev_direct[EV_RING] = {};      // ... and appended directly
     // tile skip flags of the frame, evaluated by extra workgroups of k_prep (when k_prep runs after the previous frame: no second stream)
     uint2 *d_prep_part = nullptr;
     uint32_t n_prep_blocks = 0;        // flag workgroups the frame's k_prep ran (0: the pass kernel evaluates the flags itself)
@@ -863,6 +864,7 @@ int enqueue_frame(sm_ctx *s, const uint8_t *d_rgb, const uint16_t *d_raw, const 
     if (s->ev_ok) s->ev_one_pass[s->ev_frames % EV_RING] = one_pass;
     // ... and the association appends the new surfels directly (no append kernel) when k_prep ran after the previous frame
     const bool direct = one_pass && s->direct && s->n_prep_blocks != 0;
+    if (s->ev_ok) s->ev_direct[s->ev_frames % EV_RING] = direct;
     if (one_pass) {
         if ((rc = launch_surfel_pass(s, fp, true, direct))) return rc;      // :178-197
         if (direct) {
@@ -1521,7 +1523,8 @@ int sm_stage_timings(sm_ctx *s, sm_timings *out)
     uint64_t first = s->ev_read;
     if (s->ev_frames - first > EV_RING) first = s->ev_frames - EV_RING;
     double seg[7] = {0}, run = 0, ovh = 0, cull[2] = {0, 0};
-    uint32_t nfr = 0, ncls[2] = {0, 0};
+    double own[6] = {0};          // pass, fixup (one-pass frames) | conflict (others) | associate (direct) | associate, append (others)
+    uint32_t nfr = 0, ncls[2] = {0, 0}, n_op = 0, n_dir = 0;
     for (uint64_t f = first; f < s->ev_frames; ++f) {
         const int slot = (int)(f % EV_RING);
         float ms = 0;
@@ -1538,6 +1541,8 @@ int sm_stage_timings(sm_ctx *s, sm_timings *out)
         for (int k = 0; k < 7; ++k) seg[k] += loc[k];
         cull[s->ev_compacted[slot] ? 1 : 0] += loc[3];
         ncls[s->ev_compacted[slot] ? 1 : 0]++;
+        if (s->ev_one_pass[slot]) { own[0] += loc[1]; own[1] += loc[3]; n_op++; } else own[2] += loc[1];
+        if (s->ev_direct[slot]) { own[3] += loc[4]; n_dir++; } else { own[4] += loc[4]; own[5] += loc[6]; }
         run += ms;
         ovh += o;
         nfr++;
@@ -1557,6 +1562,10 @@ int sm_stage_timings(sm_ctx *s, sm_timings *out)
         out->k_cull_lazy = ncls[0] ? (float)std::max(0.0, cull[0] / ncls[0] - oh) : 0.0f;
         out->k_compact_own = ncls[1] ? (float)std::max(0.0, cull[1] / ncls[1] - oh) : 0.0f;
         out->frames_compact = ncls[1];
+        auto avg = [&](double sum, uint32_t n) { return n ? (float)std::max(0.0, sum / n - oh) : 0.0f; };
+        out->k_surfel_pass = avg(own[0], n_op); out->k_pass_fixup = avg(own[1], n_op); out->k_conflict_own = avg(own[2], nfr - n_op);
+        out->k_associate_direct = avg(own[3], n_dir); out->k_associate_own = avg(own[4], nfr - n_dir); out->k_append_own = avg(own[5], nfr - n_dir);
+        out->frames_one_pass = n_op; out->frames_direct = n_dir;
         out->preprocess = out->k_prep;
         out->conflict = out->k_conflict + out->k_scan_cull + out->k_compact;
         out->index_map = 0.0f;

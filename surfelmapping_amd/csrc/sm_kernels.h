@@ -2221,7 +2221,10 @@ __global__ __launch_bounds__(PIX_BLOCK) void k_associate_direct(Model M, DevStat
                                                                 unsigned long long *__restrict__ host_stat)
 {
     __shared__ uint32_t s_v[4], s_n[4], s_f[4];
+    __shared__ uint32_t s_hole[12], s_dead[2];          // empty slots of this block: 6 alive words (lo, hi), 2 tiles
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x < 12) s_hole[threadIdx.x] = 0u;
+    if (threadIdx.x < 2) s_dead[threadIdx.x] = 0u;
     // candidates before this block = the groups before its group + the blocks of its group before it: a few loads per lane,
     // issued together with DevState, one wave reduction (every wave computes it for itself)
     const uint32_t grp = blockIdx.x / CAND_GROUP, in_grp = blockIdx.x % CAND_GROUP;
@@ -2265,9 +2268,25 @@ __global__ __launch_bounds__(PIX_BLOCK) void k_associate_direct(Model M, DevStat
     float3 pw = make_float3(0.f, 0.f, 0.f);
     if (wr) pw = write_new_surfel(cur, slot, L, fp);
     bounds_expand_wave(tb, wr, slot / (uint32_t)TILE, pw.x, pw.y, pw.z, (float)fp.time, false);
-    if (is_fused && room) {                                               // the slot this pixel owned stays empty
-        atomicAnd((unsigned long long *)&alive[slot >> 6], ~(1ull << (slot & 63u)));
-        atomicAdd(&tile_dead[slot / (uint32_t)TILE], 1u);
+    // The slot of a pixel that fused stays empty.  The block's <= 256 candidate slots are consecutive, i.e. they touch
+    // <= 5 alive words and <= 2 tiles: collected in LDS, then one global atomic per word / tile (a global atomic per
+    // fused pixel cost 300 us on a frame with 100 k fuses: memory-side atomics on one line serialise).
+    const uint32_t blk_first = offset + pre, w_first = blk_first >> 6, t_first = blk_first / (uint32_t)TILE;
+    const uint32_t nfused_blk = s_f[0] + s_f[1] + s_f[2] + s_f[3];        // workgroup-uniform
+    if (nfused_blk) {
+        if (is_fused && room) {
+            const uint32_t w = (slot >> 6) - w_first, bit = slot & 63u;
+            atomicOr(&s_hole[w * 2u + (bit >> 5)], 1u << (bit & 31u));
+            atomicAdd(&s_dead[slot / (uint32_t)TILE - t_first], 1u);
+        }
+        __syncthreads();
+        if (threadIdx.x < 6) {
+            const uint64_t m = (uint64_t)s_hole[threadIdx.x * 2u] | ((uint64_t)s_hole[threadIdx.x * 2u + 1u] << 32);
+            if (m) atomicAnd((unsigned long long *)&alive[w_first + threadIdx.x], ~m);
+        } else if (threadIdx.x < 8) {
+            const uint32_t d = s_dead[threadIdx.x - 6u];
+            if (d) atomicAdd(&tile_dead[t_first + threadIdx.x - 6u], d);
+        }
     }
     if (is_valid && !room) st->error = -2;
 }

@@ -46,14 +46,18 @@ def build(force: bool = False) -> str:
     return LIB_PATH
 
 
-_lib = None
+OMP_LIB_PATH = os.path.join(ORACLE_DIR, "libsmo_omp.so")     # all-core build of the same source (bit-identical results)
+_libs = {}
 
 
-def lib():
-    global _lib
-    if _lib is None:
+def lib(path=None):
+    """The oracle library (default: the serial contract build); `path` selects another build of oracle/smo.c."""
+    path = path or LIB_PATH
+    if path not in _libs:
         build()
-        L = C.CDLL(LIB_PATH)
+        if not os.path.exists(path):
+            subprocess.check_call(["make", "-C", ORACLE_DIR, "-s", os.path.basename(path)])
+        L = C.CDLL(path)
         fp = C.POINTER(C.c_float)
         L.smo_create.restype = C.c_void_p
         L.smo_create.argtypes = [C.POINTER(SmoConfig)]
@@ -101,8 +105,8 @@ def lib():
         L.smo_render_image.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_float] * 4 + [C.c_void_p] * 2
         L.smo_invert4.argtypes = [fp, fp]
         L.smo_mul4.argtypes = [fp, fp, fp]
-        _lib = L
-    return _lib
+        _libs[path] = L
+    return _libs[path]
 
 
 def _ptr(a):
@@ -127,17 +131,18 @@ def make_config(width, height, fx, fy, cx, cy, **over) -> SmoConfig:
 class Oracle:
     """Thin object wrapper with the same method names as the product binding."""
 
-    def __init__(self, cfg: SmoConfig):
+    def __init__(self, cfg: SmoConfig, libpath=None):
         self.cfg = cfg
         self.W, self.H = cfg.width, cfg.height
         self.P = self.W * self.H
-        self._h = lib().smo_create(C.byref(cfg))
+        self._L = lib(libpath)
+        self._h = self._L.smo_create(C.byref(cfg))
         if not self._h:
             raise RuntimeError("smo_create failed")
 
     def close(self):
         if self._h:
-            lib().smo_destroy(self._h)
+            self._L.smo_destroy(self._h)
             self._h = None
 
     def __del__(self):
@@ -152,7 +157,7 @@ class Oracle:
         depth = np.ascontiguousarray(depth, np.uint16)
         sem = np.ascontiguousarray(sem, np.uint8)
         pose = np.ascontiguousarray(pose, np.float32)
-        rc = lib().smo_process_frame(self._h, _ptr(rgb), _ptr(depth), _ptr(sem), _ptr(pose))
+        rc = self._L.smo_process_frame(self._h, _ptr(rgb), _ptr(depth), _ptr(sem), _ptr(pose))
         if rc not in allow:
             _chk(rc, "process_frame")
         return rc
@@ -161,26 +166,26 @@ class Oracle:
         depth = np.ascontiguousarray(depth, np.uint16)
         sem = np.ascontiguousarray(sem, np.uint8)
         pose = np.ascontiguousarray(pose, np.float32)
-        _chk(lib().smo_clean_points(self._h, _ptr(depth), _ptr(sem), _ptr(pose)), "clean_points")
+        _chk(self._L.smo_clean_points(self._h, _ptr(depth), _ptr(sem), _ptr(pose)), "clean_points")
 
     def reset(self):
-        _chk(lib().smo_reset(self._h), "reset")
+        _chk(self._L.smo_reset(self._h), "reset")
 
     def counts(self) -> dict:
         c = SmoCounts()
-        _chk(lib().smo_get_counts(self._h, C.byref(c)), "get_counts")
+        _chk(self._L.smo_get_counts(self._h, C.byref(c)), "get_counts")
         return c.as_dict()
 
     def download_model(self) -> np.ndarray:
         n = C.c_uint32()
-        _chk(lib().smo_download_model(self._h, None, 0, C.byref(n)), "download_model")
+        _chk(self._L.smo_download_model(self._h, None, 0, C.byref(n)), "download_model")
         out = np.zeros((n.value, 12), np.float32)
-        _chk(lib().smo_download_model(self._h, _ptr(out), n.value, C.byref(n)), "download_model")
+        _chk(self._L.smo_download_model(self._h, _ptr(out), n.value, C.byref(n)), "download_model")
         return out
 
     def upload_model(self, m):
         m = np.ascontiguousarray(m, np.float32)
-        _chk(lib().smo_upload_model(self._h, _ptr(m), m.shape[0]), "upload_model")
+        _chk(self._L.smo_upload_model(self._h, _ptr(m), m.shape[0]), "upload_model")
 
     def download_index_map(self):
         P = self.P
@@ -188,26 +193,26 @@ class Oracle:
         vc = np.zeros((P, 4), np.float32)
         ct = np.zeros((P, 4), np.float32)
         nr = np.zeros((P, 4), np.float32)
-        _chk(lib().smo_download_index_map(self._h, _ptr(idx), _ptr(vc), _ptr(ct), _ptr(nr)), "index_map")
+        _chk(self._L.smo_download_index_map(self._h, _ptr(idx), _ptr(vc), _ptr(ct), _ptr(nr)), "index_map")
         return idx, vc, ct, nr
 
     def download_depth(self, which=0):
         out = np.zeros((self.H, self.W), np.float32)
-        _chk(lib().smo_download_depth(self._h, which, _ptr(out)), "download_depth")
+        _chk(self._L.smo_download_depth(self._h, which, _ptr(out)), "download_depth")
         return out
 
     def download_data(self):
         n = C.c_uint32()
-        _chk(lib().smo_download_data(self._h, None, 0, C.byref(n)), "download_data")
+        _chk(self._L.smo_download_data(self._h, None, 0, C.byref(n)), "download_data")
         out = np.zeros((n.value, 12), np.float32)
-        _chk(lib().smo_download_data(self._h, _ptr(out), n.value, C.byref(n)), "download_data")
+        _chk(self._L.smo_download_data(self._h, _ptr(out), n.value, C.byref(n)), "download_data")
         return out
 
     def render_image(self, view, w, h, fx, fy, cx, cy):
         view = np.ascontiguousarray(view, np.float32)
         bgr = np.zeros((h, w, 3), np.uint8)
         sem = np.zeros((h, w), np.uint8)
-        _chk(lib().smo_render_image(self._h, _ptr(view), w, h, fx, fy, cx, cy, _ptr(bgr), _ptr(sem)), "render_image")
+        _chk(self._L.smo_render_image(self._h, _ptr(view), w, h, fx, fy, cx, cy, _ptr(bgr), _ptr(sem)), "render_image")
         return bgr, sem
 
     # -- stage level
@@ -215,39 +220,39 @@ class Oracle:
         rgb = None if rgb is None else np.ascontiguousarray(rgb, np.uint8)
         dm = None if depth_metric is None else np.ascontiguousarray(depth_metric, np.float32)
         sem = None if sem is None else np.ascontiguousarray(sem, np.uint8)
-        _chk(lib().smo_set_frame(self._h, _ptr(rgb), _ptr(dm), _ptr(sem)), "set_frame")
+        _chk(self._L.smo_set_frame(self._h, _ptr(rgb), _ptr(dm), _ptr(sem)), "set_frame")
 
     def set_tick(self, tick):
-        _chk(lib().smo_set_tick(self._h, tick), "set_tick")
+        _chk(self._L.smo_set_tick(self._h, tick), "set_tick")
 
     def stage_process_conflict(self, pose, min_depth, max_depth, fuse_thresh=0.0, is_clean=0):
         pose = np.ascontiguousarray(pose, np.float32)
-        _chk(lib().smo_stage_process_conflict(self._h, _ptr(pose), min_depth, max_depth,
+        _chk(self._L.smo_stage_process_conflict(self._h, _ptr(pose), min_depth, max_depth,
                                               fuse_thresh, is_clean), "process_conflict")
 
     def stage_update_conflict(self):
-        _chk(lib().smo_stage_update_conflict(self._h), "update_conflict")
+        _chk(self._L.smo_stage_update_conflict(self._h), "update_conflict")
 
     def stage_back_mapping(self):
-        _chk(lib().smo_stage_back_mapping(self._h), "back_mapping")
+        _chk(self._L.smo_stage_back_mapping(self._h), "back_mapping")
 
     def stage_build_model_map(self):
-        _chk(lib().smo_stage_build_model_map(self._h), "build_model_map")
+        _chk(self._L.smo_stage_build_model_map(self._h), "build_model_map")
 
     def stage_predict_indices(self, pose, time, depth_cutoff, time_delta):
         pose = np.ascontiguousarray(pose, np.float32)
-        _chk(lib().smo_stage_predict_indices(self._h, _ptr(pose), time, depth_cutoff, time_delta),
+        _chk(self._L.smo_stage_predict_indices(self._h, _ptr(pose), time, depth_cutoff, time_delta),
              "predict_indices")
 
     def stage_data_associate(self, pose, time, dmin, dmax):
         pose = np.ascontiguousarray(pose, np.float32)
-        _chk(lib().smo_stage_data_associate(self._h, _ptr(pose), time, dmin, dmax), "data_associate")
+        _chk(self._L.smo_stage_data_associate(self._h, _ptr(pose), time, dmin, dmax), "data_associate")
 
     def stage_update_fuse(self):
-        _chk(lib().smo_stage_update_fuse(self._h), "update_fuse")
+        _chk(self._L.smo_stage_update_fuse(self._h), "update_fuse")
 
     def stage_concatenate(self, allow=(0,)):
-        rc = lib().smo_stage_concatenate(self._h)
+        rc = self._L.smo_stage_concatenate(self._h)
         if rc not in allow:
             _chk(rc, "concatenate")
         return rc

@@ -23,6 +23,47 @@ import os
 import re
 
 
+# FETCH_SIZE / WRITE_SIZE -> bytes on the memory fabric.  tools/calib_fetch.hip measured (profiles/fetch_calibration.json,
+# MI355X, ROCm 7.2): FETCH_SIZE reports exactly 1/2 of the bytes of a coalesced streaming read at 4, 8 AND 16 bytes per
+# lane (factor 2.000 each), and 64 B per random 8-byte gather (i.e., by the same 1/2 rule, one 128-byte line per gather);
+# WRITE_SIZE is exact for coalesced stores at 4, 8 and 16 bytes per lane and counts 32 B per random 64-bit atomic.  So
+# one factor per counter serves every kernel here -- the load width does not matter -- and a kernel that gathers shows
+# its line over-fetch as real traffic, which is what the comparison with the algorithmic bytes is for.
+def calibrate(cdir, out):
+    """--calibrate: factors from a tools/calib_fetch run profiled with --pmc FETCH_SIZE (cdir/fetch) and WRITE_SIZE (cdir/write)."""
+    known = {"k_calib_r4": 2 ** 30, "k_calib_r8": 2 ** 30, "k_calib_r16": 2 ** 30, "k_calib_g8": 8 * 2 ** 27,
+             "k_calib_w4": 2 ** 30, "k_calib_w8": 2 ** 30, "k_calib_w16": 2 ** 30, "k_calib_a8": 8 * 2 ** 26}
+    res = {"known_bytes": known, "fetch": {}, "write": {}, "note": "factor = bytes the kernel moves / (counter x 1024); a8 / g8: per byte of lane data"}
+    for sub, ctr in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+        f = glob.glob(os.path.join(cdir, sub, "**", "*_counter_collection.csv"), recursive=True)
+        if not f:
+            continue
+        per = collections.defaultdict(list)
+        for r in csv.DictReader(open(f[0])):
+            if r["Counter_Name"] == ctr:
+                m = re.search(r"(k_calib_[a-z0-9]+)", r["Kernel_Name"])
+                if m:
+                    per[m.group(1)].append(float(r["Counter_Value"]) * 1024.0)
+        for k, v in sorted(per.items()):
+            rep = sum(v) / len(v)
+            res[sub][k.replace("k_calib_", "")] = {"reported_bytes": rep, "factor": (known[k] / rep) if rep > 0 else None, "launches": len(v),
+                                                   "spread": (max(v) - min(v)) / rep if rep > 0 else None}
+    json.dump(res, open(out, "w"), indent=1)
+    for sub in ("fetch", "write"):
+        for k, v in res[sub].items():
+            print(f"{sub:6s} {k:5s} reported {v['reported_bytes'] / 1e6:10.1f} MB  factor {v['factor']}")
+
+
+def counter_factor(cal, kind, default):
+    """mean of the calibrated factors of the coalesced shapes of this counter (fetch: r4 r8 r16, write: w4 w8 w16)"""
+    if not cal:
+        return default
+    shapes = ("r4", "r8", "r16") if kind == "fetch" else ("w4", "w8", "w16")
+    f = [(cal.get(kind, {}).get(x) or {}).get("factor") for x in shapes]
+    f = [x for x in f if x]
+    return sum(f) / len(f) if f else default
+
+
 def short(name):
     m = re.search(r"(k_[a-z_]+)", name)
     return m.group(1) if m else name[:40]
@@ -31,6 +72,8 @@ def short(name):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("dir")
+    ap.add_argument("--calibrate", action="store_true", help="dir holds fetch/ and write/ profiles of tools/calib_fetch: write the factor table to --out")
+    ap.add_argument("--calibration", default=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "fetch_calibration.json"))
     ap.add_argument("--last", type=int, default=0)
     ap.add_argument("--out", default=None)
     ap.add_argument("--steps", type=int, default=None, help="recorded in the json (bench.py --steps of the profiled command)")
@@ -39,6 +82,9 @@ def main():
     ap.add_argument("--simds", type=int, default=1024, help="SIMDs of the device (MI355X: 256 CUs x 4)")
     ap.add_argument("--mhz", type=float, default=2400.0, help="shader clock used to turn durations into cycles")
     a = ap.parse_args()
+    if a.calibrate:
+        return calibrate(a.dir, a.out or a.calibration)
+    cal = json.load(open(a.calibration)) if os.path.exists(a.calibration) else None
     res = collections.defaultdict(dict)
 
     def window(per):
@@ -58,7 +104,7 @@ def main():
         for k, d in window(per).items():
             if d:
                 res[k].update(calls=len(per[k]), averaged=len(d), avg_us=sum(d) / len(d) / 1e3, min_us=min(d) / 1e3, max_us=max(d) / 1e3)
-    for sub, ctr, mult in (("pmc_fetch", "FETCH_SIZE", 2.0), ("pmc_write", "WRITE_SIZE", 1.0)):
+    for sub, ctr, mult, kind in (("pmc_fetch", "FETCH_SIZE", 2.0, "fetch"), ("pmc_write", "WRITE_SIZE", 1.0, "write")):
         f = glob.glob(os.path.join(a.dir, sub, "*", "*_counter_collection.csv"))
         if not f:
             continue
@@ -70,7 +116,9 @@ def main():
             v.sort()
         for k, d in window(per).items():
             if d:
-                res[k][ctr + "_bytes_per_launch"] = sum(d) / len(d) * 1024.0 * mult
+                fac = counter_factor(cal, kind, mult)
+                res[k][ctr + "_bytes_per_launch"] = sum(d) / len(d) * 1024.0 * fac
+                res[k][ctr + "_factor"] = fac
     f = glob.glob(os.path.join(a.dir, "pmc_sq", "*", "*_counter_collection.csv"))
     if f:
         # SQ counters are quad-cycles (MI355X_MICROARCH.md): a wave64 VALU instruction occupies its SIMD for 4 cycles,
