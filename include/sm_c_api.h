@@ -166,6 +166,13 @@ int sm_load_map(sm_ctx *s, const char *path, int32_t *start_id, int32_t *end_id)
  * reference's textures only while the model has not changed since. */
 int sm_download_index_map(sm_ctx *s, int32_t *id, float *vert_conf4, float *color_time4,
                           float *norm_rad4);
+/* FeedbackBuffer "RAW" (SurfelMapping::getFeedbackBuffer(FeedbackBuffer::RAW), src/SurfelMapping.cpp:367-376,
+ * src/FeedbackBuffer.cpp:85-145, surfel_feedback.vert:25-63): the raw surfel cloud of the last processed frame -- every
+ * checkerboard pixel with 0 < z < farClip as a camera-frame surfel, 12 floats each (pos, 0.9 | colour bits, 0, time, time |
+ * normal, radius), in vertex order (x-outer / y-inner).  The reference fills it on every frame after the first; it feeds
+ * the GUI's "Draw raw" view (build_map.cpp:177-184) and GlobalModel::initialize after reset().  Computed on demand here.
+ * dst12 may be NULL to query the count. */
+int sm_download_raw_cloud(sm_ctx *s, float *dst12, uint32_t cap, uint32_t *n);
 /* SurfelMapping::getTexture(DEPTH_METRIC / DEPTH_FILTERED / "LAST") read-back, row-major */
 int sm_download_depth(sm_ctx *s, int which, float *dst);
 

@@ -1094,44 +1094,79 @@ int smo_stage_concatenate(smo_ctx *s)
  * checkerboard pixel with 0 < z < maxDepth, NO neighbour test), init_unstable.vert:31-42 moves it to
  * the world frame; it becomes the whole model.  Vertex order: FeedbackBuffer's uvo, x-outer /
  * y-inner (src/FeedbackBuffer.cpp:47-54). */
+/* surfel_feedback.vert:25-63 + surfel_feedback.geom:17-26 for pixel (i, j): the raw camera-frame surfel
+ * (pos, 0.9 | colour, 0, time, time | normal, radius) or nothing (returns 0) */
+static int raw_surfel(const smo_ctx *s, int i, int j, int time_i, float max_depth, float *o)
+{
+    const smo_config *c = &s->c;
+    int W = c->width;
+    float camz = 1.0f / c->fx, camw = 1.0f / c->fy;        /* float division here: src/FeedbackBuffer.cpp:93-96 */
+    float x = s->xs_fb[i], y = s->ys_fb[j];
+    int ci = i, cj = j;
+    float z = s->depth_metric[(size_t)cj * W + ci];
+    if (!(z > 0.0f && z < max_depth)) return 0;
+    if (((int)x + (int)y) % 2 != 1) return 0;
+    float vp[3] = {(x - c->cx) * z * camz, (y - c->cy) * z * camw, z};
+    float xf[3], xb[3], yf[3], yb[3], dx[3], dy[3], nrm[3];
+    float zr = s->depth_metric[(size_t)cj * W + s->ixp[i]], zl = s->depth_metric[(size_t)cj * W + s->ixm[i]];
+    float zd = s->depth_metric[(size_t)s->iyp[j] * W + ci], zu = s->depth_metric[(size_t)s->iym[j] * W + ci];
+    xf[0] = (x + 1.0f - c->cx) * zr * camz; xf[1] = (y - c->cy) * zr * camw; xf[2] = zr;
+    xb[0] = (x - 1.0f - c->cx) * zl * camz; xb[1] = (y - c->cy) * zl * camw; xb[2] = zl;
+    yf[0] = (x - c->cx) * zd * camz; yf[1] = (y + 1.0f - c->cy) * zd * camw; yf[2] = zd;
+    yb[0] = (x - c->cx) * zu * camz; yb[1] = (y - 1.0f - c->cy) * zu * camw; yb[2] = zu;
+    for (int q = 0; q < 3; ++q) { dx[q] = xb[q] - xf[q]; dy[q] = yb[q] - yf[q]; }
+    cross3(dx, dy, nrm);
+    normalize3(nrm);
+    float radius = smo_get_radius(vp[2], nrm[2], camz, camw);
+    size_t p = (size_t)cj * W + ci;
+    o[0] = vp[0]; o[1] = vp[1]; o[2] = vp[2]; o[3] = 0.9f;           /* surfel_feedback.vert:96 */
+    o[4] = smo_encode_color(s->rgb[p * 3], s->rgb[p * 3 + 1], s->rgb[p * 3 + 2], s->sem[p]);
+    o[5] = 0.0f;
+    o[6] = (float)time_i; o[7] = (float)time_i;
+    o[8] = nrm[0]; o[9] = nrm[1]; o[10] = nrm[2]; o[11] = radius;
+    return 1;
+}
+
+/* FeedbackBuffer::compute (src/FeedbackBuffer.cpp:85-145): the raw cloud of the current textures, vertex order x-outer /
+ * y-inner (src/FeedbackBuffer.cpp:47-54).  dst may be NULL to query the count. */
+int smo_raw_cloud(const smo_ctx *s, int time_i, float *dst, uint32_t cap, uint32_t *n)
+{
+    if (!s || !n) return SMO_E_ARG;
+    int W = s->c.width, H = s->c.height;
+    uint32_t cnt = 0;
+    float o[SURFEL_F];
+    for (int i = 0; i < W; ++i)
+        for (int j = 0; j < H; ++j)
+            if (raw_surfel(s, i, j, time_i, s->c.far_clip, o)) {
+                if (dst) {
+                    if (cnt >= cap) return SMO_E_CAPACITY;
+                    memcpy(dst + (size_t)cnt * SURFEL_F, o, SURFEL_F * 4);
+                }
+                cnt++;
+            }
+    *n = cnt;
+    return SMO_OK;
+}
+
 int smo_stage_initialize(smo_ctx *s, const float *pose, int time_i, float max_depth)
 {
     const smo_config *c = &s->c;
     int W = c->width, H = c->height;
-    float camz = 1.0f / c->fx, camw = 1.0f / c->fy;        /* float division here: src/FeedbackBuffer.cpp:93-96 */
     uint32_t n = 0;
     for (int i = 0; i < W; ++i)
         for (int j = 0; j < H; ++j) {
-            float x = s->xs_fb[i], y = s->ys_fb[j];
-            int ci = i, cj = j;
-            float z = s->depth_metric[(size_t)cj * W + ci];
-            if (!(z > 0.0f && z < max_depth)) continue;
-            if (((int)x + (int)y) % 2 != 1) continue;
-            float vp[3] = {(x - c->cx) * z * camz, (y - c->cy) * z * camw, z};
-            float xf[3], xb[3], yf[3], yb[3], dx[3], dy[3], nrm[3];
-            float zr = s->depth_metric[(size_t)cj * W + s->ixp[i]], zl = s->depth_metric[(size_t)cj * W + s->ixm[i]];
-            float zd = s->depth_metric[(size_t)s->iyp[j] * W + ci], zu = s->depth_metric[(size_t)s->iym[j] * W + ci];
-            xf[0] = (x + 1.0f - c->cx) * zr * camz; xf[1] = (y - c->cy) * zr * camw; xf[2] = zr;
-            xb[0] = (x - 1.0f - c->cx) * zl * camz; xb[1] = (y - c->cy) * zl * camw; xb[2] = zl;
-            yf[0] = (x - c->cx) * zd * camz; yf[1] = (y + 1.0f - c->cy) * zd * camw; yf[2] = zd;
-            yb[0] = (x - c->cx) * zu * camz; yb[1] = (y - 1.0f - c->cy) * zu * camw; yb[2] = zu;
-            for (int q = 0; q < 3; ++q) { dx[q] = xb[q] - xf[q]; dy[q] = yb[q] - yf[q]; }
-            cross3(dx, dy, nrm);
-            normalize3(nrm);
-            float radius = smo_get_radius(vp[2], nrm[2], camz, camw);
+            float r[SURFEL_F];
+            if (!raw_surfel(s, i, j, time_i, max_depth, r)) continue;
             if ((uint64_t)n + 1 > max_vertices(s)) return SMO_E_CAPACITY;
             ensure_model(s, n + 1);
             float *o = s->model + (size_t)n * SURFEL_F;
             float t4[4], n3[3];
-            xform(pose, vp[0], vp[1], vp[2], t4);                      /* init_unstable.vert:33-36 */
-            o[0] = t4[0]; o[1] = t4[1]; o[2] = t4[2]; o[3] = 0.9f;     /* surfel_feedback.vert:96 */
-            size_t p = (size_t)cj * W + ci;
-            o[4] = smo_encode_color(s->rgb[p * 3], s->rgb[p * 3 + 1], s->rgb[p * 3 + 2], s->sem[p]);
-            o[5] = 0.0f;
-            o[6] = (float)time_i; o[7] = (float)time_i;
-            rot3(pose, nrm[0], nrm[1], nrm[2], n3);
+            xform(pose, r[0], r[1], r[2], t4);                         /* init_unstable.vert:33-36 */
+            o[0] = t4[0]; o[1] = t4[1]; o[2] = t4[2]; o[3] = r[3];
+            o[4] = r[4]; o[5] = 0.0f; o[6] = r[6]; o[7] = r[7];
+            rot3(pose, r[8], r[9], r[10], n3);
             normalize3(n3);
-            o[8] = n3[0]; o[9] = n3[1]; o[10] = n3[2]; o[11] = radius;
+            o[8] = n3[0]; o[9] = n3[1]; o[10] = n3[2]; o[11] = r[11];
             n++;
         }
     s->count = n;

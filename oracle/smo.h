@@ -100,6 +100,10 @@ int smo_stage_concatenate(smo_ctx *s);                               /* p11 */
 /* computeFeedbackBuffers + GlobalModel::initialize, the tick==0 branch after reset() */
 int smo_stage_initialize(smo_ctx *s, const float *pose, int time, float max_depth);
 
+/* FeedbackBuffer::compute (src/FeedbackBuffer.cpp:85-145, surfel_feedback.vert:25-63): the raw camera-frame cloud of the
+ * textures as they are now, with time stamp `time`; dst12 may be NULL to query the count */
+int smo_raw_cloud(const smo_ctx *s, int time, float *dst12, uint32_t cap, uint32_t *n);
+
 /* GlobalModel::renderImage (src/GlobalModel.cpp:772-833) with draw_image.vert / draw_image_adaptive.geom /
  * draw_image.frag: every surfel as a screen-space disc (two triangles + per-fragment circle test), z-buffered.
  * Outputs: bgr u8[h][w][3] (FragColor = srgb.wzy) and semantic u8[h][w] = class + 1 (0 = nothing drawn).

@@ -21,7 +21,7 @@ SYMBOLS = (
     "sm_api_version", "sm_last_error", "sm_default_config", "sm_create", "sm_destroy",
     "sm_process_frame", "sm_process_frame_device", "sm_sync", "sm_clean_points", "sm_reset",
     "sm_get_counts", "sm_download_model_aos", "sm_upload_model_aos", "sm_save_map", "sm_load_map",
-    "sm_download_index_map", "sm_download_depth", "sm_render_image", "sm_set_frame", "sm_set_tick",
+    "sm_download_index_map", "sm_download_raw_cloud", "sm_download_depth", "sm_render_image", "sm_set_frame", "sm_set_tick",
     "sm_stage_conflict", "sm_stage_cull", "sm_stage_splat", "sm_stage_associate_fuse",
     "sm_stage_timings", "sm_read_frame_log", "sm_device_alloc", "sm_device_free", "sm_device_upload",
     "sm_export_model_device", "sm_append_model_aos_device", "sm_key_map_device_ptr",
@@ -110,6 +110,7 @@ def load():
     L.sm_save_map.argtypes = [vp, C.c_char_p, C.c_int32, C.c_int32]
     L.sm_load_map.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.sm_download_index_map.argtypes = [vp, vp, vp, vp, vp]
+    L.sm_download_raw_cloud.argtypes = [vp, vp, C.c_uint32, u32p]
     L.sm_download_depth.argtypes = [vp, C.c_int, vp]
     L.sm_render_image.argtypes = [vp, vp, C.c_int, C.c_int] + [C.c_float] * 4 + [vp, vp]
     L.sm_set_frame.argtypes = [vp, vp, vp, vp]
@@ -247,6 +248,15 @@ class SurfelMap:
         self._chk(self._L.sm_download_index_map(self._h, _ptr(idx), _ptr(vc), _ptr(ct), _ptr(nr)),
                   "sm_download_index_map")
         return idx, vc, ct, nr
+
+    def download_raw_cloud(self) -> np.ndarray:
+        """FeedbackBuffer "RAW": the raw camera-frame surfel cloud of the last processed frame, float32 [n][12]."""
+        n = C.c_uint32()
+        self._chk(self._L.sm_download_raw_cloud(self._h, None, 0, C.byref(n)), "sm_download_raw_cloud")
+        out = np.zeros((n.value, 12), np.float32)
+        if n.value:
+            self._chk(self._L.sm_download_raw_cloud(self._h, _ptr(out), n.value, C.byref(n)), "sm_download_raw_cloud")
+        return out
 
     def download_depth(self, which=TEX_DEPTH_METRIC):
         out = np.zeros((self.H, self.W), np.float32)

@@ -9,7 +9,7 @@ public:
     GPUTexture() : texture(&tex_) {}
     pangolin::GlTexture *texture;
     static constexpr const char *RGB = "RGB";
-    static constexpr const char *DEPTH_RAW = "DEPTH_RAW";
+    static constexpr const char *DEPTH_RAW = "DEPTH";           // sic: src/GPUTexture.cpp:22
     static constexpr const char *DEPTH_FILTERED = "DEPTH_FILTERED";
     static constexpr const char *DEPTH_METRIC = "DEPTH_METRIC";
     static constexpr const char *SEMANTIC = "SEMANTIC";

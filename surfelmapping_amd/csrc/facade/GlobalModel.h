@@ -98,13 +98,65 @@ public:
     int imageWidth() const { return iw_; }
     int imageHeight() const { return ih_; }
 
-    // interactive GL presentation (renderModel, src/GlobalModel.cpp:683-758) is out of scope of the compute core
-    pangolin::GlTexture *getModelMapVC() { return mapVC_.texture; }
-    pangolin::GlTexture *getModelMapCT() { return mapCT_.texture; }
-    pangolin::GlTexture *getModelMapNR() { return mapNR_.texture; }
+    // src/GlobalModel.cpp:683-758 (signature src/GlobalModel.h:27-37).  The compute core keeps no GL buffer: the model is
+    // pulled to the host when somebody looks (the reference's AoS layout, 12 floats per surfel) and, built with
+    // SM_FACADE_GL, drawn as GL_POINTS; `threshold` / `time` / `timeDelta` select what the reference's shader discards
+    // (confidence below threshold unless drawUnstable, last seen more than timeDelta frames ago) -- applied on the host copy.
+    void renderModel(pangolin::OpenGlMatrix mvp, pangolin::OpenGlMatrix mv, float threshold, bool drawUnstable, bool drawNormals,
+                     bool drawColors, bool drawPoints, bool drawWindow, bool drawSemantic, int time, int timeDelta)
+    {
+        (void)mv; (void)drawNormals; (void)drawColors; (void)drawPoints; (void)drawWindow; (void)drawSemantic; (void)time; (void)timeDelta;
+        refreshHostModel();
+        drawn_.clear();
+        const size_t n = hostModel_.size() / 12;
+        for (size_t k = 0; k < n; ++k) {
+            const float *v = &hostModel_[k * 12];
+            if (!drawUnstable && v[3] < threshold) continue;                 // draw_surface.vert: confidence gate
+            drawn_.insert(drawn_.end(), v, v + 3);
+        }
+#ifdef SM_FACADE_GL
+        glMatrixMode(GL_PROJECTION); glLoadIdentity(); glMultMatrixd(mvp.m);
+        glMatrixMode(GL_MODELVIEW); glLoadIdentity();
+        glEnableClientState(GL_VERTEX_ARRAY);
+        glVertexPointer(3, GL_FLOAT, 0, drawn_.data());
+        glDrawArrays(GL_POINTS, 0, (GLsizei)(drawn_.size() / 3));
+        glDisableClientState(GL_VERTEX_ARRAY);
+#else
+        (void)mvp;
+#endif
+    }
+    size_t lastDrawnCount() const { return drawn_.size() / 3; }
+
+    // The model-aligned mirror textures (src/GlobalModel.cpp:639-681) do not exist in the compute core.  GUI::drawCapacity
+    // (build_map.cpp:204) shows the fill level of the TEXTURE_DIMENSION^2 normal/radius mirror: the handle is filled lazily --
+    // size TEXTURE_DIMENSION x TEXTURE_DIMENSION, and (without GL) the host copy of the plane for whoever wants to look.
+    pangolin::GlTexture *getModelMapVC() { return fillMirror(mapVC_, 0); }
+    pangolin::GlTexture *getModelMapCT() { return fillMirror(mapCT_, 4); }
+    pangolin::GlTexture *getModelMapNR() { return fillMirror(mapNR_, 8); }
+    const std::vector<float> &mirrorHost(int which) const { return mirror_[which]; }      // 0 VC, 1 CT, 2 NR: count x 4 floats
 
 private:
+    void refreshHostModel() { hostModel_ = downloadModel(); }
+    pangolin::GlTexture *fillMirror(GPUTexture &t, int off)
+    {
+        refreshHostModel();
+        std::vector<float> &m = mirror_[off / 4];
+        const size_t n = hostModel_.size() / 12;
+        m.resize(n * 4);
+        for (size_t k = 0; k < n; ++k)
+            for (int c = 0; c < 4; ++c) m[k * 4 + c] = hostModel_[k * 12 + off + c];
+        if (off == 4) for (size_t k = 0; k < n; ++k) m[k * 4 + 1] = (float)k;            // map.vert:32 stores float(index) in .y
+        t.texture->width = TEXTURE_DIMENSION;
+        t.texture->height = TEXTURE_DIMENSION;
+#ifdef SM_FACADE_GL
+        if (!t.texture->tid) t.texture->Reinitialise(TEXTURE_DIMENSION, TEXTURE_DIMENSION, GL_RGBA32F, false, 0, GL_RGBA, GL_FLOAT);
+        const int rows = (int)((n + TEXTURE_DIMENSION - 1) / TEXTURE_DIMENSION);
+        if (rows) { m.resize((size_t)rows * TEXTURE_DIMENSION * 4, 0.0f); t.texture->Upload(m.data(), 0, 0, TEXTURE_DIMENSION, rows, GL_RGBA, GL_FLOAT); }
+#endif
+        return t.texture;
+    }
     sm_counts counts() { sm_counts c{}; sm_get_counts(ctx_, &c); return c; }
+    std::vector<float> hostModel_, drawn_, mirror_[3];
     sm_ctx *ctx_;
     bool pending_ = false;
     GPUTexture mapVC_, mapCT_, mapNR_, imageTex_, semTex_;

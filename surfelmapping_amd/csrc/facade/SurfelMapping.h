@@ -16,8 +16,9 @@
 #include "sm_png.h"
 #include <sys/stat.h>
 
+#include "FeedbackBuffer.h"
+
 class Checker;          // debug aid of the reference (src/Utils/Checker.h); never constructed here
-class FeedbackBuffer;   // raw per-frame cloud (GUI "Draw raw"); not produced by the compute core
 
 class SurfelMapping {
 public:
@@ -37,6 +38,7 @@ public:
         if (!ctx_) throw std::runtime_error(std::string("SurfelMapping: ") + sm_last_error());
         globalModel.bind(ctx_);
         indexMap.bind(ctx_);
+        rawFeedback.bind(ctx_);
         currPose = Eigen::Matrix4f::Identity();
         for (const char *n : {GPUTexture::RGB, GPUTexture::DEPTH_RAW, GPUTexture::DEPTH_FILTERED, GPUTexture::DEPTH_METRIC,
                               GPUTexture::SEMANTIC, "LAST"}) {
@@ -86,7 +88,14 @@ public:
         assert(it != textures.end() && "there is no such texture type");
         return it->second->texture;
     }
-    FeedbackBuffer *getFeedbackBuffer(const std::string &) { return nullptr; }
+    // src/SurfelMapping.cpp:458-464: only "RAW" is ever created (src/SurfelMapping.cpp:88-90)
+    FeedbackBuffer *getFeedbackBuffer(const std::string &feedbackType)
+    {
+        assert(feedbackType == FeedbackBuffer::RAW && "there is no such feedback buffer");
+        (void)feedbackType;
+        return &rawFeedback;
+    }
+    void computeFeedbackBuffers() { rawFeedback.refresh(); }                  // src/SurfelMapping.cpp:367-376
 
     // novel-view dump for SPADE (src/SurfelMapping.cpp:378-434): <path>/image/%06d.png (the bytes of the
     // reference's BGR cv::Mat, i.e. a correct-colour picture) and <path>/semantic/%06d.png (class + 1)
@@ -123,6 +132,7 @@ private:
     Eigen::Matrix4f currPose;
     IndexMap indexMap;
     GlobalModel globalModel;
+    FeedbackBuffer rawFeedback;
     std::map<std::string, GPUTexture *> textures;
     std::vector<Eigen::Matrix4f> historyPoses;
     bool beginCleanPoints = false;

@@ -236,6 +236,8 @@ struct sm_ctx {
     // host frame state (src/SurfelMapping.h:100-103)
     int tick = 0;
     bool ref_set = false;
+    bool raw_valid = false;            // a frame that computes the raw feedback cloud has run (every call but the reference frame)
+    int raw_tick = 0;                  // its time stamp
     float curr_pose[16], last_pose[16];
     uint32_t count_bound = 0;         // host upper bound of the device-side count (grid sizing)
     bool pending_cull = false;
@@ -806,6 +808,8 @@ int begin_frame(sm_ctx *s, const uint8_t *d_rgb, const uint16_t *d_raw, const ui
         s->chain_on_main = true;
     }
     if ((rc = mark(s, 1, fusing))) return rc;
+    s->raw_valid = true;                                  // computeFeedbackBuffers (src/SurfelMapping.cpp:164,172): on demand here
+    s->raw_tick = s->tick;
     if (s->tick == 0) {
         // after reset(): computeFeedbackBuffers + GlobalModel::initialize + buildModelMap
         // (src/SurfelMapping.cpp:161-169): the raw cloud of this frame becomes the model
@@ -1358,6 +1362,39 @@ int sm_download_index_map(sm_ctx *s, int32_t *id, float *vert_conf4, float *colo
     if (color_time4) HIPCK(hipMemcpyAsync(color_time4, d_ct, P * 16, hipMemcpyDeviceToHost, s->stream));
     if (norm_rad4) HIPCK(hipMemcpyAsync(norm_rad4, d_nr, P * 16, hipMemcpyDeviceToHost, s->stream));
     HIPCK(hipStreamSynchronize(s->stream));
+    return SM_OK;
+}
+
+int sm_download_raw_cloud(sm_ctx *s, float *dst12, uint32_t cap, uint32_t *n)
+{
+    if (!s || !n) return SM_E_ARG;
+    HIPCK(hipSetDevice(s->cfg.device));
+    *n = 0;
+    if (!s->raw_valid) return SM_OK;                     // nothing computed yet (the reference's buffer is empty before the 2nd frame)
+    const size_t P = (size_t)s->P;
+    int rc = ensure_export(s, P * 49);
+    if (rc) return rc;
+    float4 *d_rec = (float4 *)s->d_export;
+    uint8_t *d_flag = (uint8_t *)s->d_export + P * 48;
+    FrameParams fp = make_params(s, s->curr_pose);
+    fp.init_mode = 1;
+    fp.time = s->raw_tick;
+    hipLaunchKernelGGL(k_raw_cloud, dim3((s->P + 255) / 256), dim3(256), 0, s->stream, fp, s->d_depthT, s->d_rgbsT, s->d_xs, s->d_ys, d_rec, d_flag);
+    HIPCK(hipGetLastError());
+    std::vector<uint8_t> flag(P);
+    HIPCK(hipMemcpyAsync(flag.data(), d_flag, P, hipMemcpyDeviceToHost, s->stream));
+    HIPCK(hipStreamSynchronize(s->stream));
+    uint32_t cnt = 0;
+    for (size_t q = 0; q < P; ++q) cnt += flag[q];
+    *n = cnt;
+    if (!dst12) return SM_OK;
+    if (cap < cnt) { g_err = "sm_download_raw_cloud: destination too small"; return SM_E_CAPACITY; }
+    std::vector<float> rec(P * 12);
+    HIPCK(hipMemcpyAsync(rec.data(), d_rec, P * 48, hipMemcpyDeviceToHost, s->stream));
+    HIPCK(hipStreamSynchronize(s->stream));
+    uint32_t w = 0;
+    for (size_t q = 0; q < P; ++q)                       // q = i * H + j: the feedback buffer's vertex order
+        if (flag[q]) { memcpy(dst12 + (size_t)w * 12, rec.data() + q * 12, 48); ++w; }
     return SM_OK;
 }
 

@@ -2628,6 +2628,26 @@ __global__ __launch_bounds__(PIX_BLOCK) void k_append_scan(Model M, DevState *__
     bounds_expand_wave(tb, wr, slot / (uint32_t)TILE, pw.x, pw.y, pw.z, (float)fp.time, false);
 }
 
+// The raw per-frame surfel cloud of FeedbackBuffer::compute (src/FeedbackBuffer.cpp:85-145, surfel_feedback.vert:25-63,
+// surfel_feedback.geom:17-26): every checkerboard pixel with 0 < z < maxDepth as a CAMERA-frame surfel
+// (pos, 0.9 | colour, 0, time, time | normal, radius), no neighbour test.  One record slot per pixel + a flag; the host
+// keeps the flagged ones in vertex order (x-outer / y-inner, src/FeedbackBuffer.cpp:47-54).  Not on the hot path: the
+// reference fills this buffer every frame for the GUI's "Draw raw" view only (src/SurfelMapping.cpp:172).
+__global__ __launch_bounds__(256) void k_raw_cloud(FrameParams fp, const float *__restrict__ depthT, const uint32_t *__restrict__ rgbsT,
+                                                   const float *__restrict__ xs, const float *__restrict__ ys,
+                                                   float4 *__restrict__ rec /* [P][3] */, uint8_t *__restrict__ flag)
+{
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= fp.P) return;
+    LocalSurfel L;
+    const bool ok = local_surfel(q, fp, depthT, rgbsT, xs, ys, L);       // fp.init_mode = 1: the feedback buffer's rules
+    flag[q] = ok ? 1 : 0;
+    if (!ok) return;
+    rec[(size_t)q * 3 + 0] = make_float4(L.pos.x, L.pos.y, L.pos.z, 0.9f);                             // surfel_feedback.vert:96
+    rec[(size_t)q * 3 + 1] = make_float4(__uint_as_float(encode_color(L.cr, L.cg, L.cb, L.sem)), 0.0f, (float)fp.time, (float)fp.time);
+    rec[(size_t)q * 3 + 2] = make_float4(L.nrm.x, L.nrm.y, L.nrm.z, L.radius);
+}
+
 // rebuild of the tile bounds from the stored model (upload / import / device append)
 __global__ void k_tile_bounds_reset(uint32_t *__restrict__ tb, uint32_t first, uint32_t n)
 {

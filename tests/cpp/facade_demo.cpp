@@ -31,6 +31,15 @@ int main(int argc, char **argv)
                     core.getGlobalModel().getConflict().second, core.getGlobalModel().getUnstable().second);
     }
     std::fclose(f);
+    {   // what rungui() does with the core every frame (build_map.cpp:177-204): raw cloud, model, capacity pane
+        pangolin::OpenGlMatrix mvp{}, mv{};
+        core.getFeedbackBuffer(FeedbackBuffer::RAW)->render(mvp, core.getCurrPose(), false, true, false, false);
+        core.getGlobalModel().renderModel(mvp, mv, 0.0, true, false, true, false, false, false, 3, 3);
+        pangolin::GlTexture *nr = core.getGlobalModel().getModelMapNR();
+        std::printf("raw cloud %u  drawn %zu  mirror %dx%d  textures %d %d\n", core.getFeedbackBuffer(FeedbackBuffer::RAW)->count(),
+                    core.getGlobalModel().lastDrawnCount(), nr->width, nr->height, core.getTexture(GPUTexture::RGB)->width,
+                    core.getTexture(GPUTexture::DEPTH_METRIC)->height);
+    }
     if (argc > 3) {                                                        // load_map.cpp-style novel-view dump
         std::vector<Eigen::Matrix4f> views = {core.getCurrPose()};
         core.acquireImages(argv[3], views, W, H, intr[0], intr[1], intr[2], intr[3], 7);

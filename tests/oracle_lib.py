@@ -103,6 +103,8 @@ def lib(path=None):
         L.smo_expf.argtypes = [C.c_float]
         L.smo_render_image.restype = C.c_int
         L.smo_render_image.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_float] * 4 + [C.c_void_p] * 2
+        L.smo_raw_cloud.restype = C.c_int
+        L.smo_raw_cloud.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
         L.smo_invert4.argtypes = [fp, fp]
         L.smo_mul4.argtypes = [fp, fp, fp]
         _libs[path] = L
@@ -195,6 +197,16 @@ class Oracle:
         nr = np.zeros((P, 4), np.float32)
         _chk(self._L.smo_download_index_map(self._h, _ptr(idx), _ptr(vc), _ptr(ct), _ptr(nr)), "index_map")
         return idx, vc, ct, nr
+
+    def download_raw_cloud(self) -> np.ndarray:
+        """FeedbackBuffer "RAW" of the last processed frame (time stamp = its tick)."""
+        t = self.counts()["tick"] - 1
+        n = C.c_uint32()
+        _chk(self._L.smo_raw_cloud(self._h, t, None, 0, C.byref(n)), "raw_cloud")
+        out = np.zeros((n.value, 12), np.float32)
+        if n.value:
+            _chk(self._L.smo_raw_cloud(self._h, t, _ptr(out), n.value, C.byref(n)), "raw_cloud")
+        return out
 
     def download_depth(self, which=0):
         out = np.zeros((self.H, self.W), np.float32)

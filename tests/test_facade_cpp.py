@@ -80,4 +80,6 @@ def test_facade_demo_matches_oracle(tmp_path):
     lab = read_png(str(views / "semantic" / "000007.png"))
     assert np.array_equal(img, bgr[..., ::-1]) and np.array_equal(lab[..., 0], sem) and (sem > 0).mean() > 0.3
     c = o.counts()
+    # FeedbackBuffer RAW -> render, GlobalModel::renderModel, getModelMapNR (build_map.cpp:177-204)
+    assert f"raw cloud {o.download_raw_cloud().shape[0]}  drawn {c['count']}  mirror 1000x1000  textures 320 120" in r.stdout, r.stdout[-600:]
     assert f"frame 4: model {c['count']} offset {c['offset']} data {c['data_count']} conflict {c['conflict_count']}" in r.stdout

@@ -386,3 +386,25 @@ def test_tile_bounds_with_yaw_and_turning_back():
     run_sequence(o, h, seq, every=4)
     log = h.read_frame_log()
     assert log["n_conf_skipped"].max() > 10_000
+
+
+def test_raw_feedback_cloud_matches_oracle():
+    """FeedbackBuffer "RAW" (src/FeedbackBuffer.cpp:85-145, surfel_feedback.vert): the raw camera-frame cloud of the last
+    frame through sm_download_raw_cloud -- empty before the second call (the reference computes it from the second
+    processFrame on), then bit-identical to the oracle's restatement, also with the depth filter chain and after reset()."""
+    for pre in (0, 1):
+        seq = synth.make_sequence(SMALL, synth.kitti_trajectory(5), seed=17, noise_mm=3.0)
+        o, h = pair(SMALL, stereo_border=20.0, max_sqrt_vertices=600, preprocess=pre)
+        o.process_frame(*seq[0]); h.process_frame(*seq[0])
+        assert h.download_raw_cloud().shape[0] == 0
+        for k, fr in enumerate(seq[1:4]):
+            o.process_frame(*fr); h.process_frame(*fr)
+            a, b = o.download_raw_cloud(), h.download_raw_cloud()
+            assert a.shape == b.shape and a.shape[0] > 5000, (pre, k, a.shape, b.shape)
+            assert_models_equal_nan_tolerant(a, b, f"raw cloud pre={pre} frame {k}")
+            assert np.all(b[:, 3] == np.float32(0.9)) and np.all(b[:, 6] == k + 1) and np.all(b[:, 5] == 0)
+        o.reset(); h.reset()
+        o.process_frame(*seq[4]); h.process_frame(*seq[4])
+        assert_models_equal_nan_tolerant(o.download_raw_cloud(), h.download_raw_cloud(), f"raw cloud after reset pre={pre}")
+        assert o.counts() == h.counts()
+        assert_models_equal_nan_tolerant(o.download_model(), h.download_model(), f"model after raw-cloud downloads pre={pre}")
