@@ -340,11 +340,14 @@ def main():
     # the per-frame hot path of a camera touches only its own slice -- so it is timed separately.
     global_count, gather_ms = None, None
     if dist:
-        sm_global = capi.SurfelMap(capi.make_config(**cam, preprocess=0, device=local_rank))
+        from surfelmapping_amd import sharded as smsh
+        sm_global = capi.SurfelMap(capi.make_config(**cam, preprocess=0, device=local_rank, max_sqrt_vertices=10000 if (hd or world > 2) else 5000))
+        rig = smd.RigMapper(sm, smsh.TorchComm(device_index=local_rank), P)
+        rig.last = (frames[Wm + K - 1][1], frames[Wm + K - 1][2], frames[Wm + K - 1][3])     # the camera's latest view
         barrier()
         g0 = time.perf_counter()
-        gathered, gcounts = smd.gather_model_device(sm, local_rank)
-        global_count = smd.build_global_model(sm_global, gathered, gcounts)
+        # every slice cleaned against every camera's latest view (cleanPoints per view), then the RCCL gather on device buffers
+        global_count, gcounts, view_conflicts = rig.consolidate(device_index=local_rank, sm_global=sm_global)
         barrier()
         gather_ms = (time.perf_counter() - g0) * 1e3
     log = sm.read_frame_log(K)
@@ -464,8 +467,9 @@ def main():
                                 if hd else "BASELINE configs[1]: KITTI 1242x375 synthetic street sequence, 0.8 m/frame, ")
                                + f"depth noise {args.noise_mm} mm, metricise+conflict+cull+splat+associate+fuse+append per frame"
                                + (" + depth pre-processing p0b..p0e" if args.preprocess else ""),
-                   "frames": f"{Wm}..{Wm + K - 1}", "multi_gpu": (f"{world}-camera rig, one stream per GPU, RCCL all-gather into a single GlobalModel of "
-                                 f"{global_count} surfels after the timed frames ({gather_ms:.1f} ms, not in `value`)") if dist else "single stream",
+                   "frames": f"{Wm}..{Wm + K - 1}", "multi_gpu": (f"{world}-camera rig, one stream per GPU; consolidation after the timed frames: every slice cleaned "
+                                 f"against all {world} latest views (cleanPoints per view, {sum(view_conflicts)} conflicts), RCCL all-gather into a single "
+                                 f"GlobalModel of {global_count} surfels ({gather_ms:.1f} ms, not in `value`)") if dist else "single stream",
                    "host_sync": "per frame" if args.sync_every_frame else "none inside the timed region",
                    "compaction": (f"deferred: culled surfels keep their slots, every {args.compact_period}th cull compacts "
                                   f"({int((log['n_static'] < log['n_slots']).sum()) if len(log) else 0} of {K} timed frames moved surfels)")

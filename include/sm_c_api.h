@@ -145,6 +145,10 @@ int sm_sync(sm_ctx *s);
 /* SurfelMapping::cleanPoints (src/SurfelMapping.cpp:496-532) */
 int sm_clean_points(sm_ctx *s, const uint16_t *depth_mm, const uint8_t *semantic,
                     const float *pose16);
+/* cleanPoints for a model SLICE of a multi-GPU rig (surfelmapping_amd/dist.py, BASELINE configs[4]): as sm_clean_points,
+ * but the "surfel id 0 never conflicts" rule (conflict.geom:15) applies only where exempt_first != 0 -- i.e. on the rank
+ * whose slice holds the first surfel of the single GlobalModel; the other slices have no id 0. */
+int sm_clean_points_ex(sm_ctx *s, const uint16_t *depth_mm, const uint8_t *semantic, const float *pose16, int exempt_first);
 /* SurfelMapping::reset (src/SurfelMapping.cpp:436-441): empties the model and sets tick = 0; the next processFrame
  * builds the model anew from that frame's raw cloud (GlobalModel::initialize), discarding anything uploaded in between.
  * The index map is left as the last predictIndices drew it. */

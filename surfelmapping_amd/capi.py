@@ -19,7 +19,7 @@ TEX_DEPTH_METRIC, TEX_DEPTH_FILTERED, TEX_LAST = 0, 1, 2
 # every extern "C" symbol include/sm_c_api.h declares
 SYMBOLS = (
     "sm_api_version", "sm_last_error", "sm_default_config", "sm_create", "sm_destroy",
-    "sm_process_frame", "sm_process_frame_device", "sm_sync", "sm_clean_points", "sm_reset",
+    "sm_process_frame", "sm_process_frame_device", "sm_sync", "sm_clean_points", "sm_clean_points_ex", "sm_reset",
     "sm_get_counts", "sm_download_model_aos", "sm_upload_model_aos", "sm_save_map", "sm_load_map",
     "sm_download_index_map", "sm_download_raw_cloud", "sm_download_depth", "sm_render_image", "sm_set_frame", "sm_set_tick",
     "sm_stage_conflict", "sm_stage_cull", "sm_stage_splat", "sm_stage_associate_fuse",
@@ -81,6 +81,32 @@ class SurfelMapError(RuntimeError):
 _lib = None
 
 
+def _preload_torch_hip_runtime():
+    """One HIP runtime per process.  PyTorch's ROCm wheels bundle their own libamdhip64.so (soname libamdhip64.so.7) and ask
+    for it by the name "libamdhip64.so"; the HIP core asks for "libamdhip64.so.7".  If the core is loaded first, ROCm's copy
+    comes in and torch later loads its own as well -- two runtimes, and RCCL (torch's) cannot use the core's device memory
+    (sm_create / sm_export_model_device refuse with both paths).  Loading torch's copy first makes either import order work:
+    the core's request matches its soname.  No torch, or SM_NO_TORCH_HIP_PRELOAD=1: nothing is done."""
+    if os.environ.get("SM_NO_TORCH_HIP_PRELOAD") == "1":
+        return
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return                                   # torch's runtime is loaded already
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if not spec or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load():
     """dlopen the HIP library (no compute).  Raises if it has not been built."""
     global _lib
@@ -90,6 +116,7 @@ def load():
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(make -C surfelmapping_amd/csrc). surfelmapping_amd has no CPU fallback.")
+    _preload_torch_hip_runtime()
     L = C.CDLL(LIB_PATH)
     vp, u32p = C.c_void_p, C.POINTER(C.c_uint32)
     L.sm_api_version.restype = C.c_int
@@ -103,6 +130,7 @@ def load():
     L.sm_process_frame_device.argtypes = [vp, vp, vp, vp, vp]
     L.sm_sync.argtypes = [vp]
     L.sm_clean_points.argtypes = [vp, vp, vp, vp]
+    L.sm_clean_points_ex.argtypes = [vp, vp, vp, vp, C.c_int]
     L.sm_reset.argtypes = [vp]
     L.sm_get_counts.argtypes = [vp, C.POINTER(SmCounts)]
     L.sm_download_model_aos.argtypes = [vp, vp, C.c_uint32, u32p]
@@ -209,6 +237,13 @@ class SurfelMap:
         sem = np.ascontiguousarray(sem, np.uint8)
         pose = np.ascontiguousarray(pose, np.float32)
         self._chk(self._L.sm_clean_points(self._h, _ptr(depth), _ptr(sem), _ptr(pose)), "sm_clean_points")
+
+    def clean_points_slice(self, depth, sem, pose, exempt_first: bool):
+        """cleanPoints on a rig slice (surfelmapping_amd/dist.py): the id-0 exemption only where the slice holds the global surfel 0"""
+        depth = np.ascontiguousarray(depth, np.uint16)
+        sem = np.ascontiguousarray(sem, np.uint8)
+        pose = np.ascontiguousarray(pose, np.float32)
+        self._chk(self._L.sm_clean_points_ex(self._h, _ptr(depth), _ptr(sem), _ptr(pose), 1 if exempt_first else 0), "sm_clean_points_ex")
 
     def reset(self):
         self._chk(self._L.sm_reset(self._h), "sm_reset")

@@ -7,6 +7,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <link.h>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -114,6 +116,36 @@ float exp_spec(float x)
     return ldexpf(p, (int)k);
 }
 
+}  // namespace
+
+// Two HIP runtimes in one process.  PyTorch's ROCm wheels bundle their own libamdhip64.so (soname libamdhip64.so.7) and
+// request it by the name "libamdhip64.so"; this library requests "libamdhip64.so.7".  The dynamic loader matches a
+// request against the names / sonames of what is loaded already: torch first -> its copy satisfies our request (one
+// runtime, fine); this library first -> ROCm's copy is loaded, torch's later request for "libamdhip64.so" does not match its
+// soname, so torch/lib/libamdhip64.so is loaded TOO, and torch / its RCCL then run on another runtime than the one that
+// owns this library's device memory (seen as a process exit inside RCCL: gpurun_out/pytest_gpu2.log, round 1).
+// surfelmapping_amd.capi.load() avoids it by pre-loading torch's copy when torch is installed; any other host gets a
+// refusal with the two paths instead of undefined behaviour.
+namespace {
+int collect_hip_runtime(struct dl_phdr_info *info, size_t, void *data)
+{
+    auto *v = static_cast<std::vector<std::string> *>(data);
+    if (info->dlpi_name && std::strstr(info->dlpi_name, "libamdhip64")) v->push_back(info->dlpi_name);
+    return 0;
+}
+// true (and g_err set) if more than one libamdhip64 is mapped into this process
+bool hip_runtime_conflict(const char *where)
+{
+    std::vector<std::string> libs;
+    dl_iterate_phdr(collect_hip_runtime, &libs);
+    std::sort(libs.begin(), libs.end());
+    libs.erase(std::unique(libs.begin(), libs.end()), libs.end());
+    if (libs.size() <= 1) return false;
+    g_err = std::string(where) + ": two HIP runtimes are loaded in this process (" + libs[0] + ", " + libs[1] +
+            "); device memory of one is not valid in the other.  Load the other user's runtime first (Python: import torch, or "
+            "surfelmapping_amd.capi, before anything that loads ROCm's libamdhip64; C++: link RCCL and this library against the same ROCm)";
+    return true;
+}
 }  // namespace
 
 // Contexts of one process that share a GPU: the in-place compaction kernel waits on tile hand-off flags and, in its
@@ -987,6 +1019,7 @@ sm_ctx *sm_create(const sm_config *c)
         g_err = "sm_create: bad config";
         return nullptr;
     }
+    if (hip_runtime_conflict("sm_create")) return nullptr;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || c->device >= ndev) {
         g_err = "sm_create: no HIP device visible (this library has no CPU fallback)";
@@ -1209,6 +1242,11 @@ int sm_process_frame(sm_ctx *s, const uint8_t *rgb, const uint16_t *depth_mm, co
 
 int sm_clean_points(sm_ctx *s, const uint16_t *depth_mm, const uint8_t *semantic, const float *pose16)
 {
+    return sm_clean_points_ex(s, depth_mm, semantic, pose16, 1);
+}
+
+int sm_clean_points_ex(sm_ctx *s, const uint16_t *depth_mm, const uint8_t *semantic, const float *pose16, int exempt_first)
+{
     if (!s || !depth_mm || !semantic || !pose16) { g_err = "sm_clean_points: null argument"; return SM_E_ARG; }
     HIPCK(hipSetDevice(s->cfg.device));
     if (s->pending_cull) { g_err = "sm_stage_conflict without sm_stage_cull"; return SM_E_ARG; }
@@ -1223,6 +1261,7 @@ int sm_clean_points(sm_ctx *s, const uint16_t *depth_mm, const uint8_t *semantic
     fp.max_depth = s->cfg.far_clip - 15.0f;     // src/SurfelMapping.cpp:515
     fp.conflict_thresh = 0.1f;                  // :516
     fp.is_clean = 1;                            // :517
+    fp.no_exempt = exempt_first ? 0 : 1;
     fp.compact_now = decide_compact(s) ? 1u : 0u;
     note_cull(s, fp.compact_now != 0u);
     if ((rc = launch_conflict(s, fp))) return rc;
@@ -1667,6 +1706,7 @@ int sm_device_upload(sm_ctx *s, void *dst_device, const void *src_host, size_t b
 int sm_export_model_device(sm_ctx *s, void **d_aos, uint32_t *n)
 {
     if (!s || !d_aos || !n) return SM_E_ARG;
+    if (hip_runtime_conflict("sm_export_model_device")) return SM_E_HIP;     // the pointer goes to foreign code (RCCL)
     HIPCK(hipSetDevice(s->cfg.device));
     if (s->pending_cull) { g_err = "sm_export_model_device between sm_stage_conflict and sm_stage_cull"; return SM_E_ARG; }
     int rc = ensure_compact(s);
@@ -1687,6 +1727,7 @@ int sm_export_model_device(sm_ctx *s, void **d_aos, uint32_t *n)
 int sm_append_model_aos_device(sm_ctx *s, const float *d_src12, uint32_t n)
 {
     if (!s || (!d_src12 && n)) return SM_E_ARG;
+    if (hip_runtime_conflict("sm_append_model_aos_device")) return SM_E_HIP;
     HIPCK(hipSetDevice(s->cfg.device));
     if (s->pending_cull) { g_err = "sm_append_model_aos_device between sm_stage_conflict and sm_stage_cull"; return SM_E_ARG; }
     int rc = ensure_compact(s);
@@ -1706,7 +1747,7 @@ int sm_append_model_aos_device(sm_ctx *s, const float *d_src12, uint32_t n)
     return pull_state(s);
 }
 
-void *sm_key_map_device_ptr(sm_ctx *s) { return s ? (void *)s->d_keyT : nullptr; }
+void *sm_key_map_device_ptr(sm_ctx *s) { return (s && !hip_runtime_conflict("sm_key_map_device_ptr")) ? (void *)s->d_keyT : nullptr; }
 
 void *sm_fused_mask_device_ptr(sm_ctx *s, uint32_t *nwords)
 {

@@ -109,6 +109,7 @@ struct FrameParams {
                               // Decided by the host (a fixed period + a capacity bound), so that it can launch the matching kernels
     int maintenance;          // 1: compaction outside a frame (no kills): frame statistics are left alone
     int compact_tickets;      // 1: k_compact hands its moving tiles out in order from a ticket counter (no co-residency needed)
+    int no_exempt;            // 1: no surfel is exempt from the conflict test (a rig slice that does not hold the global surfel 0)
 };
 
 // local index -> global id through the per-segment tables (segments = surfels created by one frame,

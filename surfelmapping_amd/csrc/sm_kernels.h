@@ -409,7 +409,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SM_CONFLICT
     __shared__ uint8_t s_flags[64];
     const uint32_t N = st->count;
     const bool has_dead = st->garbage != 0u;          // slots of surfels killed since the last physical compaction
-    const uint32_t exempt = fp.world > 1 ? fp.exempt_local : st->first_live;   // the surfel with (global) id 0
+    const uint32_t exempt = fp.no_exempt ? 0xFFFFFFFFu : (fp.world > 1 ? fp.exempt_local : st->first_live);   // the surfel with (global) id 0
     const float4 *__restrict__ pc = M.s[st->cur].pos_conf;
     const uint32_t ntiles = (N + TILE - 1) / TILE;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

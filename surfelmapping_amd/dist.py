@@ -85,3 +85,64 @@ def build_global_model(sm_global, gathered, counts):
         if n:
             sm_global.append_model_device(gathered[r].data_ptr(), n)
     return sm_global.counts()["count"]
+
+
+class RigMapper:
+    """BASELINE configs[4]: a rig of G cameras, one per rank (= one per GPU), consolidated into a SINGLE GlobalModel.
+
+    Frame loop: every rank fuses its own camera into its own slice with the ordinary per-frame path -- no collective.
+
+    `consolidate()` defines "single GlobalModel" with the reference's own operations:
+      1. the slices concatenated in rank order (GlobalModel::concatenate's order for G append lists), and
+      2. that union cleaned against EVERY camera's latest view, one view after the other in rank order, with the
+         reference's tool for testing the model against a view it was not fused from: SurfelMapping::cleanPoints
+         (src/SurfelMapping.cpp:496-532 -- conflict.vert with maxDepth = far - 15, threshold 0.1, isClean = 1 -- then
+         updateConflict + backMapping).  This is the "conflict pass of every camera's depth against the union" of
+         SURVEY.md 8e.
+    The conflict test is per surfel and per view, so every rank cleans ITS slice against all G views (after an all-gather
+    of the G latest depth / semantic images and poses: 3 bytes per pixel per camera) and the cleaned slices are gathered.
+    Two rules of the reference couple the slices and are carried explicitly: surfel id 0 never conflicts
+    (conflict.geom:15) -- only the rank holding the first surfel of the union applies the exemption -- and at most W*H
+    conflicts take effect per view (src/GlobalModel.cpp:54-57) -- the per-view total is all-reduced and a view with more
+    conflicts than pixels raises instead of returning a model that could differ from the definition.
+
+    `backend` is the rank's mapper (capi.SurfelMap, or an oracle-backed stand-in in CPU tests) with process_frame, counts,
+    clean_points_slice(depth, sem, pose, exempt_first), download_model; `comm` has rank, world, allgather(obj),
+    allreduce_sum(array) (sharded.ThreadComm / sharded.TorchComm)."""
+
+    def __init__(self, backend, comm, n_pixels: int, conflict_cap: bool = True):
+        self.be, self.comm = backend, comm
+        self.P = n_pixels
+        self.conflict_cap = conflict_cap
+        self.last = None
+
+    def process_frame(self, rgb, depth, sem, pose):
+        rc = self.be.process_frame(rgb, depth, sem, pose)
+        self.last = (np.ascontiguousarray(depth, np.uint16), np.ascontiguousarray(sem, np.uint8), np.ascontiguousarray(pose, np.float32))
+        return rc
+
+    def consolidate(self, device_index=None, sm_global=None):
+        """-> (single GlobalModel as AoS float32 [n][12], identical on every rank; per-rank counts; conflicts per view).
+        With `device_index` and `sm_global` (a second capi.SurfelMap on the same GPU) the cleaned slices are gathered over
+        RCCL on device buffers and appended into `sm_global` without a host round trip; the first return value is then the
+        surfel count of that GlobalModel."""
+        views = self.comm.allgather(self.last)
+        per_view = []
+        for v, view in enumerate(views):
+            if view is None:
+                continue
+            counts = [int(c) for c in self.comm.allgather(int(self.be.counts()["count"]))]
+            first = next((r for r, c in enumerate(counts) if c > 0), None)
+            self.be.clean_points_slice(*view, exempt_first=(first == self.comm.rank))
+            total = int(self.comm.allreduce_sum(np.array([self.be.counts()["conflict_count"]], np.int64))[0])
+            if self.conflict_cap and total > self.P:
+                raise RuntimeError(f"view {v}: {total} conflicts > W*H = {self.P}: the reference's conflict cap would truncate them in "
+                                   "global surfel order, which a per-slice pass does not reproduce")
+            per_view.append(total)
+        if device_index is not None and sm_global is not None:
+            gathered, counts = gather_model_device(self.be, device_index)
+            return build_global_model(sm_global, gathered, counts), counts, per_view
+        slices = self.comm.allgather(np.ascontiguousarray(self.be.download_model(), np.float32))
+        counts = [int(x.shape[0]) for x in slices]
+        model = np.concatenate(slices, axis=0) if slices else np.zeros((0, 12), np.float32)
+        return model, counts, per_view

@@ -55,9 +55,37 @@ SCRIPT = textwrap.dedent("""
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("order", ["torch_first"])   # torch must be imported before the HIP core (one HIP runtime per process)
+@pytest.mark.parametrize("order", ["torch_first", "lib_first"])   # either order: capi.load() pre-loads torch's bundled HIP runtime
 def test_rccl_gather_world1(order, tmp_path):
     f = tmp_path / "w1.py"
     f.write_text(SCRIPT)
     r = subprocess.run([sys.executable, str(f), order], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "DIST_GPU_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+CONFLICT = textwrap.dedent("""
+    import os, sys, ctypes
+    sys.path.insert(0, "__ROOT__")
+    os.environ["SM_NO_TORCH_HIP_PRELOAD"] = "1"          # what a C++ host that loads ROCm's runtime first would see
+    from surfelmapping_amd import capi
+    L = capi.load()                                       # binds /opt/rocm's libamdhip64.so.7
+    cfg = capi.make_config(64, 48, 50.0, 50.0, 31.5, 23.5, max_sqrt_vertices=64)
+    h1 = L.sm_create(ctypes.byref(cfg))
+    assert h1, L.sm_last_error()
+    import importlib.util
+    tl = os.path.join(list(importlib.util.find_spec("torch").submodule_search_locations)[0], "lib", "libamdhip64.so")
+    ctypes.CDLL(tl, mode=ctypes.RTLD_GLOBAL)              # torch's request "libamdhip64.so" does not match the soname: a 2nd runtime
+    h2 = L.sm_create(ctypes.byref(cfg))
+    msg = L.sm_last_error().decode()
+    assert not h2 and "two HIP runtimes" in msg and "torch" in msg, msg
+    print("CONFLICT_DETECTED")
+""").replace("__ROOT__", ROOT)
+
+
+@pytest.mark.gpu
+def test_second_hip_runtime_is_refused_not_undefined(tmp_path):
+    """The cause of round 1's lib_first failure: two libamdhip64 copies in one process.  The core names both and refuses."""
+    f = tmp_path / "c.py"
+    f.write_text(CONFLICT)
+    r = subprocess.run([sys.executable, str(f)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "CONFLICT_DETECTED" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])

@@ -400,7 +400,7 @@ def test_raw_feedback_cloud_matches_oracle():
         for k, fr in enumerate(seq[1:4]):
             o.process_frame(*fr); h.process_frame(*fr)
             a, b = o.download_raw_cloud(), h.download_raw_cloud()
-            assert a.shape == b.shape and a.shape[0] > 5000, (pre, k, a.shape, b.shape)
+            assert a.shape == b.shape and a.shape[0] > 2000, (pre, k, a.shape, b.shape)
             assert_models_equal_nan_tolerant(a, b, f"raw cloud pre={pre} frame {k}")
             assert np.all(b[:, 3] == np.float32(0.9)) and np.all(b[:, 6] == k + 1) and np.all(b[:, 5] == 0)
         o.reset(); h.reset()

@@ -1,0 +1,172 @@
+"""BASELINE configs[4]: a G-camera rig, one camera per rank, consolidated into a single GlobalModel
+(surfelmapping_amd/dist.py::RigMapper).
+
+Definition under test (reference operations only): the rank slices concatenated in rank order, then
+SurfelMapping::cleanPoints (src/SurfelMapping.cpp:496-532) of that union against every camera's latest view, in rank
+order.  `definition()` evaluates exactly that on ONE oracle instance; the distributed form (every rank cleans its own
+slice against all views, then the slices are gathered) must give the same surfels bit for bit:
+  * CPU, G = 2, 3 threads and 2 gloo processes with oracle-backed ranks (the host logic: view all-gather, id-0 exemption
+    on the first non-empty slice only, conflict totals, gather order);
+  * GPU, G = 2 and 4 HIP contexts on the one GPU (ThreadComm), the product path end to end."""
+import ctypes as C
+import math
+import os
+import socket
+import sys
+import threading
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from surfelmapping_amd import dist as smd
+from surfelmapping_amd import sharded, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CAM = dict(width=192, height=80, fx=110.0, fy=110.0, cx=95.5, cy=39.5)
+OVER = dict(preprocess=0, stereo_border=12.0, max_sqrt_vertices=500)
+N_FRAMES = 5
+
+
+def rank_stream(rank, world):
+    """camera `rank` of the rig: same forward motion, yawed by rank * 12 degrees (overlapping fields of view, so that the
+    cameras see each other's surfels).  Every camera looks at its own set of parked cars (boxes): a car only one camera has
+    seen is contradicted by the others' depth -- the situation the cross-camera conflict pass is for."""
+    poses = [synth.pose_matrix(0.0, 0.0, 0.6 * k, 12.0 * rank + 0.4 * math.sin(k)) for k in range(N_FRAMES)]
+    return synth.make_sequence(CAM, poses, seed=41, noise_mm=4.0 + rank, scene=synth.Scene(41 + rank, n_boxes=12, length=22.0))
+
+
+class OracleRigBackend:
+    """oracle-backed rank (CPU tests): cleanPoints with the id-0 exemption switched per slice"""
+
+    def __init__(self):
+        self.o = ol.Oracle(ol.make_config(**CAM, **OVER))
+        self.L = ol.lib()
+        self.L.smo_set_exempt_id.argtypes = [C.c_void_p, C.c_int32]
+
+    def process_frame(self, *fr):
+        return self.o.process_frame(*fr)
+
+    def counts(self):
+        return self.o.counts()
+
+    def download_model(self):
+        return self.o.download_model()
+
+    def clean_points_slice(self, depth, sem, pose, exempt_first):
+        self.L.smo_set_exempt_id(self.o._h, 0 if exempt_first else -1)
+        self.o.clean_points(depth, sem, pose)
+        self.L.smo_set_exempt_id(self.o._h, 0)
+
+
+def definition(world):
+    """the single GlobalModel by its definition, on one oracle: union in rank order, cleanPoints per view in rank order"""
+    slices, views = [], []
+    for r in range(world):
+        o = ol.Oracle(ol.make_config(**CAM, **OVER))
+        seq = rank_stream(r, world)
+        for fr in seq:
+            o.process_frame(*fr)
+        slices.append(o.download_model())
+        views.append(seq[-1][1:])
+    g = ol.Oracle(ol.make_config(**CAM, **dict(OVER, max_sqrt_vertices=1200)))
+    g.upload_model(np.concatenate(slices, axis=0))
+    g.set_tick(N_FRAMES)
+    conflicts = []
+    for depth, sem, pose in views:
+        g.clean_points(depth, sem, pose)
+        conflicts.append(g.counts()["conflict_count"])
+    return g.download_model(), [s.shape[0] for s in slices], conflicts
+
+
+def run_threads(world, make_backend):
+    group = sharded.ThreadGroup(world)
+    out, err = [None] * world, []
+
+    def work(r):
+        try:
+            mp = smd.RigMapper(make_backend(r), sharded.ThreadComm(group, r), CAM["width"] * CAM["height"])
+            for fr in rank_stream(r, world):
+                mp.process_frame(*fr)
+            out[r] = mp.consolidate()
+        except BaseException as e:          # a failing rank must not leave the others waiting at the barrier
+            err.append(e)
+            group.barrier.abort()
+
+    ts = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(600)
+    if err:
+        raise err[0]
+    return out
+
+
+def check(out, world):
+    model, sizes, conflicts = definition(world)
+    assert sum(conflicts) > 50, conflicts                      # the views do clean each other's surfels
+    assert model.shape[0] < sum(sizes)
+    for r in range(world):
+        got, counts, per_view = out[r]
+        assert per_view == conflicts
+        assert sum(counts) == model.shape[0]
+        assert np.array_equal(got.view(np.uint32), model.view(np.uint32)), f"rank {r}"
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_rig_consolidation_oracle_ranks_in_threads(world):
+    check(run_threads(world, lambda r: OracleRigBackend()), world)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 4])
+def test_rig_consolidation_hip_contexts_equal_the_definition(world):
+    from surfelmapping_amd import capi
+    check(run_threads(world, lambda r: capi.SurfelMap(capi.make_config(**CAM, **OVER))), world)
+
+
+# ---------------------------------------------------------------- 2 gloo processes (torch.distributed on host arrays)
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    for p in (ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        import test_rig as tr
+        mp = smd.RigMapper(tr.OracleRigBackend(), sharded.TorchComm(), CAM["width"] * CAM["height"])
+        for fr in tr.rank_stream(rank, world):
+            mp.process_frame(*fr)
+        model, counts, per_view = mp.consolidate()
+        q.put((rank, counts, per_view, model.view(np.uint32).tobytes()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_rig_consolidation_two_gloo_processes():
+    import torch.multiprocessing as tmp
+    world = 2
+    ctx = tmp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    model, sizes, conflicts = definition(world)
+    for rank, counts, per_view, blob in res:
+        assert per_view == conflicts and sum(counts) == model.shape[0]
+        assert np.array_equal(np.frombuffer(blob, np.uint32).reshape(-1, 12), model.view(np.uint32))
