@@ -147,7 +147,7 @@ def kernel_table(log, tim, P, K, args, workload=None):
     return kern, launches, roofline
 
 
-def bench_sharded(args, dist, torch, capi, cam, frames, rank, world, local_rank, K, Wm, t_gen):
+def bench_sharded(args, dist, torch, capi, cam, frames, rank, world, local_rank, K, Wm, t_gen, emit):
     """ONE camera stream split over the GPUs (surfelmapping_amd/sharded.py); every rank holds the
     replicated frame sequence, so all ranks generated the same frames (seed, no rank offset)."""
     from surfelmapping_amd import sharded
@@ -172,7 +172,7 @@ def bench_sharded(args, dist, torch, capi, cam, frames, rank, world, local_rank,
     dist.destroy_process_group()
     if rank != 0:
         return
-    print(json.dumps({
+    emit(({
         "metric": "frames/sec, 1242x375 KITTI-shaped RGB-D+semantic, full associate+fuse+merge",
         "value": K / elapsed, "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm,
         "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
@@ -251,6 +251,15 @@ def main():
                     help="reference semantics: host waits for the counters after every frame")
     args = ap.parse_args()
 
+    # ONE JSON line on stdout: native libraries (RCCL prints a version banner to stdout when a communicator is created)
+    # write to file descriptor 1 directly, so fd 1 is pointed at stderr for the whole run and the line goes to the real stdout
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(obj):
+        os.write(real_stdout, (json.dumps(obj) + "\n").encode())
+
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -281,7 +290,7 @@ def main():
 
     from surfelmapping_amd import capi
     if dist and args.mode == "sharded":
-        return bench_sharded(args, dist, torch, capi, cam, frames, rank, world, local_rank, K, Wm, t_gen)
+        return bench_sharded(args, dist, torch, capi, cam, frames, rank, world, local_rank, K, Wm, t_gen, emit)
     # hd20m: the conflict cap is off for the stress benchmark (SURVEY.md A13 says to state which)
     mk = lambda timing: capi.SurfelMap(capi.make_config(**cam, preprocess=args.preprocess, device=local_rank,
                                                         enable_timing=timing, conflict_cap=0 if hd else 1,
@@ -492,7 +501,7 @@ def main():
         "event_overhead_ms": tim.get("event_overhead", 0.0),
         "gen_seconds": t_gen,
     }
-    print(json.dumps(out))
+    emit(out)
 
 
 if __name__ == "__main__":
