@@ -17,6 +17,7 @@ timed on this host over the same frames, 1 thread.
 from __future__ import annotations
 
 import argparse
+import gc
 import json
 import multiprocessing as mp
 import os
@@ -148,40 +149,80 @@ def kernel_table(log, tim, P, K, args, workload=None):
 
 
 def bench_sharded(args, dist, torch, capi, cam, frames, rank, world, local_rank, K, Wm, t_gen, emit):
-    """ONE camera stream split over the GPUs (surfelmapping_amd/sharded.py); every rank holds the
-    replicated frame sequence, so all ranks generated the same frames (seed, no rank offset)."""
+    """ONE camera stream split over the GPUs (BASELINE configs[3]); every rank holds the replicated frame sequence (same
+    seed, no rank offset).  Default: the in-stream form (sm_shard_frame_device: slot-addressed shards, RCCL called from the
+    HIP core on the context's stream, frames resident in HBM); --shard-form staged is round 1's per-stage form driven from
+    Python (surfelmapping_amd/sharded.py ShardedMapper), kept for comparison."""
     from surfelmapping_amd import sharded
     P = cam["width"] * cam["height"]
-    sm = capi.SurfelMap(capi.make_config(**cam, preprocess=args.preprocess, device=local_rank, conflict_cap=1))
-    mp = sharded.ShardedMapper(sharded.HipShardBackend(sm, rank, world), sharded.TorchComm(device_index=local_rank), P,
-                               collect_stats=False)
+    stream = args.shard_form == "stream"
+    kw = dict(preprocess=args.preprocess, device=local_rank, conflict_cap=1)
+    if args.compact_period is not None:
+        kw["compact_period"] = args.compact_period
+    sm = capi.SurfelMap(capi.make_config(**cam, **kw))
+    if stream:
+        ids = [capi.rccl_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        mp = sharded.StreamShard(sm, rank, world, *((None,) if (args.no_rccl and world == 1) else ("rccl", ids[0])))
+        dptr = []
+        for rgb, depth, sem, pose in frames:
+            dr, dd, ds = sm.device_alloc(P * 3), sm.device_alloc(P * 2), sm.device_alloc(P)
+            sm.device_upload(dr, rgb); sm.device_upload(dd, depth); sm.device_upload(ds, sem)
+            dptr.append((dr, dd, ds, pose))
+        step = lambda k: sm.shard_frame_device(*dptr[k])
+    else:
+        mp = sharded.ShardedMapper(sharded.HipShardBackend(sm, rank, world), sharded.TorchComm(device_index=local_rank), P,
+                                   collect_stats=False)
+        step = lambda k: mp.process_frame(*frames[k])
     for k in range(Wm):
-        mp.process_frame(*frames[k])
+        step(k)
+    sm.sync()
+    c0 = sm.counts() if stream else mp.counts()
     dist.barrier(); torch.cuda.synchronize()
+    gc.collect(); gc.disable()      # with torch imported a full collection takes ~45 ms (measured: one frame call of 110 stalled that long)
     t0 = time.perf_counter()
-    fused = 0
+    enq = []
     for k in range(Wm, Wm + K):
-        c = mp.process_frame(*frames[k])
-        fused += c["fused_count"] + c["unstable_count"]
+        te = time.perf_counter()
+        step(k)
+        enq.append(time.perf_counter() - te)
+    t_enq = time.perf_counter() - t0
+    sm.sync()
     dist.barrier(); torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     t = torch.tensor([elapsed], dtype=torch.float64, device=torch.device("cuda", local_rank))
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t[0])
-    total = mp.counts()["count"]
+    c1 = sm.counts() if stream else mp.counts()
+    log = sm.read_frame_log(K) if stream else None
+    fused = int(log["fused_count"].sum() + log["unstable_count"].sum()) if log is not None and len(log) else 0
+    plain = None
+    if rank == 0 and stream and not args.no_plain_leg:
+        # the same frames on the plain single-GPU path of this GPU: what sharding has to beat
+        fps1, ms1, _, cp, _ = run_simple_leg(capi, cam, frames, K, Wm, dict(preprocess=args.preprocess, conflict_cap=1, **(
+            {"compact_period": args.compact_period} if args.compact_period is not None else {})), argparse.Namespace(no_events=True))
+        plain = {"frames_per_sec": fps1, "ms_per_step": ms1, "surfels_end": int(cp["count"]),
+                 "sharded_over_plain": (elapsed / K * 1e3) / ms1}
+    if stream and not (args.no_rccl and world == 1):
+        sm.shard_rccl_finalize()
     dist.destroy_process_group()
     if rank != 0:
         return
+    form = ("in-stream form: slot-addressed shards, per frame all-reduce(min) of the 3.7 MB key map and all-reduce(sum) of the fused-pixel "
+            "mask + 3 counters, RCCL called from the HIP core on the frame's stream, frames resident in HBM, deferred compaction "
+            "between frames (all-reduce(sum) of the alive bits)") if stream else (
+            "staged form driven from Python: all-reduce(sum) segment counts, all-reduce(min) key map, all-reduce(sum) fused mask; "
+            "host-buffer frames (PCIe-inclusive)")
     emit(({
         "metric": "frames/sec, 1242x375 KITTI-shaped RGB-D+semantic, full associate+fuse+merge",
         "value": K / elapsed, "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm,
         "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "BASELINE configs[3]: ONE KITTI 1242x375 stream sharded by creation-frame segments over "
-                               f"{world} GPUs; per frame: all-reduce(sum) segment counts, all-reduce(min) 3.7 MB key map, "
-                               "all-reduce(sum) fused mask (RCCL); host-buffer frames (PCIe-inclusive), result bit-identical to 1 GPU",
-                   "frames": f"{Wm}..{Wm + K - 1}", "surfels_end": int(total)},
-        "surfels_fused_per_sec": fused / elapsed, "roofline": None, "cpu_baseline": None, "gen_seconds": t_gen}))
+        "config": {"workload": f"BASELINE configs[3]: ONE KITTI 1242x375 stream sharded over {world} GPUs, {form}; result bit-identical to 1 GPU",
+                   "frames": f"{Wm}..{Wm + K - 1}", "surfels_start": int(c0["count"]), "surfels_end": int(c1["count"])},
+        "surfels_fused_per_sec": fused / elapsed, "plain_single_gpu": plain,
+        "host_enqueue_ms_per_step": t_enq / K * 1e3, "host_enqueue_max_ms": max(enq) * 1e3, "host_enqueue_argmax": int(np.argmax(enq)), "host_enqueue_median_ms": float(np.median(enq)) * 1e3, "roofline": None, "cpu_baseline": None, "gen_seconds": t_gen}))
 
 
 def run_simple_leg(capi, cam, frames, K, Wm, cfg_kw, args):
@@ -202,11 +243,13 @@ def run_simple_leg(capi, cam, frames, K, Wm, cfg_kw, args):
     for k in range(Wm):
         sm.process_frame_device(*dptr[k])
     sm.sync()
+    gc.collect(); gc.disable()
     t0 = time.perf_counter()
     for k in range(Wm, Wm + K):
         sm.process_frame_device(*dptr[k])
     sm.sync()
     el = time.perf_counter() - t0
+    gc.enable()
     log, counts = sm.read_frame_log(K), sm.counts()
     sm.close()
     tim = None
@@ -243,6 +286,10 @@ def main():
                     help="N>1: 'rig' = one camera stream per GPU + all-gather into one GlobalModel (weak scaling); "
                          "'sharded' = ONE stream split over the GPUs, bit-identical to 1 GPU (strong scaling)")
     ap.add_argument("--force-dist", action="store_true", help="rehearse the multi-GPU code path with WORLD_SIZE=1")
+    ap.add_argument("--shard-form", choices=["stream", "staged"], default="stream",
+                    help="--mode sharded: in-stream form (RCCL from the HIP core; default) or round 1's per-stage form driven from Python")
+    ap.add_argument("--no-rccl", action="store_true", help="--mode sharded with one rank: no communicator (the core's identity path) instead of RCCL")
+    ap.add_argument("--no-plain-leg", action="store_true", help="--mode sharded: skip the plain single-GPU run of the same frames on rank 0")
     ap.add_argument("--compact-period", type=int, default=8,
                     help="deferred compaction: culled surfels keep their slots, every Nth cull squeezes them out (1: every frame)")
     ap.add_argument("--no-fuse-leg", action="store_true",
@@ -339,12 +386,14 @@ def main():
     run(sm, 0, Wm)
     sm.sync()
     barrier()
+    gc.collect(); gc.disable()                    # no collector pause inside the timed region (~45 ms with torch imported)
     t0 = time.perf_counter()
     run(sm, Wm, Wm + K)
     t_enq = time.perf_counter() - t0              # host time to enqueue the K frames (no waiting inside)
     sm.sync()
     barrier()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     # Consolidation into a single GlobalModel (BASELINE configs[4]): an end-of-run exchange, not part of a frame --
     # the per-frame hot path of a camera touches only its own slice -- so it is timed separately.
     global_count, gather_ms = None, None

@@ -251,6 +251,35 @@ int sm_shard_associate(sm_ctx *s, const uint32_t *gseg_base, int n_gseg);
 /* p11 on the rank that owns this frame's segment (append_here), counters everywhere; ends the frame */
 int sm_shard_append(sm_ctx *s, int append_here);
 
+/* ---- The same sharding, in-stream form: no host or Python between the stages of a frame.  Every rank
+ * addresses surfels by the slot number the single-GPU run uses and stores only the segments it owns (owner of a frame's
+ * new surfels = fusing-frame index % world); the key map (min) and the fused-pixel mask + 3 counters (sum) are
+ * all-reduced on the context's own stream through the installed collective -- RCCL's ncclAllReduce, bound at run time
+ * by sm_shard_rccl_init, or any callback with the same meaning (tests: several contexts on one GPU).  All ranks hold
+ * the same counters (sm_get_counts) after every frame.  Replaces the per-stage calls above and the Python loop over
+ * them (surfelmapping_amd/sharded.py) for production use; results are bit-identical to the single-GPU path. */
+enum { SM_COLL_SUM = 0, SM_COLL_MIN = 1 };
+/* all-reduce `count` unsigned 64-bit words from `send` to `recv` (may be equal; device memory of this context) over the
+ * ranks, enqueued on `hip_stream`; returns 0 on success */
+typedef int (*sm_collective_fn)(void *user, const void *send, void *recv, size_t count, int op, void *hip_stream);
+/* on a new context (no frame yet); allocates the second surfel set the sharded compaction stages through */
+int sm_shard_stream_configure(sm_ctx *s, int rank, int world);
+int sm_shard_set_collective(sm_ctx *s, sm_collective_fn fn, void *user);
+/* RCCL bootstrap: rank 0 makes the 128-byte id, the host program hands it to every rank (MPI / torch.distributed /
+ * a file), each rank calls sm_shard_rccl_init -- a collective call (ncclCommInitRank) */
+int sm_shard_rccl_unique_id(void *out128);
+int sm_shard_rccl_init(sm_ctx *s, const void *id128);
+int sm_shard_rccl_finalize(sm_ctx *s);
+/* SurfelMapping::processFrame (src/SurfelMapping.cpp:115-251) on every rank with the same arguments; the _device form
+ * takes device pointers and only enqueues (sm_sync to wait) */
+int sm_shard_frame_device(sm_ctx *s, const uint8_t *d_rgb, const uint16_t *d_depth_mm, const uint8_t *d_semantic, const float *pose16);
+int sm_shard_frame(sm_ctx *s, const uint8_t *rgb, const uint16_t *depth_mm, const uint8_t *semantic, const float *pose16);
+/* squeeze the dead slots out now (collective; frames do it every compact_period-th time by themselves) */
+int sm_shard_compact(sm_ctx *s);
+/* collective: compacts, then exposes this rank's part of the union as `*count` x 12 floats in device memory with zeros
+ * in the other ranks' slots -- the integer (u32) sum over the ranks is the single GlobalModel in the reference's order */
+int sm_shard_export_dense_device(sm_ctx *s, const float **d_out12, uint32_t *count);
+
 #ifdef __cplusplus
 }
 #endif

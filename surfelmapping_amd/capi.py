@@ -27,7 +27,13 @@ SYMBOLS = (
     "sm_export_model_device", "sm_append_model_aos_device", "sm_key_map_device_ptr",
     "sm_fused_mask_device_ptr", "sm_device_download", "sm_shard_configure", "sm_shard_begin_frame",
     "sm_shard_conflict", "sm_shard_cull_splat", "sm_shard_associate", "sm_shard_append",
+    "sm_shard_stream_configure", "sm_shard_set_collective", "sm_shard_rccl_unique_id", "sm_shard_rccl_init",
+    "sm_shard_rccl_finalize", "sm_shard_frame_device", "sm_shard_frame", "sm_shard_compact", "sm_shard_export_dense_device",
 )
+
+SM_COLL_SUM, SM_COLL_MIN = 0, 1
+# int fn(void *user, const void *send, void *recv, size_t count_u64, int op, void *hip_stream)
+COLLECTIVE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p)
 
 
 class SmConfig(C.Structure):
@@ -107,6 +113,34 @@ def _preload_torch_hip_runtime():
             pass
 
 
+def _choose_rccl():
+    """RCCL for the in-stream sharded mode is bound at run time by the core.  When PyTorch is installed this module has made
+    PyTorch's bundled HIP runtime the process's runtime (above); name PyTorch's bundled RCCL too, so that both come from one
+    build.  SM_RCCL_LIB set by the user wins; without PyTorch the core takes ROCm's librccl."""
+    if os.environ.get("SM_RCCL_LIB") or os.environ.get("SM_NO_TORCH_HIP_PRELOAD") == "1":
+        return
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if spec and spec.submodule_search_locations:
+        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "librccl.so")
+        if os.path.exists(cand):
+            os.environ["SM_RCCL_LIB"] = cand
+
+
+def rccl_unique_id() -> bytes:
+    """128-byte RCCL id made by one rank and handed to all (sm_shard_rccl_unique_id)"""
+    _choose_rccl()
+    L = load()
+    buf = C.create_string_buffer(128)
+    rc = L.sm_shard_rccl_unique_id(buf)
+    if rc:
+        raise SurfelMapError("sm_shard_rccl_unique_id", rc, L.sm_last_error().decode())
+    return buf.raw
+
+
 def load():
     """dlopen the HIP library (no compute).  Raises if it has not been built."""
     global _lib
@@ -164,6 +198,15 @@ def load():
     L.sm_shard_cull_splat.argtypes = [vp, vp, vp, C.c_int]
     L.sm_shard_associate.argtypes = [vp, vp, C.c_int]
     L.sm_shard_append.argtypes = [vp, C.c_int]
+    L.sm_shard_stream_configure.argtypes = [vp, C.c_int, C.c_int]
+    L.sm_shard_set_collective.argtypes = [vp, COLLECTIVE_FN, vp]
+    L.sm_shard_rccl_unique_id.argtypes = [vp]
+    L.sm_shard_rccl_init.argtypes = [vp, vp]
+    L.sm_shard_rccl_finalize.argtypes = [vp]
+    L.sm_shard_frame_device.argtypes = [vp, vp, vp, vp, vp]
+    L.sm_shard_frame.argtypes = [vp, vp, vp, vp, vp]
+    L.sm_shard_compact.argtypes = [vp]
+    L.sm_shard_export_dense_device.argtypes = [vp, C.POINTER(vp), u32p]
     L.sm_key_map_device_ptr.restype = vp
     L.sm_key_map_device_ptr.argtypes = [vp]
     for name in SYMBOLS:
@@ -413,6 +456,59 @@ class SurfelMap:
 
     def shard_append(self, append_here: bool, allow=(0,)):
         return self._chk(self._L.sm_shard_append(self._h, 1 if append_here else 0), "sm_shard_append", allow)
+
+    # -- sharded mode, in-stream form (slot-addressed; the collectives run on the context's stream)
+    def shard_stream_configure(self, rank, world):
+        self._chk(self._L.sm_shard_stream_configure(self._h, rank, world), "sm_shard_stream_configure")
+
+    def shard_set_collective(self, fn):
+        """fn(send_ptr, recv_ptr, count_u64, op) -> 0: an all-reduce over the ranks with the meaning of sm_collective_fn"""
+        def tramp(user, send, recv, count, op, stream):
+            try:
+                return int(fn(send, recv, count, op) or 0)
+            except Exception as e:                       # never let an exception cross the C frame
+                self._coll_error = e
+                return SM_E_HIP
+        self._coll_cb = COLLECTIVE_FN(tramp)            # keep the trampoline alive as long as the context
+        self._chk(self._L.sm_shard_set_collective(self._h, self._coll_cb, None), "sm_shard_set_collective")
+
+    def shard_rccl_init(self, unique_id: bytes):
+        _choose_rccl()
+        buf = C.create_string_buffer(bytes(unique_id), 128)
+        self._chk(self._L.sm_shard_rccl_init(self._h, buf), "sm_shard_rccl_init")
+
+    def shard_rccl_finalize(self):
+        self._chk(self._L.sm_shard_rccl_finalize(self._h), "sm_shard_rccl_finalize")
+
+    def shard_frame(self, rgb, depth, sem, pose, allow=(0,)):
+        rgb = np.ascontiguousarray(rgb, np.uint8)
+        depth = None if depth is None else np.ascontiguousarray(depth, np.uint16)
+        sem = None if sem is None else np.ascontiguousarray(sem, np.uint8)
+        pose = np.ascontiguousarray(pose, np.float32)
+        rc = self._L.sm_shard_frame(self._h, _ptr(rgb), _ptr(depth), _ptr(sem), _ptr(pose))
+        if rc and getattr(self, "_coll_error", None) is not None:
+            e, self._coll_error = self._coll_error, None
+            raise e
+        return self._chk(rc, "sm_shard_frame", allow)
+
+    def shard_frame_device(self, d_rgb, d_depth, d_sem, pose):
+        pose = np.ascontiguousarray(pose, np.float32)
+        return self._chk(self._L.sm_shard_frame_device(self._h, d_rgb, d_depth, d_sem, _ptr(pose)), "sm_shard_frame_device")
+
+    def shard_compact(self):
+        self._chk(self._L.sm_shard_compact(self._h), "sm_shard_compact")
+
+    def shard_export_dense_device(self):
+        p, n = C.c_void_p(), C.c_uint32()
+        self._chk(self._L.sm_shard_export_dense_device(self._h, C.byref(p), C.byref(n)), "sm_shard_export_dense_device")
+        return p.value, n.value
+
+    def shard_export_dense(self) -> np.ndarray:
+        """this rank's surfels of the compacted union, zeros in the other ranks' slots: (count, 12) float32 (collective)"""
+        p, n = self.shard_export_dense_device()
+        if n == 0:
+            return np.zeros((0, 12), np.float32)
+        return self.device_download(p, n * 48, np.float32).reshape(n, 12)
 
     def key_map_device_ptr(self) -> int:
         return self._L.sm_key_map_device_ptr(self._h)

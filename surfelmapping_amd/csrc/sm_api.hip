@@ -7,7 +7,9 @@
 
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
 #include <link.h>
+#include <rccl/rccl.h>      // types and enums only: the library is bound at run time (sm_shard_rccl_*), never linked
 
 #include <algorithm>
 #include <cmath>
@@ -260,6 +262,15 @@ struct sm_ctx {
     int sh_rank = 0, sh_world = 1, sh_nseg = 0, sh_ngseg = 0;
     uint32_t sh_exempt = 0;
     bool sh_in_frame = false;
+    // slot-addressed sharding of one stream, in-stream form (sm_shard_stream_*)
+    bool ss_on = false;
+    int ss_rank = 0, ss_world = 1;
+    uint32_t ss_frames = 0;            // fusing frames so far = index of the next segment (its owner: index % world)
+    sm_collective_fn ss_coll = nullptr;
+    void *ss_user = nullptr;
+    void *ss_comm = nullptr;           // ncclComm_t when the built-in RCCL binding is used
+    uint64_t *d_galive = nullptr, *d_new_alive = nullptr, *d_gmask = nullptr;
+    uint32_t *d_ss_info = nullptr;
     int n_pix_blocks = 0;
     uint32_t n_odd_pixels = 0;
     // export staging
@@ -402,7 +413,10 @@ int take_error(sm_ctx *s)
         s->h_state->error = 0;
         HIPCK(hipMemcpyAsync(&s->d_state->error, &s->h_state->error, sizeof(int32_t), hipMemcpyHostToDevice, s->stream));
         HIPCK(hipStreamSynchronize(s->stream));
-        g_err = e == SM_E_CAPACITY ? "model capacity (MAX_VERTICES) exceeded; frame's new surfels dropped" : "device-side error";
+        g_err = e == SM_E_CAPACITY ? "model capacity (MAX_VERTICES) exceeded; frame's new surfels dropped"
+              : e == SM_E_UNSUPPORTED ? "sharded frame with more than W*H conflicts over all ranks: the reference's conflict cap would truncate them in "
+                                        "global surfel order, which a sharded cull does not reproduce"
+              : "device-side error";
         return e;
     }
     return SM_OK;
@@ -531,9 +545,11 @@ int launch_surfel_pass(sm_ctx *s, const FrameParams &fp, bool timed, bool direct
 // association + in-place fuse + direct append (the frame's last kernel; its statistics are completed later)
 int launch_associate_direct(sm_ctx *s, const FrameParams &fp, bool timed)
 {
-    hipLaunchKernelGGL(k_associate_direct, dim3(s->n_pix_blocks), dim3(PIX_BLOCK), 0, s->stream, s->M, s->d_state, fp, s->d_depthT, s->d_rgbsT,
+    ShardArgs sh;
+    memset(&sh, 0, sizeof sh);
+    hipLaunchKernelGGL(k_associate_direct<false>, dim3(s->n_pix_blocks), dim3(PIX_BLOCK), 0, s->stream, s->M, s->d_state, fp, s->d_depthT, s->d_rgbsT,
                        s->d_keyT, s->d_xs, s->d_ys, s->d_blk_cand, s->d_grp_cand, s->d_frame_sub, s->d_tb, s->d_alive, s->d_tile_dead, s->n_grp,
-                       s->d_stat);
+                       s->d_stat, sh);
     HIPCK(hipGetLastError());
     s->lazy_part_live = false;
     s->fix_part_live = false;
@@ -632,9 +648,19 @@ int launch_post_fill(sm_ctx *s)
 // Physical compaction outside a frame: every entry point that exposes slots as surfel ids (downloads, the per-pass
 // API, rendering, sharding, uploads) first squeezes out the slots that deferred culls left dead.  Nothing is killed:
 // empty conflict masks, then the regular scan + in-place compaction, with the key map's ids translated on the way.
+int ss_compact(sm_ctx *s);
+
 int ensure_compact(sm_ctx *s)
 {
     if (finalize_if_pending(s)) return SM_E_HIP;
+    if (s->ss_on) {
+        // slot-addressed sharding: a rank's arrays always hold the (dead) slots of the other ranks' surfels; the compaction is
+        // a collective step, so every rank must be making this same call
+        int rc = ss_compact(s);
+        if (rc) return rc;
+        HIPCK(hipStreamSynchronize(s->stream));
+        return SM_OK;
+    }
     if (!s->maybe_garbage) return SM_OK;
     if (s->pending_cull) { g_err = "internal: deferred compaction with a pending per-pass cull"; return SM_E_ARG; }
     FrameParams fp = make_params(s, s->curr_pose);
@@ -878,7 +904,7 @@ void end_frame(sm_ctx *s, bool timed)
 // SurfelMapping::processFrame body (src/SurfelMapping.cpp:130-251); enqueue only.
 int enqueue_frame(sm_ctx *s, const uint8_t *d_rgb, const uint16_t *d_raw, const uint8_t *d_sem, const float *pose)
 {
-    if (s->sh_world > 1) { g_err = "context is configured for sharding: use the sm_shard_* entry points"; return SM_E_ARG; }
+    if (s->sh_world > 1 || s->ss_on) { g_err = "context is configured for sharding: use the sm_shard_* entry points"; return SM_E_ARG; }
     FrameParams fp;
     // the cull's kind is decided first: a frame whose cull only marks the dead lets k_prep evaluate the tile skip flags for
     // the one-pass surfel kernel (not when k_prep runs ahead of the previous frame on the second stream)
@@ -1197,6 +1223,7 @@ void sm_destroy(sm_ctx *s)
     (void)hipFree(s->d_tile_cnt); (void)hipFree(s->d_tile_allow); (void)hipFree(s->d_tile_keep); (void)hipFree(s->d_tile_flag); (void)hipFree(s->d_group_tot); (void)hipFree(s->d_group_base); (void)hipFree(s->d_tb); (void)hipFree(s->d_tile_flags); (void)hipFree(s->d_conf_part); (void)hipFree(s->d_compact_part); (void)hipFree(s->d_lazy_part); (void)hipFree(s->d_conf_sub); (void)hipFree(s->d_fix_part); (void)hipFree(s->d_blk_cand); (void)hipFree(s->d_grp_cand); (void)hipFree(s->d_frame_sub); (void)hipFree(s->d_wave_cnt); (void)hipFree(s->d_undo); (void)hipFree(s->d_prep_part);
     (void)hipFree(s->d_validmask); (void)hipFree(s->d_fusedmask); (void)hipFree(s->d_blk_prefix); (void)hipFree(s->d_desc); (void)hipFree(s->d_blk_cnt);
     (void)hipFree(s->d_seg_lstart); (void)hipFree(s->d_seg_gbase); (void)hipFree(s->d_gseg_base); (void)hipFree(s->d_seg_keep);
+    (void)hipFree(s->d_galive); (void)hipFree(s->d_new_alive); (void)hipFree(s->d_gmask); (void)hipFree(s->d_ss_info);
     if (s->d_export) (void)hipFree(s->d_export);
     for (void *p : s->user_allocs) (void)hipFree(p);
     if (s->ev_ok)
@@ -1866,6 +1893,295 @@ int sm_shard_append(sm_ctx *s, int append_here)
     end_frame(s);
     s->sh_in_frame = false;
     return sm_sync(s);
+}
+
+}  // extern "C"
+
+// ---- ONE stream sharded over `world` GPUs, in-stream form: slot-addressed, no host in the frame ----------------------
+//
+// Every rank addresses surfels by the slot number the single-GPU run uses (k_associate_direct: slot = offset + candidate
+// pixels before the pixel -- computable on every rank, the frame is replicated) and stores only the segments it owns
+// (segment = one frame's new surfels, owner = frame index % world); everywhere else its alive bits are 0, its tile
+// bounds empty, so the one-pass surfel kernel runs unchanged and skips what it does not own.  DevState is replicated:
+// all ranks publish the same counts.  A frame is  k_prep | k_surfel_pass | k_pass_fixup | all-reduce(min) key map |
+// k_associate_direct<shard> | all-reduce(sum) fused mask + 3 counters | k_shard_settle, all on the context's stream.
+
+namespace {
+
+struct RcclApi {
+    void *lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+RcclApi g_rccl;
+std::mutex g_rccl_mu;
+
+int find_rccl(struct dl_phdr_info *info, size_t, void *data)
+{
+    auto *v = static_cast<std::string *>(data);
+    if (v->empty() && info->dlpi_name && std::strstr(info->dlpi_name, "librccl")) *v = info->dlpi_name;
+    return 0;
+}
+
+// RCCL is bound at run time: the copy already mapped into the process if there is one (a PyTorch process has its own
+// bundled librccl; two RCCLs would work but the one that is there already shares the HIP runtime for certain), else ROCm's.
+int load_rccl()
+{
+    std::lock_guard<std::mutex> lk(g_rccl_mu);
+    if (g_rccl.lib) return SM_OK;
+    std::string loaded;
+    dl_iterate_phdr(find_rccl, &loaded);
+    void *h = nullptr;
+    // SM_RCCL_LIB: an explicit copy (surfelmapping_amd.capi names PyTorch's bundled one when it pre-loaded PyTorch's HIP
+    // runtime: RCCL and the runtime then come from the same build)
+    if (const char *e = std::getenv("SM_RCCL_LIB")) { if (e[0]) { h = dlopen(e, RTLD_NOW | RTLD_LOCAL); if (h) loaded = e; } }
+    if (!h && !loaded.empty()) h = dlopen(loaded.c_str(), RTLD_NOW | RTLD_NOLOAD);
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+    if (!h) { g_err = std::string("RCCL not found: ") + (dlerror() ? dlerror() : "dlopen failed"); return SM_E_UNSUPPORTED; }
+    g_rccl.GetUniqueId = reinterpret_cast<decltype(g_rccl.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
+    g_rccl.CommInitRank = reinterpret_cast<decltype(g_rccl.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
+    g_rccl.AllReduce = reinterpret_cast<decltype(g_rccl.AllReduce)>(dlsym(h, "ncclAllReduce"));
+    g_rccl.CommDestroy = reinterpret_cast<decltype(g_rccl.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+    g_rccl.GetErrorString = reinterpret_cast<decltype(g_rccl.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.CommDestroy) {
+        g_err = "RCCL: missing symbols in " + (loaded.empty() ? std::string("librccl.so") : loaded);
+        return SM_E_UNSUPPORTED;
+    }
+    g_rccl.lib = h;
+    return SM_OK;
+}
+
+int rccl_collective(void *user, const void *send, void *recv, size_t count, int op, void *stream)
+{
+    sm_ctx *s = static_cast<sm_ctx *>(user);
+    const ncclResult_t r = g_rccl.AllReduce(send, recv, count, ncclUint64, op == SM_COLL_MIN ? ncclMin : ncclSum,
+                                            static_cast<ncclComm_t>(s->ss_comm), static_cast<hipStream_t>(stream));
+    if (r != ncclSuccess) { g_err = std::string("ncclAllReduce: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "failed"); return SM_E_HIP; }
+    return SM_OK;
+}
+
+int ss_collective(sm_ctx *s, const void *send, void *recv, size_t count, int op)
+{
+    if (!s->ss_coll) {
+        if (s->ss_world == 1) {          // one rank and no communicator: the reduction is the identity
+            if (send != recv) HIPCK(hipMemcpyAsync(recv, send, count * 8, hipMemcpyDeviceToDevice, s->stream));
+            return SM_OK;
+        }
+        g_err = "sharded stream: no collective installed (sm_shard_rccl_init or sm_shard_set_collective)";
+        return SM_E_ARG;
+    }
+    const int rc = s->ss_coll(s->ss_user, send, recv, count, op, s->stream);
+    if (rc && g_err.empty()) g_err = "sharded stream: the collective callback failed";
+    return rc;
+}
+
+// Physical compaction between two frames of a sharded stream (k_shard_* in sm_kernels.h); enqueue only.
+int ss_compact(sm_ctx *s)
+{
+    if (finalize_if_pending(s)) return SM_E_HIP;
+    const uint64_t nw = ((uint64_t)s->count_bound + 63) / 64;
+    const uint64_t tiles = ((uint64_t)s->count_bound + TILE - 1) / TILE;
+    const int g1 = (int)std::min<uint64_t>(std::max<uint64_t>((nw + 255) / 256, 1), 1024);
+    const int gt = (int)std::min<uint64_t>(std::max<uint64_t>(tiles, 1), MAX_GRID);
+    hipLaunchKernelGGL(k_shard_alive_copy, dim3(g1), dim3(256), 0, s->stream, s->d_state, s->d_alive, s->d_galive, s->d_new_alive, (uint32_t)nw);
+    HIPCK(hipGetLastError());
+    int rc = ss_collective(s, s->d_galive, s->d_galive, (size_t)nw, SM_COLL_SUM);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_shard_tile_popc, dim3(std::max(1, std::min(gt / 16 + 1, 256))), dim3(256), 0, s->stream, s->d_state, s->d_galive, s->d_tile_keep);
+    hipLaunchKernelGGL(k_shard_scan, dim3(1), dim3(1024), 0, s->stream, s->d_state, s->d_tile_keep, s->d_tile_allow, s->d_ss_info, s->d_stat);
+    hipLaunchKernelGGL(k_shard_stage, dim3(gt), dim3(256), 0, s->stream, s->M, s->d_state, s->d_alive, s->d_galive, s->d_tile_allow, s->d_ss_info,
+                       s->d_new_alive);
+    hipLaunchKernelGGL(k_shard_unstage, dim3(gt), dim3(256), 0, s->stream, s->M, s->d_state, s->d_ss_info, s->d_new_alive, s->d_alive,
+                       s->d_tile_dead, s->d_tb);
+    HIPCK(hipGetLastError());
+    s->culls_since_compact = 0;
+    s->keys_are_slots = false;
+    s->lazy_part_live = false;
+    s->fix_part_live = false;
+    return SM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sm_shard_stream_configure(sm_ctx *s, int rank, int world)
+{
+    if (!s || world < 1 || rank < 0 || rank >= world) return SM_E_ARG;
+    HIPCK(hipSetDevice(s->cfg.device));
+    if (s->ss_on) { g_err = "sm_shard_stream_configure: already configured"; return SM_E_ARG; }
+    if (!s->one_pass || !s->use_list || !s->direct || s->use_fused_assoc) {
+        g_err = "sm_shard_stream_configure: needs the one-pass frame with direct append (SM_ONE_PASS / SM_TILE_FLAGS_IN_PREP / SM_DIRECT_APPEND / SM_FUSED_ASSOC are set against it)";
+        return SM_E_UNSUPPORTED;
+    }
+    int rc = pull_state(s);
+    if (rc) return rc;
+    if (s->h_state->count != 0 || s->maybe_garbage || s->tick != 0 || s->ref_set) {
+        g_err = "sm_shard_stream_configure: the context must be new (no frame, no model)";
+        return SM_E_ARG;
+    }
+    if ((rc = alloc_set(s->M.s[1], s->cap))) return rc;                        // staging set of the sharded compaction
+    if ((rc = dalloc(&s->d_galive, s->alive_words)) || (rc = dalloc(&s->d_new_alive, s->alive_words)) ||
+        (rc = dalloc(&s->d_gmask, (size_t)(s->P + 63) / 64 + 4)) || (rc = dalloc(&s->d_ss_info, 4)))
+        return rc;
+    HIPCK(hipMemset(s->d_ss_info, 0, 16));
+    s->ss_on = true; s->ss_rank = rank; s->ss_world = world; s->ss_frames = 0;
+    return SM_OK;
+}
+
+int sm_shard_set_collective(sm_ctx *s, sm_collective_fn fn, void *user)
+{
+    if (!s || !s->ss_on) { g_err = "sm_shard_set_collective: call sm_shard_stream_configure first"; return SM_E_ARG; }
+    s->ss_coll = fn; s->ss_user = user;
+    return SM_OK;
+}
+
+int sm_shard_rccl_unique_id(void *out128)
+{
+    if (!out128) return SM_E_ARG;
+    int rc = load_rccl();
+    if (rc) return rc;
+    ncclUniqueId id;
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+    const ncclResult_t r = g_rccl.GetUniqueId(&id);
+    if (r != ncclSuccess) { g_err = "ncclGetUniqueId failed"; return SM_E_HIP; }
+    memcpy(out128, &id, 128);
+    return SM_OK;
+}
+
+int sm_shard_rccl_init(sm_ctx *s, const void *id128)
+{
+    if (!s || !id128 || !s->ss_on) { g_err = "sm_shard_rccl_init: call sm_shard_stream_configure first"; return SM_E_ARG; }
+    HIPCK(hipSetDevice(s->cfg.device));
+    if (hip_runtime_conflict("sm_shard_rccl_init")) return SM_E_HIP;
+    int rc = load_rccl();
+    if (rc) return rc;
+    ncclUniqueId id;
+    memcpy(&id, id128, 128);
+    ncclComm_t comm = nullptr;
+    const ncclResult_t r = g_rccl.CommInitRank(&comm, s->ss_world, id, s->ss_rank);
+    if (r != ncclSuccess) { g_err = std::string("ncclCommInitRank: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "failed"); return SM_E_HIP; }
+    s->ss_comm = comm;
+    s->ss_coll = rccl_collective; s->ss_user = s;
+    return SM_OK;
+}
+
+int sm_shard_rccl_finalize(sm_ctx *s)
+{
+    if (!s) return SM_E_ARG;
+    if (s->ss_comm && g_rccl.CommDestroy) {
+        HIPCK(hipSetDevice(s->cfg.device));
+        HIPCK(hipStreamSynchronize(s->stream));
+        (void)g_rccl.CommDestroy(static_cast<ncclComm_t>(s->ss_comm));
+    }
+    s->ss_comm = nullptr;
+    if (s->ss_coll == rccl_collective) { s->ss_coll = nullptr; s->ss_user = nullptr; }
+    return SM_OK;
+}
+
+int sm_shard_compact(sm_ctx *s)
+{
+    if (!s || !s->ss_on) return SM_E_ARG;
+    HIPCK(hipSetDevice(s->cfg.device));
+    return ss_compact(s);
+}
+
+// SurfelMapping::processFrame for one rank of a sharded stream; images already on the device; enqueue only
+int sm_shard_frame_device(sm_ctx *s, const uint8_t *d_rgb, const uint16_t *d_depth_mm, const uint8_t *d_semantic, const float *pose16)
+{
+    if (!s || !d_rgb || !pose16) { g_err = "sm_shard_frame_device: null argument"; return SM_E_ARG; }
+    if (!s->ss_on) { g_err = "sm_shard_frame_device: call sm_shard_stream_configure first"; return SM_E_ARG; }
+    HIPCK(hipSetDevice(s->cfg.device));
+    if (s->pending_cull) { g_err = "sm_stage_conflict without sm_stage_cull"; return SM_E_ARG; }
+    if (s->ref_set && s->tick == 0) { g_err = "reset() is not supported in sharded mode"; return SM_E_UNSUPPORTED; }
+    s->overlap = false;
+    s->idle_hint = false;
+    const bool fusing = s->ref_set && s->tick != 0;
+    int rc;
+    if (fusing) {
+        // The compaction schedule must be the same on every rank: the period counter, and a capacity bound that only uses
+        // what all ranks know (after a synchronisation the host's bound is the device's count, identical everywhere).
+        bool compact = s->cfg.compact_period <= 1 || s->culls_since_compact + 1 >= s->cfg.compact_period;
+        if (!compact && (uint64_t)s->count_bound + s->n_odd_pixels > s->cap) {
+            if ((rc = pull_state(s))) return rc;
+            compact = (uint64_t)s->count_bound + s->n_odd_pixels > s->cap;
+        }
+        if (compact && s->culls_since_compact > 0) {
+            if ((rc = ss_compact(s))) return rc;
+            if ((uint64_t)s->count_bound + s->n_odd_pixels > s->cap && (rc = pull_state(s))) return rc;
+        }
+    }
+    s->want_list = fusing;
+    FrameParams fp;
+    rc = begin_frame(s, d_rgb, d_depth_mm ? d_depth_mm : s->d_depth_raw, d_semantic ? d_semantic : s->d_sem, pose16, &fp);
+    s->want_list = false;
+    if (rc <= 0) return rc;
+    fp.compact_now = 0u;
+    fp.conflict_cap = 0xFFFFFFFFu;            // evaluated over all ranks by k_shard_settle
+    fp.shard_slots = 1;
+    note_cull(s, false);
+    s->keys_are_slots = true;
+    if (s->ev_ok) { s->ev_compacted[s->ev_frames % EV_RING] = false; s->ev_one_pass[s->ev_frames % EV_RING] = true; s->ev_direct[s->ev_frames % EV_RING] = true; }
+    if (s->n_prep_blocks == 0) { g_err = "internal: sharded frame without tile flags from k_prep"; return SM_E_ARG; }
+    if ((rc = launch_surfel_pass(s, fp, true, true))) return rc;
+    if ((rc = ss_collective(s, s->d_keyT, s->d_keyT, (size_t)s->P, SM_COLL_MIN))) return rc;
+    ShardArgs sh;
+    sh.validmask = s->d_validmask; sh.ownmask = s->d_fusedmask; sh.gmask = s->d_gmask; sh.nwords = (uint32_t)((s->P + 63) / 64);
+    sh.owner = (int)(s->ss_frames % (uint32_t)s->ss_world) == s->ss_rank ? 1 : 0;
+    hipLaunchKernelGGL(k_associate_direct<true>, dim3(s->n_pix_blocks), dim3(PIX_BLOCK), 0, s->stream, s->M, s->d_state, fp, s->d_depthT, s->d_rgbsT,
+                       s->d_keyT, s->d_xs, s->d_ys, s->d_blk_cand, s->d_grp_cand, s->d_frame_sub, s->d_tb, s->d_alive, s->d_tile_dead, s->n_grp,
+                       s->d_stat, sh);
+    HIPCK(hipGetLastError());
+    if ((rc = mark(s, 5, true))) return rc;
+    if ((rc = ss_collective(s, s->d_gmask, s->d_gmask, (size_t)sh.nwords + 4, SM_COLL_SUM))) return rc;   // in place, like the key map
+    hipLaunchKernelGGL(k_shard_settle, dim3(s->n_pix_blocks), dim3(PIX_BLOCK), 0, s->stream, s->d_state, fp, s->d_validmask, s->d_fusedmask,
+                       s->d_gmask, sh.nwords, s->d_blk_cand, s->d_grp_cand, s->d_frame_sub, s->d_alive, s->d_tile_dead, sh.owner,
+                       s->cfg.conflict_cap ? (uint32_t)s->P : 0xFFFFFFFFu);
+    HIPCK(hipGetLastError());
+    if ((rc = mark(s, 6, true)) || (rc = mark(s, 7, true))) return rc;
+    s->lazy_part_live = false;
+    s->fix_part_live = false;
+    s->pend_finalize = true;
+    s->frames_enq++;
+    s->ss_frames++;
+    bump_bound(s);
+    end_frame(s);
+    return SM_OK;
+}
+
+int sm_shard_frame(sm_ctx *s, const uint8_t *rgb, const uint16_t *depth_mm, const uint8_t *semantic, const float *pose16)
+{
+    if (!s || !rgb || !pose16) { g_err = "sm_shard_frame: null argument"; return SM_E_ARG; }
+    HIPCK(hipSetDevice(s->cfg.device));
+    s->overlap = false;
+    int rc = upload_inputs(s, rgb, depth_mm, semantic, true);
+    if (rc) return rc;
+    if ((rc = sm_shard_frame_device(s, s->d_rgb, s->d_depth_raw, s->d_sem, pose16))) return rc;
+    return sm_sync(s);
+}
+
+// This rank's part of the (compacted) union as a dense AoS plane of `*count` surfels with zeros where other ranks own the
+// slot: the integer sum of the planes over the ranks is the single GlobalModel.  Collective (it compacts first).
+int sm_shard_export_dense_device(sm_ctx *s, const float **d_out12, uint32_t *count)
+{
+    if (!s || !d_out12 || !count || !s->ss_on) return SM_E_ARG;
+    HIPCK(hipSetDevice(s->cfg.device));
+    if (hip_runtime_conflict("sm_shard_export_dense_device")) return SM_E_HIP;
+    int rc = ensure_compact(s);
+    if (rc) return rc;
+    if ((rc = pull_state(s))) return rc;
+    const uint32_t n = s->h_state->count;
+    if ((rc = ensure_export(s, (size_t)std::max<uint32_t>(n, 1) * 48))) return rc;
+    if (n) hipLaunchKernelGGL(k_shard_export_aos, dim3((n + 255) / 256), dim3(256), 0, s->stream, s->M, s->d_state, s->d_alive, (float *)s->d_export, n);
+    HIPCK(hipGetLastError());
+    HIPCK(hipStreamSynchronize(s->stream));
+    *d_out12 = (const float *)s->d_export;
+    *count = n;
+    return SM_OK;
 }
 
 }  // extern "C"

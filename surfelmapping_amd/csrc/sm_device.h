@@ -110,6 +110,7 @@ struct FrameParams {
     int maintenance;          // 1: compaction outside a frame (no kills): frame statistics are left alone
     int compact_tickets;      // 1: k_compact hands its moving tiles out in order from a ticket counter (no co-residency needed)
     int no_exempt;            // 1: no surfel is exempt from the conflict test (a rig slice that does not hold the global surfel 0)
+    int shard_slots;          // 1: slot-addressed sharding of one stream: ids are global slot numbers on every rank
 };
 
 // local index -> global id through the per-segment tables (segments = surfels created by one frame,

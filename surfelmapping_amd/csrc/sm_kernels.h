@@ -2078,7 +2078,8 @@ __device__ __forceinline__ void associate_pixel(int q, const SurfelSet &cur, con
                                                 const uint64_t *__restrict__ keyT, const float *__restrict__ xs,
                                                 const float *__restrict__ ys, const uint32_t *__restrict__ gseg_base,
                                                 const uint32_t *__restrict__ seg_lstart, LocalSurfel &L, bool &is_valid,
-                                                bool &is_fused, uint32_t *__restrict__ tb, uint32_t first_live)
+                                                bool &is_fused, uint32_t *__restrict__ tb, uint32_t first_live,
+                                                const uint64_t *__restrict__ own_alive = nullptr /* slot-addressed sharding: this rank's alive bits */)
 {
     is_valid = false;
     is_fused = false;
@@ -2088,9 +2089,19 @@ __device__ __forceinline__ void associate_pixel(int q, const SurfelSet &cur, con
         const int32_t gid = (int32_t)(uint32_t)(key & 0xFFFFFFFFull);
         uint32_t id = 0;
         // data.vert:142 "id > 0" on the GLOBAL id (single GPU: the slot of the first live surfel is id 0);
-        // only the rank that owns the winner tries to fuse it
-        if (!fp.init_mode && key != KEY_EMPTY && (fp.world > 1 ? gid > 0 : (uint32_t)gid != first_live) &&
-            global_to_local((uint32_t)gid, gseg_base, fp.n_gseg, seg_lstart, fp.rank, fp.world, &id)) {
+        // only the rank that owns the winner tries to fuse it.  Slot-addressed sharding (own_alive): ids are global slot
+        // numbers on every rank and a rank owns exactly the slots whose alive bit it holds.
+        bool mine = false;
+        if (!fp.init_mode && key != KEY_EMPTY) {
+            if (own_alive) {
+                id = (uint32_t)gid;
+                mine = id != first_live && ((own_alive[id >> 6] >> (id & 63u)) & 1ull) != 0ull;
+            } else {
+                mine = (fp.world > 1 ? gid > 0 : (uint32_t)gid != first_live) &&
+                       global_to_local((uint32_t)gid, gseg_base, fp.n_gseg, seg_lstart, fp.rank, fp.world, &id);
+            }
+        }
+        if (mine) {
             const float4 pc = cur.pos_conf[id];
             const uint32_t col = cur.color[id];
             const uint32_t sem_o = col >> 24;
@@ -2208,6 +2219,19 @@ __global__ __launch_bounds__(PIX_BLOCK) void k_associate(Model M, const DevState
 // surfel order are the reference's (stable cull; column-major append, src/GlobalModel.cpp:67-74), ids handed out by
 // the API are positions among the live surfels as with any deferred compaction.
 // ---------------------------------------------------------------------------------------------
+// Slot-addressed sharding of ONE stream over several GPUs ("sharded mode, in-stream form"): every rank
+// addresses surfels by the slot number the single-GPU run would use; it stores (and holds the alive bit of) only the
+// slots of the segments it owns.  The association kernel then also leaves the two ballot planes the ranks exchange.
+struct ShardArgs {
+    uint64_t *validmask;      // candidate pixels (identical on every rank: the frame is replicated)
+    uint64_t *ownmask;        // pixels fused by THIS rank (kept: k_shard_settle tells them from the pixels other ranks fused)
+    uint64_t *gmask;          // the same words again, sum-reduced IN PLACE over the ranks afterwards (disjoint bit sets: sum == union);
+                              //   4 more words follow: [nw + 0..2] this rank's conflicts / surfels drawn into the index map / surfels killed
+    uint32_t nwords;          // ceil(P / 64)
+    int owner;                // 1: this rank owns the frame's new surfels (frame's segment index % world == rank)
+};
+
+template <bool SHARD>
 __global__ __launch_bounds__(PIX_BLOCK) void k_associate_direct(Model M, DevState *__restrict__ st, FrameParams fp,
                                                                 const float *__restrict__ depthT,
                                                                 const uint32_t *__restrict__ rgbsT,
@@ -2218,7 +2242,7 @@ __global__ __launch_bounds__(PIX_BLOCK) void k_associate_direct(Model M, DevStat
                                                                 uint32_t *__restrict__ frame_sub /* sets 2, 3: new, fused -- 64 sub-counters each */,
                                                                 uint32_t *__restrict__ tb, uint64_t *__restrict__ alive,
                                                                 uint32_t *__restrict__ tile_dead, uint32_t n_grp,
-                                                                unsigned long long *__restrict__ host_stat)
+                                                                unsigned long long *__restrict__ host_stat, ShardArgs sh)
 {
     __shared__ uint32_t s_v[4], s_n[4], s_f[4];
     __shared__ uint32_t s_hole[12], s_dead[2];          // empty slots of this block: 6 alive words (lo, hi), 2 tiles
@@ -2235,11 +2259,21 @@ __global__ __launch_bounds__(PIX_BLOCK) void k_associate_direct(Model M, DevStat
     const int q = blockIdx.x * PIX_BLOCK + threadIdx.x;
     bool is_valid, is_fused;
     LocalSurfel L;
-    associate_pixel(q, cur, fp, depthT, rgbsT, keyT, xs, ys, nullptr, nullptr, L, is_valid, is_fused, tb, st->first_live);
+    associate_pixel(q, cur, fp, depthT, rgbsT, keyT, xs, ys, nullptr, nullptr, L, is_valid, is_fused, tb, st->first_live,
+                    SHARD ? alive : nullptr);
     const uint64_t vw = __ballot(is_valid), fw = __ballot(is_fused);
     if (lane == 0) { s_v[wave] = (uint32_t)__popcll(vw); s_n[wave] = (uint32_t)__popcll(vw & ~fw); s_f[wave] = (uint32_t)__popcll(fw); }
+    if (SHARD && lane == 0) {
+        const uint32_t word = blockIdx.x * (PIX_BLOCK / 64) + (uint32_t)wave;
+        if (word < sh.nwords) { sh.validmask[word] = vw; sh.ownmask[word] = fw; sh.gmask[word] = fw; }
+    }
     pre = wave_sum_u32(pre);
     __syncthreads();
+    if (SHARD && blockIdx.x == 0 && threadIdx.x == 0) {
+        // this rank's share of the frame's counters travels with the mask (k_pass_fixup published them)
+        sh.gmask[sh.nwords] = st->conflict_count; sh.gmask[sh.nwords + 1] = st->visible_count;
+        sh.gmask[sh.nwords + 2] = st->n_kill; sh.gmask[sh.nwords + 3] = 0ull;
+    }
     if (blockIdx.x == 0 && wave == 0) {
         // every candidate pixel of the frame owns a slot: the new count (the host never lets a frame of this form start
         // without room for all of them), published for the next frame's kernels and for the host's capacity bound
@@ -2255,7 +2289,7 @@ __global__ __launch_bounds__(PIX_BLOCK) void k_associate_direct(Model M, DevStat
                                    __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
-    if (threadIdx.x == 0) {
+    if (!SHARD && threadIdx.x == 0) {                    // (sharded: k_shard_settle counts, from the masks of all ranks)
         const uint32_t nn = s_n[0] + s_n[1] + s_n[2] + s_n[3], nf = s_f[0] + s_f[1] + s_f[2] + s_f[3];
         if (nn) atomicAdd(&frame_sub[2 * SUB_SET + (blockIdx.x & 63u) * SUB_STRIDE], nn);
         if (nf) atomicAdd(&frame_sub[3 * SUB_SET + (blockIdx.x & 63u) * SUB_STRIDE], nf);
@@ -2264,7 +2298,10 @@ __global__ __launch_bounds__(PIX_BLOCK) void k_associate_direct(Model M, DevStat
     for (int w = 0; w < wave; ++w) rank += s_v[w];
     const uint32_t slot = offset + pre + rank;
     const bool room = (uint64_t)slot < (uint64_t)fp.max_vertices;       // always, by the host's capacity rule for this frame form
-    const bool wr = is_valid && !is_fused && room;
+    // sharded: the owner of the frame's segment writes every candidate this rank did not fuse (one that another rank fused
+    // is emptied again by k_shard_settle); on the other ranks every candidate slot stays empty
+    const bool wr = is_valid && !is_fused && room && (!SHARD || sh.owner != 0);
+    const bool hole = is_valid && room && (is_fused || (SHARD && sh.owner == 0));
     float3 pw = make_float3(0.f, 0.f, 0.f);
     if (wr) pw = write_new_surfel(cur, slot, L, fp);
     bounds_expand_wave(tb, wr, slot / (uint32_t)TILE, pw.x, pw.y, pw.z, (float)fp.time, false);
@@ -2272,9 +2309,9 @@ __global__ __launch_bounds__(PIX_BLOCK) void k_associate_direct(Model M, DevStat
     // <= 5 alive words and <= 2 tiles: collected in LDS, then one global atomic per word / tile (a global atomic per
     // fused pixel cost 300 us on a frame with 100 k fuses: memory-side atomics on one line serialise).
     const uint32_t blk_first = offset + pre, w_first = blk_first >> 6, t_first = blk_first / (uint32_t)TILE;
-    const uint32_t nfused_blk = s_f[0] + s_f[1] + s_f[2] + s_f[3];        // workgroup-uniform
+    const uint32_t nfused_blk = (SHARD && sh.owner == 0) ? s_v[0] + s_v[1] + s_v[2] + s_v[3] : s_f[0] + s_f[1] + s_f[2] + s_f[3];   // workgroup-uniform
     if (nfused_blk) {
-        if (is_fused && room) {
+        if (hole) {
             const uint32_t w = (slot >> 6) - w_first, bit = slot & 63u;
             atomicOr(&s_hole[w * 2u + (bit >> 5)], 1u << (bit & 31u));
             atomicAdd(&s_dead[slot / (uint32_t)TILE - t_first], 1u);
@@ -2289,6 +2326,272 @@ __global__ __launch_bounds__(PIX_BLOCK) void k_associate_direct(Model M, DevStat
         }
     }
     if (is_valid && !room) st->error = -2;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Slot-addressed sharding, last kernel of a frame: after the fused masks of all ranks were sum-reduced (gmask), every
+// rank counts the frame's fused / new pixels from the same two planes (so DevState stays identical on all ranks), the
+// owner of the frame's segment empties the slots of candidates that ANOTHER rank fused (it wrote them speculatively in
+// k_associate_direct<true>: each candidate owns its slot, so that write disturbed nothing), and block 0 replaces this
+// rank's share of the pass counters by the totals over the ranks.  The W*H conflict cap (src/GlobalModel.cpp:54-57)
+// is defined on the conflicts of ALL ranks in slot order and is not evaluated per shard: a frame that exceeds it is
+// flagged (sticky SM_E_UNSUPPORTED) instead of producing a model that could differ.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(PIX_BLOCK) void k_shard_settle(DevState *__restrict__ st, FrameParams fp,
+                                                            const uint64_t *__restrict__ validmask,
+                                                            const uint64_t *__restrict__ ownmask,
+                                                            const uint64_t *__restrict__ gmask, uint32_t nwords,
+                                                            const uint32_t *__restrict__ blk_cand,
+                                                            const uint32_t *__restrict__ grp_cand,
+                                                            uint32_t *__restrict__ frame_sub, uint64_t *__restrict__ alive,
+                                                            uint32_t *__restrict__ tile_dead, int owner, uint32_t cap_pixels)
+{
+    __shared__ uint32_t s_v[4], s_any;
+    __shared__ uint32_t s_hole[12], s_dead[2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x < 12) s_hole[threadIdx.x] = 0u;
+    if (threadIdx.x < 2) s_dead[threadIdx.x] = 0u;
+    if (threadIdx.x == 0) s_any = 0u;
+    const uint32_t word = blockIdx.x * (PIX_BLOCK / 64) + (uint32_t)wave;
+    const bool in = word < nwords;
+    const uint64_t vw = in ? validmask[word] : 0ull, gw = in ? gmask[word] : 0ull, ow = in ? ownmask[word] : 0ull;
+    const uint64_t foreign = gw & ~ow & vw;                       // fused by another rank
+    const uint32_t grp = blockIdx.x / CAND_GROUP, in_grp = blockIdx.x % CAND_GROUP;
+    uint32_t pre = 0;
+    const bool need = owner != 0;                                 // (uniform) only the owner has slots to empty
+    if (need) {
+        pre = (lane < (int)in_grp) ? blk_cand[grp * CAND_GROUP + lane] : 0u;
+        for (uint32_t g = lane; g < grp; g += 64u) pre += grp_cand[g];
+    }
+    const uint32_t offset = st->offset;
+    __syncthreads();
+    if (lane == 0) {
+        s_v[wave] = (uint32_t)__popcll(vw);
+        if (foreign) s_any = 1u;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const uint64_t conf = gmask[nwords], vis = gmask[nwords + 1], kill = gmask[nwords + 2];
+        st->conflict_count = (uint32_t)conf;
+        st->visible_count = (uint32_t)vis;
+        st->n_kill = (uint32_t)kill;
+        if (conf > (uint64_t)cap_pixels) st->error = -3;          // SM_E_UNSUPPORTED: the conflict cap would bind
+    }
+    if (lane == 0) {
+        const uint32_t nf = (uint32_t)__popcll(gw & vw), nn = (uint32_t)__popcll(vw & ~gw);
+        if (nn) atomicAdd(&frame_sub[2 * SUB_SET + (word & 63u) * SUB_STRIDE], nn);
+        if (nf) atomicAdd(&frame_sub[3 * SUB_SET + (word & 63u) * SUB_STRIDE], nf);
+    }
+    __syncthreads();
+    if (!need || s_any == 0u) return;                             // workgroup-uniform
+    pre = wave_sum_u32(pre);
+    uint32_t rank = (uint32_t)__popcll(vw & ((1ull << lane) - 1ull));
+    for (int w = 0; w < wave; ++w) rank += s_v[w];
+    const uint32_t slot = offset + pre + rank;
+    const uint32_t blk_first = offset + pre, w_first = blk_first >> 6, t_first = blk_first / (uint32_t)TILE;
+    if (((foreign >> lane) & 1ull) && (uint64_t)slot < (uint64_t)fp.max_vertices) {
+        const uint32_t w = (slot >> 6) - w_first, bit = slot & 63u;
+        atomicOr(&s_hole[w * 2u + (bit >> 5)], 1u << (bit & 31u));
+        atomicAdd(&s_dead[slot / (uint32_t)TILE - t_first], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const uint64_t m = (uint64_t)s_hole[threadIdx.x * 2u] | ((uint64_t)s_hole[threadIdx.x * 2u + 1u] << 32);
+        if (m) atomicAnd((unsigned long long *)&alive[w_first + threadIdx.x], ~m);
+    } else if (threadIdx.x < 8) {
+        const uint32_t d = s_dead[threadIdx.x - 6u];
+        if (d) atomicAdd(&tile_dead[t_first + threadIdx.x - 6u], d);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Slot-addressed sharding: physical compaction BETWEEN frames.  The single-GPU run squeezes the dead slots out and a
+// survivor's new slot is the number of live slots below it -- over ALL ranks.  Every rank contributes its alive bits
+// (non-owned and dead slots are 0), the planes are sum-reduced (disjoint bit sets: sum == union) into `galive`, and
+// each rank then moves only its own survivors:  stage (own survivors -> a second SoA set at their new slot, own bits
+// of the new alive plane), unstage (copy back, rebuild the alive words, dead counts and bounds of every tile from the
+// first moving one on).  Two plain passes instead of the in-place hand-off protocol of k_compact: this runs once per
+// `compact_period` frames, outside the frame.  info = {first moving tile, new slot count, old slot count}.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_shard_alive_copy(const DevState *__restrict__ st, const uint64_t *__restrict__ alive,
+                                                          uint64_t *__restrict__ out, uint64_t *__restrict__ new_alive,
+                                                          uint32_t nw_bound /* words the ranks exchange: the host's bound, the same on every rank */)
+{
+    const uint32_t N = st->count;
+    for (uint32_t w = blockIdx.x * 256u + threadIdx.x; w < nw_bound; w += gridDim.x * 256u) {
+        const uint64_t base = (uint64_t)w * 64u;
+        uint64_t range = 0ull;
+        if (base < N) { const uint64_t rem = (uint64_t)N - base; range = rem >= 64 ? ~0ull : ((1ull << rem) - 1ull); }
+        out[w] = alive[w] & range;
+        new_alive[w] = 0ull;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_shard_tile_popc(const DevState *__restrict__ st, const uint64_t *__restrict__ galive,
+                                                         uint32_t *__restrict__ tile_keep)
+{
+    const uint32_t N = st->count;
+    const uint32_t ntiles = (N + TILE - 1) / TILE, nw = (N + 63u) / 64u;
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave_g = (blockIdx.x * 256u + threadIdx.x) >> 6;
+    for (uint32_t t0 = wave_g * 4u; t0 < ntiles; t0 += (gridDim.x * 4u) * 4u) {      // 4 tiles per wave: 16 lanes per tile
+        const uint32_t t = t0 + (uint32_t)(lane >> 4), w = t * TILE_WORDS + (uint32_t)(lane & 15);
+        uint32_t p = (t < ntiles && w < nw) ? (uint32_t)__popcll(galive[w]) : 0u;
+        p += __shfl_xor(p, 1); p += __shfl_xor(p, 2); p += __shfl_xor(p, 4); p += __shfl_xor(p, 8);
+        if ((lane & 15) == 0 && t < ntiles) tile_keep[t] = p;
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_shard_scan(DevState *__restrict__ st, const uint32_t *__restrict__ tile_keep,
+                                                     uint32_t *__restrict__ tile_base, uint32_t *__restrict__ info,
+                                                     unsigned long long *__restrict__ host_stat)
+{
+    __shared__ uint32_t s_sum[1024], s_fm[1024];
+    const uint32_t N = st->count;
+    const uint32_t ntiles = (N + TILE - 1) / TILE;
+    const uint32_t chunk = (ntiles + 1023u) / 1024u;
+    const uint32_t b = threadIdx.x * chunk, e = min(b + chunk, ntiles);
+    uint32_t sum = 0, fm = 0xFFFFFFFFu;
+    for (uint32_t t = b; t < e; ++t) {
+        const uint32_t k = tile_keep[t];
+        if (k != (uint32_t)TILE && fm == 0xFFFFFFFFu) fm = t;
+        sum += k;
+    }
+    s_sum[threadIdx.x] = sum; s_fm[threadIdx.x] = fm;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024u; d <<= 1) {                   // inclusive Hillis-Steele scan of the chunk sums
+        const uint32_t v = threadIdx.x >= d ? s_sum[threadIdx.x - d] : 0u;
+        const uint32_t f = threadIdx.x >= d ? s_fm[threadIdx.x - d] : 0xFFFFFFFFu;
+        __syncthreads();
+        s_sum[threadIdx.x] += v; s_fm[threadIdx.x] = min(s_fm[threadIdx.x], f);
+        __syncthreads();
+    }
+    uint32_t run = threadIdx.x ? s_sum[threadIdx.x - 1] : 0u;
+    for (uint32_t t = b; t < e; ++t) { tile_base[t] = run; run += tile_keep[t]; }
+    if (threadIdx.x == 1023u) {
+        info[0] = min(s_fm[1023], ntiles);       // first tile that loses or moves surfels (== ntiles: nothing to do)
+        info[1] = s_sum[1023];                   // live surfels over all ranks = the new slot count
+        info[2] = N;
+        // publish the compacted state (k_shard_stage / k_shard_unstage take the old count from info[2], not from DevState)
+        const uint32_t Nn = s_sum[1023];
+        st->count = Nn; st->offset = Nn;
+        st->garbage = 0u; st->garbage_prev = 0u; st->holes_last = 0u;
+        st->first_live = 0u; st->fl_dirty = 0u;  // the first live surfel of the union moves to slot 0
+        if (host_stat)
+            __hip_atomic_store(host_stat, ((unsigned long long)st->stat_frames << 32) | (unsigned long long)Nn, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_shard_stage(Model M, const DevState *__restrict__ st, const uint64_t *__restrict__ alive,
+                                                     const uint64_t *__restrict__ galive, const uint32_t *__restrict__ tile_base,
+                                                     const uint32_t *__restrict__ info, uint64_t *__restrict__ new_alive)
+{
+    const SurfelSet src = M.s[st->cur], dst = M.s[st->cur ^ 1u];
+    const uint32_t fm = info[0], N = info[2];
+    const uint32_t ntiles = (N + TILE - 1) / TILE, nw = (N + 63u) / 64u;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (uint32_t t = fm + blockIdx.x; t < ntiles; t += gridDim.x) {
+        // live slots (any rank) of the tile's words below each of this wave's words
+        const uint32_t w16 = t * TILE_WORDS + (uint32_t)(lane & 15);
+        const uint32_t pc = (lane < 16 && w16 < nw) ? (uint32_t)__popcll(galive[w16]) : 0u;
+        uint32_t before = tile_base[t];
+        for (int i = 0; i < wave * 4; ++i) before += lane_bcast(pc, i);
+#pragma unroll 1
+        for (int r = 0; r < 4; ++r) {
+            const uint32_t w = t * TILE_WORDS + (uint32_t)wave * 4u + (uint32_t)r;
+            if (w >= nw) break;                                   // wave-uniform
+            const uint64_t g = galive[w];
+            const uint64_t rem = (uint64_t)N - (uint64_t)w * 64u;
+            const uint64_t own = alive[w] & g & (rem >= 64 ? ~0ull : ((1ull << rem) - 1ull));
+            const uint32_t rk = (uint32_t)__popcll(g & ((1ull << lane) - 1ull));       // rank among the word's live slots (any rank)
+            const bool mine = (own >> lane) & 1ull;
+            if (mine) {
+                const uint32_t k = w * 64u + (uint32_t)lane;
+                const uint32_t d = before + rk;
+                dst.pos_conf[d] = src.pos_conf[k];
+                dst.norm_rad[d] = src.norm_rad[k];
+                dst.color[d] = src.color[k];
+                dst.init_time[d] = src.init_time[k];
+                dst.time[d] = src.time[k];
+            }
+            // the word's survivors land in the run [before, before + popc(g)): this rank's bits of it, gathered with two wave
+            // sums (distinct bits: sum == or) and published with <= 2 atomics (an atomic per surfel serialises on the line)
+            const uint32_t lo = wave_sum_u32((mine && rk < 32u) ? (1u << rk) : 0u), hi = wave_sum_u32((mine && rk >= 32u) ? (1u << (rk - 32u)) : 0u);
+            const uint64_t run = (uint64_t)lo | ((uint64_t)hi << 32);
+            if (run && lane == 0) {
+                const uint32_t sft = before & 63u;
+                atomicOr((unsigned long long *)&new_alive[before >> 6], run << sft);
+                if (sft && (run >> (64u - sft))) atomicOr((unsigned long long *)&new_alive[(before >> 6) + 1u], run >> (64u - sft));
+            }
+            before += (uint32_t)__popcll(g);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_shard_unstage(Model M, const DevState *__restrict__ st, const uint32_t *__restrict__ info,
+                                                       const uint64_t *__restrict__ new_alive, uint64_t *__restrict__ alive,
+                                                       uint32_t *__restrict__ tile_dead, uint32_t *__restrict__ tb)
+{
+    __shared__ uint32_t s_live[4];
+    const SurfelSet dst = M.s[st->cur], src = M.s[st->cur ^ 1u];
+    const uint32_t fm = info[0], Nn = info[1], No = info[2];
+    const uint32_t ntiles_old = (No + TILE - 1) / TILE;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (uint32_t t = fm + blockIdx.x; t < ntiles_old; t += gridDim.x) {
+        if (threadIdx.x < 8) atomicExch(&tb[(size_t)t * 8 + threadIdx.x], 0u);     // empty box (memory-side, before the atomicMax below)
+        __syncthreads();
+        uint32_t live = 0;
+#pragma unroll 1
+        for (int r = 0; r < 4; ++r) {
+            const uint32_t w = t * TILE_WORDS + (uint32_t)wave * 4u + (uint32_t)r;
+            const uint64_t base = (uint64_t)w * 64u;
+            uint64_t range = 0ull;
+            if (base < Nn) { const uint64_t rem = (uint64_t)Nn - base; range = rem >= 64 ? ~0ull : ((1ull << rem) - 1ull); }
+            const uint64_t m = (base < No ? new_alive[w] : 0ull) & range;
+            const uint32_t d = w * 64u + (uint32_t)lane;
+            const bool mine = (m >> lane) & 1ull;
+            float4 pv = make_float4(0.f, 0.f, 0.f, 1.f);
+            float tl = 0.f;
+            if (mine) {
+                pv = src.pos_conf[d]; tl = src.time[d];
+                dst.pos_conf[d] = pv;
+                dst.norm_rad[d] = src.norm_rad[d];
+                dst.color[d] = src.color[d];
+                dst.init_time[d] = src.init_time[d];
+                dst.time[d] = tl;
+            }
+            bounds_expand_wave(tb, mine, t, pv.x, pv.y, pv.z, tl, !(pv.w > 0.0f));
+            if (lane == 0) alive[w] = m | ~range;                 // free slots (>= the new count) read 1
+            live += (uint32_t)__popcll(m);
+        }
+        if (lane == 0) s_live[wave] = live;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const uint64_t tb0 = (uint64_t)t * TILE;
+            const uint32_t occ = tb0 < Nn ? (uint32_t)min((uint64_t)TILE, (uint64_t)Nn - tb0) : 0u;
+            tile_dead[t] = occ - (s_live[0] + s_live[1] + s_live[2] + s_live[3]);      // slots of other ranks' surfels count as dead here
+        }
+        __syncthreads();
+    }
+}
+
+// AoS export of this rank's surfels of the (compacted) union, zeros in the slots of other ranks: the integer sum of
+// the planes of all ranks is the single GlobalModel (GlobalModel::downloadMap layout, 12 floats per surfel)
+__global__ void k_shard_export_aos(Model M, const DevState *__restrict__ st, const uint64_t *__restrict__ alive,
+                                   float *__restrict__ dst, uint32_t n)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const SurfelSet cur = M.s[st->cur];
+    float4 *o = reinterpret_cast<float4 *>(dst + (size_t)k * 12);
+    if ((alive[k >> 6] >> (k & 63u)) & 1ull) {
+        const float4 pc = cur.pos_conf[k], nr = cur.norm_rad[k];
+        o[0] = pc;
+        o[1] = make_float4(__uint_as_float(cur.color[k]), 0.0f, cur.init_time[k], cur.time[k]);
+        o[2] = nr;
+    } else {
+        o[0] = make_float4(0.f, 0.f, 0.f, 0.f); o[1] = o[0]; o[2] = o[0];
+    }
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -257,3 +257,62 @@ class ShardedMapper:
         for rk in range(w):
             assert cursor[rk] == locals_[rk].shape[0], "segment table out of step with the local model"
         return np.concatenate(parts, axis=0) if parts else np.zeros((0, 12), np.float32)
+
+
+# ---------------------------------------------------------------------------------------------
+# in-stream form: slot-addressed sharding, the whole frame inside the HIP core (sm_shard_frame*)
+# ---------------------------------------------------------------------------------------------
+class ThreadCollective:
+    """The collective of sm_shard_set_collective for G contexts driven by G threads of one process (the ranks may share one
+    GPU): staged through the host, for tests and for rehearsing the multi-rank path on a 1-GPU box.  Production uses
+    RCCL on the context's stream (SurfelMap.shard_rccl_init)."""
+
+    def __init__(self, group: ThreadGroup, rank: int, sm):
+        self.comm = ThreadComm(group, rank)
+        self.sm = sm
+
+    def __call__(self, send, recv, count, op):
+        from .capi import SM_COLL_MIN
+        a = self.sm.device_download(send, count * 8, np.uint64)          # waits for the context's stream
+        vals = self.comm._exchange(a)
+        if op == SM_COLL_MIN:
+            r = np.minimum.reduce(np.stack(vals))
+        else:
+            r = np.sum(np.stack(vals), axis=0, dtype=np.uint64)
+        self.sm.device_upload(recv, np.ascontiguousarray(r, np.uint64))
+        return 0
+
+
+class StreamShard:
+    """One rank of ONE camera stream sharded over `world` GPUs, in-stream form: every rank calls
+    process_frame with the same arguments; counters are identical on all ranks after every frame.
+
+    collective: None with world == 1 (identity), a callable (send_ptr, recv_ptr, count_u64, op) -> 0, or the string
+    "rccl" together with `rccl_id` (capi.rccl_unique_id() of one rank, handed to all)."""
+
+    def __init__(self, sm, rank: int, world: int, collective=None, rccl_id: bytes | None = None):
+        self.sm, self.rank, self.world = sm, rank, world
+        sm.shard_stream_configure(rank, world)
+        if collective == "rccl":
+            sm.shard_rccl_init(rccl_id)
+        elif collective is not None:
+            sm.shard_set_collective(collective)
+
+    def process_frame(self, rgb, depth, sem, pose):
+        self.sm.shard_frame(rgb, depth, sem, pose)
+        return self.sm.counts()
+
+    def counts(self):
+        return self.sm.counts()
+
+    def export_dense(self) -> np.ndarray:
+        """this rank's surfels at their positions in the union, zeros elsewhere (collective: it compacts)"""
+        return self.sm.shard_export_dense()
+
+    @staticmethod
+    def union(planes) -> np.ndarray:
+        """the single GlobalModel from the dense planes of all ranks (their supports are disjoint: integer sum == union)"""
+        acc = np.zeros(planes[0].shape, np.uint32)
+        for p in planes:
+            acc += np.ascontiguousarray(p, np.float32).view(np.uint32)
+        return acc.view(np.float32)

@@ -1,0 +1,132 @@
+"""In-stream form of the sharded mode (BASELINE configs[3]): slot-addressed shards, the frame entirely inside
+the HIP core, collectives on the context's stream.  G ranks = G HIP contexts on the one GPU driven by G threads with a
+host-staged collective (the multi-rank logic), and RCCL itself with world = 1 (the production binding); every variant must
+equal the single-process oracle bit for bit -- counters after every frame, the union at the end."""
+import threading
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from surfelmapping_amd import capi, sharded, synth
+
+CAM = dict(width=192, height=80, fx=110.0, fy=110.0, cx=95.5, cy=39.5)
+
+
+def _seq(n, noise_mm=3.0, seed=11):
+    return synth.make_sequence(CAM, synth.kitti_trajectory(n), seed=seed, noise_mm=noise_mm)
+
+
+def _oracle(seq, over):
+    o = ol.Oracle(ol.make_config(**CAM, **over))
+    cs = []
+    for fr in seq:
+        o.process_frame(*fr)
+        cs.append(o.counts())
+    return o.download_model(), cs
+
+
+KEYS = ("count", "offset", "conflict_count", "unstable_count", "fused_count", "data_count", "visible_count")
+
+
+def _run_threads(G, seq, over, period):
+    grp = sharded.ThreadGroup(G)
+    out, errs = [None] * G, []
+
+    def work(r):
+        try:
+            sm = capi.SurfelMap(capi.make_config(**CAM, **over, compact_period=period))
+            coll = sharded.ThreadCollective(grp, r, sm) if G > 1 else None
+            mp = sharded.StreamShard(sm, r, G, coll)
+            cs = [mp.process_frame(*fr) for fr in seq]
+            out[r] = (mp.export_dense(), cs, sm.counts())
+            sm.close()
+        except Exception as e:          # keep the other ranks from waiting forever
+            errs.append((r, repr(e)))
+            grp.barrier.abort()
+
+    ts = [threading.Thread(target=work, args=(r,)) for r in range(G)]
+    [t.start() for t in ts]
+    [t.join(600) for t in ts]
+    assert not errs, errs
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("G,period", [(1, 8), (2, 3), (4, 3), (3, 1000), (2, 1)])
+def test_stream_shards_equal_oracle(G, period):
+    over = dict(preprocess=0, stereo_border=10.0, max_sqrt_vertices=400, fuse_thresh=0.05)
+    seq = _seq(12)
+    ref, ref_counts = _oracle(seq, over)
+    out = _run_threads(G, seq, over, period)
+    for r in range(G):
+        for f, (a, b) in enumerate(zip(out[r][1], ref_counts)):
+            assert all(a[k] == b[k] for k in KEYS), (r, f, {k: (a[k], b[k]) for k in KEYS})
+    union = sharded.StreamShard.union([o[0] for o in out])
+    assert union.shape == ref.shape and ref.shape[0] > 1000
+    assert np.array_equal(union.view(np.uint32), ref.view(np.uint32))
+    assert sum(c["fused_count"] for c in ref_counts) > 500, "the sequence must exercise pixels fused on other ranks"
+    assert sum(c["conflict_count"] for c in ref_counts) > 0
+    for r in range(G):              # counters after the collective export are the union's, on every rank
+        assert out[r][2]["count"] == ref.shape[0]
+
+
+@pytest.mark.gpu
+def test_stream_shard_world1_equals_plain_path():
+    over = dict(preprocess=1, stereo_border=10.0, max_sqrt_vertices=400)
+    seq = _seq(10, noise_mm=8.0)
+    plain = capi.SurfelMap(capi.make_config(**CAM, **over))
+    sm = capi.SurfelMap(capi.make_config(**CAM, **over))
+    mp = sharded.StreamShard(sm, 0, 1)
+    for fr in seq:
+        plain.process_frame(*fr)
+        c = mp.process_frame(*fr)
+        p = plain.counts()
+        assert all(c[k] == p[k] for k in KEYS), (c, p)
+    a, b = mp.export_dense(), plain.download_model()
+    assert a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_stream_shard_rccl_world1():
+    """the production binding: ncclAllReduce on the context's stream, bound at run time; one rank"""
+    over = dict(preprocess=0, stereo_border=10.0, max_sqrt_vertices=400, fuse_thresh=0.05)
+    seq = _seq(8)
+    ref, ref_counts = _oracle(seq, over)
+    sm = capi.SurfelMap(capi.make_config(**CAM, **over, compact_period=3))
+    mp = sharded.StreamShard(sm, 0, 1, "rccl", capi.rccl_unique_id())
+    for fr, b in zip(seq, ref_counts):
+        a = mp.process_frame(*fr)
+        assert all(a[k] == b[k] for k in KEYS), (a, b)
+    got = mp.export_dense()
+    sm.shard_rccl_finalize()
+    assert got.shape == ref.shape and np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_stream_shard_conflict_cap_is_flagged():
+    """more conflicts than W*H over all ranks: the frame is flagged, not silently different"""
+    cam = dict(width=64, height=48, fx=50.0, fy=50.0, cx=31.5, cy=23.5)
+    over = dict(preprocess=0, stereo_border=0.0, max_sqrt_vertices=300)
+    sm = capi.SurfelMap(capi.make_config(**cam, **over))
+    mp = sharded.StreamShard(sm, 0, 1)
+    rng = np.random.default_rng(5)
+    W, H = cam["width"], cam["height"]
+    rgb = rng.integers(0, 255, (H, W, 3), dtype=np.uint8)
+    sem = np.full((H, W), 3, np.uint8)
+    pose = np.eye(4, dtype=np.float32).T.copy()
+    near = np.full((H, W), 4000, np.uint16)
+    plain = capi.SurfelMap(capi.make_config(**cam, **over))
+    # a model with more surfels in view than pixels: every frame a little closer than the last, so nothing conflicts or fuses
+    for k in range(6):
+        d = near - np.uint16(40 * k)
+        mp.sm.shard_frame(rgb, d, sem, pose)
+        plain.process_frame(rgb, d, sem, pose)
+    assert sm.counts()["count"] == plain.counts()["count"] > 2 * W * H
+    # then a frame far behind all of them: every surfel in view conflicts
+    far = np.full((H, W), 20000, np.uint16)
+    plain.process_frame(rgb, far, sem, pose)
+    assert plain.counts()["conflict_count"] == W * H, "the scenario must make the cap bind on the plain path"
+    with pytest.raises(capi.SurfelMapError) as ei:
+        mp.sm.shard_frame(rgb, far, sem, pose)
+    assert ei.value.rc == capi.SM_E_UNSUPPORTED
