@@ -136,7 +136,9 @@ void sm_destroy(sm_ctx *s);
  * 4x4 camera->world (Eigen::Matrix4f storage).  Inputs are borrowed for the call only. */
 int sm_process_frame(sm_ctx *s, const uint8_t *rgb, const uint16_t *depth_mm,
                      const uint8_t *semantic, const float *pose16);
-/* Same, inputs already resident in device memory of this ctx's GPU; enqueue only. */
+/* Same, inputs already resident in device memory of this ctx's GPU; enqueue only.  (One bounded exception: when the model
+ * is within one frame of MAX_VERTICES and the host has run ahead of the device, the call waits up to SM_CAPACITY_WAIT_US
+ * (default 2000) microseconds for the device's slot count before deciding whether this frame's cull must compact.) */
 int sm_process_frame_device(sm_ctx *s, const uint8_t *d_rgb, const uint16_t *d_depth_mm,
                             const uint8_t *d_semantic, const float *pose16);
 /* Wait for all enqueued work; refresh counters; returns a sticky device-side error. */
@@ -250,6 +252,12 @@ int sm_shard_cull_splat(sm_ctx *s, const uint32_t *seg_lstart_new, const uint32_
 int sm_shard_associate(sm_ctx *s, const uint32_t *gseg_base, int n_gseg);
 /* p11 on the rank that owns this frame's segment (append_here), counters everywhere; ends the frame */
 int sm_shard_append(sm_ctx *s, int append_here);
+
+/* Diagnostic: processes that hold compute queues on this context's GPU according to the KFD driver's tables (>= 1: this
+ * one included), or -1 if /sys/class/kfd is not readable.  The in-place compaction switches to its ticket-ordered form
+ * (no co-residency assumption) whenever the value is > 1 or a second context of this process shares the GPU; the value is
+ * re-read at most once per second.  SM_COMPACT_TICKETS=1 / 0 overrides the detection. */
+int sm_gpu_process_count(sm_ctx *s);
 
 /* ---- The same sharding, in-stream form: no host or Python between the stages of a frame.  Every rank
  * addresses surfels by the slot number the single-GPU run uses and stores only the segments it owns (owner of a frame's

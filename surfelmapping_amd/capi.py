@@ -29,6 +29,7 @@ SYMBOLS = (
     "sm_shard_conflict", "sm_shard_cull_splat", "sm_shard_associate", "sm_shard_append",
     "sm_shard_stream_configure", "sm_shard_set_collective", "sm_shard_rccl_unique_id", "sm_shard_rccl_init",
     "sm_shard_rccl_finalize", "sm_shard_frame_device", "sm_shard_frame", "sm_shard_compact", "sm_shard_export_dense_device",
+    "sm_gpu_process_count",
 )
 
 SM_COLL_SUM, SM_COLL_MIN = 0, 1
@@ -207,6 +208,7 @@ def load():
     L.sm_shard_frame.argtypes = [vp, vp, vp, vp, vp]
     L.sm_shard_compact.argtypes = [vp]
     L.sm_shard_export_dense_device.argtypes = [vp, C.POINTER(vp), u32p]
+    L.sm_gpu_process_count.argtypes = [vp]
     L.sm_key_map_device_ptr.restype = vp
     L.sm_key_map_device_ptr.argtypes = [vp]
     for name in SYMBOLS:
@@ -509,6 +511,10 @@ class SurfelMap:
         if n == 0:
             return np.zeros((0, 12), np.float32)
         return self.device_download(p, n * 48, np.float32).reshape(n, 12)
+
+    def gpu_process_count(self) -> int:
+        """processes with compute queues on this context's GPU per the KFD tables (this one included); -1 if unreadable"""
+        return self._L.sm_gpu_process_count(self._h)
 
     def key_map_device_ptr(self) -> int:
         return self._L.sm_key_map_device_ptr(self._h)

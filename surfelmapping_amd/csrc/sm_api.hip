@@ -7,11 +7,13 @@
 
 #include <hip/hip_runtime.h>
 
+#include <dirent.h>
 #include <dlfcn.h>
 #include <link.h>
 #include <rccl/rccl.h>      // types and enums only: the library is bound at run time (sm_shard_rccl_*), never linked
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -160,13 +162,91 @@ constexpr int MAX_DEV = 64;
 std::mutex g_compact_mu;
 int g_ctx_on_dev[MAX_DEV] = {};
 
+// Other PROCESSES on the same GPU are invisible to the counter above.  The KFD driver lists every process with its
+// queues under /sys/class/kfd/kfd/proc/<pid>/queues/<n>/gpuid (host pids: inside a container our own pid does not match,
+// so processes are only counted).  Device -> gpuid goes through the PCI address (topology/nodes/<n>/properties location_id).
+// Returns the number of processes that hold queues on this device's GPU (>= 1 once this process has a context there),
+// or -1 if the tables cannot be read.
+int kfd_processes_on_gpu(int dev)
+{
+    char bus[64] = {0};
+    if (hipDeviceGetPCIBusId(bus, sizeof bus, dev) != hipSuccess) return -1;
+    unsigned dom = 0, b = 0, d = 0, f = 0;
+    if (sscanf(bus, "%x:%x:%x.%x", &dom, &b, &d, &f) != 4) return -1;
+    const unsigned long want_loc = ((unsigned long)b << 8) | ((unsigned long)d << 3) | f;
+    unsigned long gpuid = 0;
+    bool found = false;
+    for (int n = 0; n < 64 && !found; ++n) {
+        char path[128];
+        snprintf(path, sizeof path, "/sys/class/kfd/kfd/topology/nodes/%d/properties", n);
+        FILE *fp = fopen(path, "r");
+        if (!fp) { if (n > 16) break; continue; }
+        char key[64]; unsigned long val, loc = ~0ul, domain = 0;
+        while (fscanf(fp, "%63s %lu", key, &val) == 2) {
+            if (!strcmp(key, "location_id")) loc = val;
+            else if (!strcmp(key, "domain")) domain = val;
+        }
+        fclose(fp);
+        if (loc == want_loc && domain == dom) {
+            snprintf(path, sizeof path, "/sys/class/kfd/kfd/topology/nodes/%d/gpu_id", n);
+            FILE *fg = fopen(path, "r");
+            if (fg) { found = fscanf(fg, "%lu", &gpuid) == 1 && gpuid != 0; fclose(fg); }
+        }
+    }
+    if (!found) return -1;
+    DIR *pd = opendir("/sys/class/kfd/kfd/proc");
+    if (!pd) return -1;
+    int procs = 0;
+    while (struct dirent *pe = readdir(pd)) {
+        if (pe->d_name[0] < '0' || pe->d_name[0] > '9') continue;
+        char qdir[256];
+        snprintf(qdir, sizeof qdir, "/sys/class/kfd/kfd/proc/%s/queues", pe->d_name);
+        DIR *qd = opendir(qdir);
+        if (!qd) continue;
+        bool here = false;
+        while (struct dirent *qe = readdir(qd)) {
+            if (qe->d_name[0] < '0' || qe->d_name[0] > '9') continue;
+            char gp[400];
+            snprintf(gp, sizeof gp, "%s/%s/gpuid", qdir, qe->d_name);
+            FILE *fg = fopen(gp, "r");
+            unsigned long g = 0;
+            if (fg) { if (fscanf(fg, "%lu", &g) == 1 && g == gpuid) here = true; fclose(fg); }
+            if (here) break;
+        }
+        closedir(qd);
+        if (here) ++procs;
+    }
+    closedir(pd);
+    return procs;
+}
+
+// cached per device, refreshed at most once per second (a few sysfs reads: ~0.2 ms)
+bool gpu_shared_with_other_process(int dev)
+{
+    static std::mutex mu;
+    static std::chrono::steady_clock::time_point last[MAX_DEV];
+    static int cached[MAX_DEV];
+    static bool valid[MAX_DEV] = {};
+    if (dev < 0 || dev >= MAX_DEV) return false;
+    std::lock_guard<std::mutex> lk(mu);
+    const auto now = std::chrono::steady_clock::now();
+    if (!valid[dev] || std::chrono::duration_cast<std::chrono::milliseconds>(now - last[dev]).count() > 1000) {
+        cached[dev] = kfd_processes_on_gpu(dev);
+        last[dev] = now; valid[dev] = true;
+    }
+    return cached[dev] > 1;
+}
+
 bool compaction_needs_tickets(int dev)
 {
     static const char *env = std::getenv("SM_COMPACT_TICKETS");      // "1": always, "0": never (contexts known not to overlap)
     if (env) return env[0] != '0';
     if (dev < 0 || dev >= MAX_DEV) return true;
-    std::lock_guard<std::mutex> lk(g_compact_mu);
-    return g_ctx_on_dev[dev] > 1;
+    {
+        std::lock_guard<std::mutex> lk(g_compact_mu);
+        if (g_ctx_on_dev[dev] > 1) return true;
+    }
+    return gpu_shared_with_other_process(dev);
 }
 }  // namespace
 
@@ -610,6 +690,10 @@ bool decide_compact(sm_ctx *s)
     // bound = slots at the last device update + one frame's worth of new surfels for every append enqueued since.
     // When the host has run far ahead of the device the bound is loose; rather than compacting for nothing it then
     // lets the device catch up (the queue still holds every frame in between, so the GPU stays busy).
+    // (This is the one place where an "enqueue only" call may wait, and only within one frame's worth of the capacity:
+    //  at most SM_CAPACITY_WAIT_US, default 2000 us, then it compacts instead.)
+    static const long wait_us = std::getenv("SM_CAPACITY_WAIT_US") ? std::atol(std::getenv("SM_CAPACITY_WAIT_US")) : 2000;
+    const auto t_start = std::chrono::steady_clock::now();
     for (uint32_t spins = 0;; ++spins) {
         const unsigned long long v = __atomic_load_n(s->h_stat, __ATOMIC_RELAXED);
         const uint32_t fr = (uint32_t)(v >> 32), slots = (uint32_t)v;
@@ -617,8 +701,11 @@ bool decide_compact(sm_ctx *s)
         const uint32_t ahead = s->frames_enq >= fr ? s->frames_enq - fr : 0u;
         if (s->frames_enq >= fr) bound = std::min<uint64_t>(bound, (uint64_t)slots + (uint64_t)ahead * s->n_odd_pixels);
         if (bound + s->n_odd_pixels <= s->cap) break;                  // fits even if every candidate pixel is new
-        if (ahead <= 1u || spins > (1u << 22)) return true;            // the bound is (nearly) exact: compact
+        if (ahead <= 1u) return true;                                  // the bound is (nearly) exact: compact
         if ((uint64_t)slots + 2ull * s->n_odd_pixels > s->cap) return true;   // would not fit with the device caught up either
+        if ((spins & 63u) == 63u &&
+            std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t_start).count() > wait_us)
+            return true;                                               // the device is further behind than we are willing to wait for
         std::this_thread::yield();
     }
     return s->culls_since_compact + 1 >= s->cfg.compact_period;
@@ -2008,6 +2095,12 @@ int ss_compact(sm_ctx *s)
 }  // namespace
 
 extern "C" {
+
+int sm_gpu_process_count(sm_ctx *s)
+{
+    if (!s) return SM_E_ARG;
+    return kfd_processes_on_gpu(s->cfg.device);
+}
 
 int sm_shard_stream_configure(sm_ctx *s, int rank, int world)
 {

@@ -2473,7 +2473,9 @@ __global__ __launch_bounds__(1024) void k_shard_scan(DevState *__restrict__ st, 
         info[2] = N;
         // publish the compacted state (k_shard_stage / k_shard_unstage take the old count from info[2], not from DevState)
         const uint32_t Nn = s_sum[1023];
-        st->count = Nn; st->offset = Nn;
+        // `offset` is what the reference reports between frames: the surfels that were there before the last append
+        const uint32_t live_before_append = st->offset - (st->garbage - st->holes_last);
+        st->count = Nn; st->offset = live_before_append;
         st->garbage = 0u; st->garbage_prev = 0u; st->holes_last = 0u;
         st->first_live = 0u; st->fl_dirty = 0u;  // the first live surfel of the union moves to slot 0
         if (host_stat)

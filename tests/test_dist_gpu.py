@@ -89,3 +89,40 @@ def test_second_hip_runtime_is_refused_not_undefined(tmp_path):
     f.write_text(CONFLICT)
     r = subprocess.run([sys.executable, str(f)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "CONFLICT_DETECTED" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+
+
+HOLDER = textwrap.dedent("""
+    import sys, time
+    sys.path.insert(0, "__ROOT__")
+    from surfelmapping_amd import capi
+    sm = capi.SurfelMap(capi.make_config(64, 48, 50.0, 50.0, 31.5, 23.5, max_sqrt_vertices=64))
+    print("HOLDING", flush=True)
+    sys.stdin.readline()
+""").replace("__ROOT__", ROOT)
+
+
+@pytest.mark.gpu
+def test_other_process_on_the_gpu_is_detected(tmp_path):
+    """The in-place compaction assumes its grid is resident; another PROCESS on the GPU breaks that silently.  The core
+    counts the processes with queues on its GPU in the KFD driver's tables and switches to the ticket-ordered kernel."""
+    import time
+    sys.path.insert(0, ROOT)
+    from surfelmapping_amd import capi
+    sm = capi.SurfelMap(capi.make_config(64, 48, 50.0, 50.0, 31.5, 23.5, max_sqrt_vertices=64))
+    alone = sm.gpu_process_count()
+    if alone < 0:
+        pytest.skip("/sys/class/kfd is not readable here")
+    assert alone >= 1
+    f = tmp_path / "holder.py"
+    f.write_text(HOLDER)
+    p = subprocess.Popen([sys.executable, str(f)], stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True)
+    try:
+        assert "HOLDING" in p.stdout.readline()
+        assert sm.gpu_process_count() == alone + 1
+    finally:
+        try:
+            p.communicate(input="\n", timeout=60)
+        except subprocess.TimeoutExpired:
+            p.kill()
+    time.sleep(0.2)
+    assert sm.gpu_process_count() == alone

@@ -130,3 +130,85 @@ def test_stream_shard_conflict_cap_is_flagged():
     with pytest.raises(capi.SurfelMapError) as ei:
         mp.sm.shard_frame(rgb, far, sem, pose)
     assert ei.value.rc == capi.SM_E_UNSUPPORTED
+
+
+def _run_threads_script(G, seq, over, period, script):
+    """like _run_threads, but every rank runs `script(mp, sm, seq)` (the same call sequence on all ranks)"""
+    grp = sharded.ThreadGroup(G)
+    out, errs = [None] * G, []
+
+    def work(r):
+        try:
+            sm = capi.SurfelMap(capi.make_config(**CAM, **over, compact_period=period))
+            mp = sharded.StreamShard(sm, r, G, sharded.ThreadCollective(grp, r, sm) if G > 1 else None)
+            out[r] = script(mp, sm, seq)
+            sm.close()
+        except Exception as e:
+            errs.append((r, repr(e)))
+            grp.barrier.abort()
+
+    ts = [threading.Thread(target=work, args=(r,)) for r in range(G)]
+    [t.start() for t in ts]
+    [t.join(600) for t in ts]
+    assert not errs, errs
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("G", [2, 3])
+def test_stream_shards_export_midway_then_continue(G):
+    """a collective export (it compacts) in the middle of the stream, an explicit sm_shard_compact, the depth filter chain on"""
+    over = dict(preprocess=1, stereo_border=10.0, max_sqrt_vertices=400, fuse_thresh=0.05)
+    seq = _seq(14, noise_mm=2.0, seed=23)
+    o = ol.Oracle(ol.make_config(**CAM, **over))
+    mids = {}
+    for k, fr in enumerate(seq):
+        o.process_frame(*fr)
+        if k == 6:
+            mids["model"] = o.download_model()
+    ref = o.download_model()
+
+    def script(mp, sm, seq):
+        for k, fr in enumerate(seq):
+            mp.process_frame(*fr)
+            if k == 6:
+                mid = mp.export_dense()
+            if k == 9:
+                sm.shard_compact()
+        return mid, mp.export_dense(), sm.counts()
+
+    out = _run_threads_script(G, seq, over, 5, script)
+    mid = sharded.StreamShard.union([x[0] for x in out])
+    fin = sharded.StreamShard.union([x[1] for x in out])
+    assert mid.shape == mids["model"].shape and np.array_equal(mid.view(np.uint32), mids["model"].view(np.uint32))
+    assert fin.shape == ref.shape and np.array_equal(fin.view(np.uint32), ref.view(np.uint32))
+    oc = o.counts()
+    for x in out:
+        assert all(x[2][k] == oc[k] for k in KEYS), (x[2], oc)
+
+
+@pytest.mark.gpu
+def test_stream_shards_under_capacity_pressure():
+    """slots (live + dead) approach MAX_VERTICES: the schedule must compact early, identically on every rank, and the result
+    stays the oracle's as long as the surfels themselves fit"""
+    over = dict(preprocess=0, stereo_border=10.0, fuse_thresh=0.05)
+    seq = _seq(14, noise_mm=2.0, seed=29)
+    o = ol.Oracle(ol.make_config(**CAM, **over, max_sqrt_vertices=400))
+    for fr in seq:
+        o.process_frame(*fr)
+    ref = o.download_model()
+    n = ref.shape[0]
+    side = int(np.ceil(np.sqrt(n + CAM["width"] * CAM["height"] // 2 + 2048)))        # room for the model + one frame of candidates, little more
+    o2 = ol.Oracle(ol.make_config(**CAM, **over, max_sqrt_vertices=side))
+    for fr in seq:
+        o2.process_frame(*fr)
+    assert np.array_equal(o2.download_model().view(np.uint32), ref.view(np.uint32))
+
+    def script(mp, sm, seq):
+        for fr in seq:
+            mp.process_frame(*fr)
+        return mp.export_dense(), sm.counts()
+
+    out = _run_threads_script(2, seq, dict(over, max_sqrt_vertices=side), 1000, script)
+    fin = sharded.StreamShard.union([x[0] for x in out])
+    assert fin.shape == ref.shape and np.array_equal(fin.view(np.uint32), ref.view(np.uint32))
