@@ -44,6 +44,39 @@ def test_single_disc_far_mode(backend):
     assert sem[0, 0] == 0 and tuple(bgr[0, 0]) == (0, 0, 0)
 
 
+def _disc_80():
+    """Pixels (i, j) of a 32x32 image whose centres (i + 0.5, j + 0.5) lie within 5 px of (16, 16).  By hand: per quadrant
+    the half-integer offsets a = 0.5 .. 4.5 admit b <= 4.5, 4.5, 3.5, 3.5, 1.5 (a^2 + b^2 <= 25), i.e. 5+5+4+4+2 = 20
+    pixels, 80 in all; a^2 + b^2 is never exactly 25 for half-integers (nearest: 24.5 inside, 26.5 outside), so the set does
+    not depend on rounding."""
+    m = np.zeros((32, 32), bool)
+    for j in range(32):
+        for i in range(32):
+            m[j, i] = (i + 0.5 - 16.0) ** 2 + (j + 0.5 - 16.0) ** 2 <= 25.0
+    assert m.sum() == 80
+    return m
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("mode", ["far", "near"])
+def test_K17_exact_disc_footprint(backend, mode):
+    """Hand-derived from draw_image_adaptive.geom:44-81 + draw_image.frag:13.  Far mode (z > 5): tmpNorm = (0,0,1) gives
+    x = (-r sqrt2, 0, 0), y = cross(tmpNorm, x) = (0, -r sqrt2, 0); the strip P+x, P+y, P-y, P-x carries texcoords
+    (-1,-1), (1,-1), (-1,1), (1,1), an affine map with |texcoord|^2 = (dx^2 + dy^2) / r^2, so the fragments kept are the
+    pixel centres within r of P: f r / z = 100 * 0.5 / 10 = 5 px around (cx, cy) = (16, 16).  Near mode (z <= 5) with a
+    fronto-parallel normal: cos = 1, radius = r / 1.5, the same construction: 100 * (0.3 / 1.5) / 4 = 5 px."""
+    o = make(backend, 32, 32, 100.0, 100.0, 16.0, 16.0, preprocess=0, stereo_border=0.0)
+    if mode == "far":
+        o.upload_model(np.stack([surfel(0.0, 0.0, 10.0, 0.5, n=(0.6, 0.0, 0.8), sem=4, rgb=(11, 22, 33))]))
+    else:
+        o.upload_model(np.stack([surfel(0.0, 0.0, 4.0, 0.3, n=(0.0, 0.0, 1.0), sem=4, rgb=(11, 22, 33))]))
+    bgr, sem = o.render_image(IDENT, 32, 32, 100.0, 100.0, 16.0, 16.0)
+    want = _disc_80()
+    assert np.array_equal(sem == 5, want)                       # class + 1 exactly on the disc
+    assert np.all(sem[~want] == 0) and np.all(bgr[~want] == 0)
+    assert np.all(bgr[want] == np.array([33, 22, 11], np.uint8))  # B, G, R
+
+
 @pytest.mark.parametrize("backend", BACKENDS)
 def test_depth_test_and_range(backend):
     o = mk(backend)
