@@ -28,12 +28,12 @@ OVER = dict(preprocess=0, stereo_border=12.0, max_sqrt_vertices=500)
 N_FRAMES = 5
 
 
-def rank_stream(rank, world):
+def rank_stream(rank, world, cam=None, n_frames=None):
     """camera `rank` of the rig: same forward motion, yawed by rank * 12 degrees (overlapping fields of view, so that the
     cameras see each other's surfels).  Every camera looks at its own set of parked cars (boxes): a car only one camera has
     seen is contradicted by the others' depth -- the situation the cross-camera conflict pass is for."""
-    poses = [synth.pose_matrix(0.0, 0.0, 0.6 * k, 12.0 * rank + 0.4 * math.sin(k)) for k in range(N_FRAMES)]
-    return synth.make_sequence(CAM, poses, seed=41, noise_mm=4.0 + rank, scene=synth.Scene(41 + rank, n_boxes=12, length=22.0))
+    poses = [synth.pose_matrix(0.0, 0.0, 0.6 * k, 12.0 * rank + 0.4 * math.sin(k)) for k in range(n_frames or N_FRAMES)]
+    return synth.make_sequence(cam or CAM, poses, seed=41, noise_mm=4.0 + rank, scene=synth.Scene(41 + rank, n_boxes=12, length=22.0))
 
 
 class OracleRigBackend:
@@ -59,19 +59,20 @@ class OracleRigBackend:
         self.L.smo_set_exempt_id(self.o._h, 0)
 
 
-def definition(world):
+def definition(world, cam=None, over=None, n_frames=None):
     """the single GlobalModel by its definition, on one oracle: union in rank order, cleanPoints per view in rank order"""
     slices, views = [], []
+    CAM_, OVER_, NF = cam or CAM, over or OVER, n_frames or N_FRAMES
     for r in range(world):
-        o = ol.Oracle(ol.make_config(**CAM, **OVER))
-        seq = rank_stream(r, world)
+        o = ol.Oracle(ol.make_config(**CAM_, **OVER_))
+        seq = rank_stream(r, world, CAM_, NF)
         for fr in seq:
             o.process_frame(*fr)
         slices.append(o.download_model())
         views.append(seq[-1][1:])
-    g = ol.Oracle(ol.make_config(**CAM, **dict(OVER, max_sqrt_vertices=1200)))
+    g = ol.Oracle(ol.make_config(**CAM_, **dict(OVER_, max_sqrt_vertices=int(math.ceil(math.sqrt(sum(x.shape[0] for x in slices)))) + 8)))
     g.upload_model(np.concatenate(slices, axis=0))
-    g.set_tick(N_FRAMES)
+    g.set_tick(NF)
     conflicts = []
     for depth, sem, pose in views:
         g.clean_points(depth, sem, pose)
@@ -79,14 +80,15 @@ def definition(world):
     return g.download_model(), [s.shape[0] for s in slices], conflicts
 
 
-def run_threads(world, make_backend):
+def run_threads(world, make_backend, cam=None, n_frames=None):
     group = sharded.ThreadGroup(world)
     out, err = [None] * world, []
+    CAM_ = cam or CAM
 
     def work(r):
         try:
-            mp = smd.RigMapper(make_backend(r), sharded.ThreadComm(group, r), CAM["width"] * CAM["height"])
-            for fr in rank_stream(r, world):
+            mp = smd.RigMapper(make_backend(r), sharded.ThreadComm(group, r), CAM_["width"] * CAM_["height"])
+            for fr in rank_stream(r, world, CAM_, n_frames):
                 mp.process_frame(*fr)
             out[r] = mp.consolidate()
         except BaseException as e:          # a failing rank must not leave the others waiting at the barrier
@@ -103,8 +105,8 @@ def run_threads(world, make_backend):
     return out
 
 
-def check(out, world):
-    model, sizes, conflicts = definition(world)
+def check(out, world, cam=None, over=None, n_frames=None):
+    model, sizes, conflicts = definition(world, cam, over, n_frames)
     assert sum(conflicts) > 50, conflicts                      # the views do clean each other's surfels
     assert model.shape[0] < sum(sizes)
     for r in range(world):
@@ -124,6 +126,17 @@ def test_rig_consolidation_oracle_ranks_in_threads(world):
 def test_rig_consolidation_hip_contexts_equal_the_definition(world):
     from surfelmapping_amd import capi
     check(run_threads(world, lambda r: capi.SurfelMap(capi.make_config(**CAM, **OVER))), world)
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_rig_two_cameras_at_1920x1080():
+    """the image size of BASELINE configs[4] (8 x 1920x1080, one camera per GPU), two of the cameras as two HIP contexts on
+    the one GPU: three frames each, then the consolidation into a single GlobalModel, against the one-oracle definition"""
+    from surfelmapping_amd import capi
+    cam = dict(synth.HD)
+    over = dict(preprocess=0, stereo_border=12.0, max_sqrt_vertices=2200)
+    check(run_threads(2, lambda r: capi.SurfelMap(capi.make_config(**cam, **over)), cam, 3), 2, cam, over, 3)
 
 
 # ---------------------------------------------------------------- 2 gloo processes (torch.distributed on host arrays)

@@ -212,3 +212,43 @@ def test_stream_shards_under_capacity_pressure():
     out = _run_threads_script(2, seq, dict(over, max_sqrt_vertices=side), 1000, script)
     fin = sharded.StreamShard.union([x[0] for x in out])
     assert fin.shape == ref.shape and np.array_equal(fin.view(np.uint32), ref.view(np.uint32))
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_stream_shards_kitti_size():
+    """BASELINE configs[3]'s image size (1242x375): one stream over two ranks (two HIP contexts on the one GPU), six frames
+    with fuses and conflicts, one compaction between frames; counters every frame and the union against the oracle"""
+    cam = dict(synth.KITTI)
+    over = dict(preprocess=0, fuse_thresh=0.05, max_sqrt_vertices=1500)
+    seq = synth.make_sequence(cam, synth.kitti_trajectory(6), seed=5, noise_mm=4.0)
+    o = ol.Oracle(ol.make_config(**cam, **over))
+    ref_counts = []
+    for fr in seq:
+        o.process_frame(*fr)
+        ref_counts.append(o.counts())
+    ref = o.download_model()
+    assert sum(c["fused_count"] for c in ref_counts) > 50000
+    grp = sharded.ThreadGroup(2)
+    out, errs = [None, None], []
+
+    def work(r):
+        try:
+            sm = capi.SurfelMap(capi.make_config(**cam, **over, compact_period=4))
+            mp = sharded.StreamShard(sm, r, 2, sharded.ThreadCollective(grp, r, sm))
+            cs = [mp.process_frame(*fr) for fr in seq]
+            out[r] = (mp.export_dense(), cs)
+            sm.close()
+        except Exception as e:
+            errs.append((r, repr(e)))
+            grp.barrier.abort()
+
+    ts = [threading.Thread(target=work, args=(r,)) for r in range(2)]
+    [t.start() for t in ts]
+    [t.join(600) for t in ts]
+    assert not errs, errs
+    for r in range(2):
+        for f, (a, b) in enumerate(zip(out[r][1], ref_counts)):
+            assert all(a[k] == b[k] for k in KEYS), (r, f, {k: (a[k], b[k]) for k in KEYS})
+    union = sharded.StreamShard.union([x[0] for x in out])
+    assert union.shape == ref.shape and np.array_equal(union.view(np.uint32), ref.view(np.uint32))
