@@ -1599,7 +1599,7 @@ template <bool READY, int NW>
 __global__ __launch_bounds__(256) void k_surfel_pass(Model M, DevState *__restrict__ st, FrameParams fp,
                                                      const uint2 *__restrict__ dcT, uint64_t *__restrict__ cm,
                                                      uint64_t *__restrict__ km, uint4 *__restrict__ wave_cnt,
-                                                     const uint32_t *__restrict__ tb, uint8_t *__restrict__ tile_flags,
+                                                     uint32_t *__restrict__ tb, uint8_t *__restrict__ tile_flags,
                                                      uint4 *__restrict__ part /* [grid] (visible, splat-skipped, killed, conflict-skipped) */,
                                                      uint64_t *__restrict__ alive, uint32_t *__restrict__ tile_dead,
                                                      uint32_t *__restrict__ conf_sub, uint64_t *__restrict__ keyT,
@@ -1656,6 +1656,9 @@ __global__ __launch_bounds__(256) void k_surfel_pass(Model M, DevState *__restri
             if (!READY && threadIdx.x == 0) wave_cnt[tile] = make_uint4(0u, 0u, 0u, 0u);
             continue;
         }
+        // the tile can reach the index map, so its surfels can be fused in this frame (k_associate_direct leaves the box's time
+        // word to this kernel): stamp it -- "in view now" is never older than the last update of any of its surfels
+        if (!sk1 && threadIdx.x == 0) atomicMax(&tb[(size_t)tile * 8 + 7], f2ord((float)fp.time));
         pass_quarter<NW>(set, st, fp, dcT, cm, km, wave_cnt, alive, tile_dead, keyT, undo, N, exempt, tile, wave, sk0, sk1,
                          lane_bcast(m_dead, sl) != 0u, lane, acc);
     }
@@ -2069,6 +2072,65 @@ __device__ __forceinline__ bool local_surfel(int q, const FrameParams &fp, const
     return true;
 }
 
+// Where a fused surfel went (for the tile-bounds update)
+struct FuseMove { uint32_t id; float x, y, z; };
+
+// Tile boxes of the surfels a workgroup fused (k_associate_direct), grown through a small LDS table: every fused lane finds
+// its tile's slot (hash + linear probing, LDS compare-and-swap on the tag) and applies six LDS atomicMax; after a barrier
+// the used slots go out with one atomicMax per word that actually grows -- rare: a fused surfel seldom leaves its tile's
+// box.  The box's time word is not touched here: k_surfel_pass, which always precedes this kernel, stamps every tile it
+// visits for the index map with the frame's time (one atomic per tile from the workgroup that owns it), and only such
+// tiles can hold a surfel that is fused in this frame.  Measured on a frame with 99 k fuses (this kernel, us): per fused
+// lane eight loads of the box + compares + atomics 45; wave-level groups by tile with DPP reductions 30 (a wave's 64 pixels
+// fuse into surfels of ~8 tiles, every group a serial round); this table with the time word in it 28 (every workgroup
+// saw a stale time and sent the atomic: ~14 per tile line at ~0.2 us each); seven blind global atomics per lane 135; no
+// update at all 17.6.  nfused_blk is workgroup-uniform; no-op (no barrier) when it is 0.
+constexpr uint32_t FB_SLOTS = 64u, FB_EMPTY = 0xFFFFFFFFu;
+__device__ __forceinline__ void fuse_bounds_block(uint32_t *__restrict__ tb, bool is_fused, const FuseMove &mv,
+                                                  uint32_t nfused_blk, uint32_t *s_tag /* [FB_SLOTS] */, uint32_t *s_box /* [FB_SLOTS * 8] */)
+{
+    if (nfused_blk == 0u) return;
+    for (uint32_t i = threadIdx.x; i < FB_SLOTS; i += blockDim.x) s_tag[i] = FB_EMPTY;
+    for (uint32_t i = threadIdx.x; i < FB_SLOTS * 8u; i += blockDim.x) s_box[i] = 0u;
+    __syncthreads();
+    if (is_fused) {
+        const uint32_t tile = mv.id / (uint32_t)TILE;
+        const uint32_t ox = f2ord(mv.x), oy = f2ord(mv.y), oz = f2ord(mv.z);
+        const bool bad = mv.x != mv.x || mv.y != mv.y || mv.z != mv.z;
+        uint32_t h = (tile * 0x9E3779B1u) >> 26;
+        int slot = -1;
+#pragma unroll 1
+        for (int probe = 0; probe < 8; ++probe) {
+            const uint32_t sidx = (h + (uint32_t)probe) & (FB_SLOTS - 1u);
+            const uint32_t old = atomicCAS(&s_tag[sidx], FB_EMPTY, tile);
+            if (old == FB_EMPTY || old == tile) { slot = (int)sidx; break; }
+        }
+        if (slot >= 0) {
+            uint32_t *b = s_box + (uint32_t)slot * 8u;
+            atomicMax(&b[0], ~ox); atomicMax(&b[1], ~oy); atomicMax(&b[2], ~oz);
+            atomicMax(&b[4], ox); atomicMax(&b[5], oy); atomicMax(&b[6], oz);
+            if (bad) atomicAdd(&b[3], 1u);
+        } else {                                     // more than a handful of colliding tiles: straight to memory (rare)
+            uint32_t *b = tb + (size_t)tile * 8;
+            if (~ox > b[0]) atomicMax(&b[0], ~ox);
+            if (~oy > b[1]) atomicMax(&b[1], ~oy);
+            if (~oz > b[2]) atomicMax(&b[2], ~oz);
+            if (ox > b[4]) atomicMax(&b[4], ox);
+            if (oy > b[5]) atomicMax(&b[5], oy);
+            if (oz > b[6]) atomicMax(&b[6], oz);
+            if (bad) atomicAdd(&b[3], 1u);
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < FB_SLOTS * 8u; i += blockDim.x) {
+        const uint32_t tile = s_tag[i >> 3], w = i & 7u, v = s_box[i];
+        if (tile == FB_EMPTY || v == 0u) continue;
+        uint32_t *g = tb + (size_t)tile * 8 + w;
+        if (w == 3u) atomicAdd(g, v);
+        else if (v > *g) atomicMax(g, v);
+    }
+}
+
 // Association + in-place fuse (p8 + p9 + p10) of pixel q.  Every surfel id occupies at most one
 // key-map pixel, so the read-modify-write of surfel `id` by this thread is race-free.
 // Returns is_valid (candidate pixel) / is_fused (matched and fused into an existing surfel);
@@ -2079,7 +2141,8 @@ __device__ __forceinline__ void associate_pixel(int q, const SurfelSet &cur, con
                                                 const float *__restrict__ ys, const uint32_t *__restrict__ gseg_base,
                                                 const uint32_t *__restrict__ seg_lstart, LocalSurfel &L, bool &is_valid,
                                                 bool &is_fused, uint32_t *__restrict__ tb, uint32_t first_live,
-                                                const uint64_t *__restrict__ own_alive = nullptr /* slot-addressed sharding: this rank's alive bits */)
+                                                const uint64_t *__restrict__ own_alive = nullptr /* slot-addressed sharding: this rank's alive bits */,
+                                                FuseMove *mv = nullptr /* given: the caller grows the tile boxes (fuse_bounds_block) */)
 {
     is_valid = false;
     is_fused = false;
@@ -2154,13 +2217,11 @@ __device__ __forceinline__ void associate_pixel(int q, const SurfelSet &cur, con
             }
         }
     }
-    // The fused surfels moved: grow their tiles' boxes.  Wave-level (every lane of the wave reaches this point): lanes are
-    // grouped by tile, each group reduces its box with DPP and publishes it with ONE atomicMax wave instruction (lanes 0..7).
-    // Measured on a frame with 99 k fuses (k_associate_direct, us): per fused lane -- eight loads of the box, compares,
-    // atomics -- 45; this form 30; the same with a compare against the current box before each atomic 33; a per-workgroup
-    // LDS table (hash + CAS, seven LDS atomicMax per lane, checked flush) 28; seven blind global atomics per fused lane 135
-    // (atomics to one 128-byte line serialise at ~0.2 us each); no update at all 17.6.
-    bounds_expand_wave(tb, is_fused, f_id / (uint32_t)TILE, f_x, f_y, f_z, (float)fp.time, false);
+    // The fused surfels moved: their tiles' boxes must grow.  k_associate_direct does it per workgroup (fuse_bounds_block: it
+    // passes mv); the other forms wave-level: lanes grouped by tile, each group reduces its box with DPP and publishes it
+    // with ONE atomicMax wave instruction (lanes 0..7).
+    if (mv) { mv->id = f_id; mv->x = f_x; mv->y = f_y; mv->z = f_z; }
+    else bounds_expand_wave(tb, is_fused, f_id / (uint32_t)TILE, f_x, f_y, f_z, (float)fp.time, false);
 }
 
 // data.vert:210-225: the new surfel of a valid, unmatched pixel, written to model slot `slot`
@@ -2244,6 +2305,7 @@ __global__ __launch_bounds__(PIX_BLOCK) void k_associate_direct(Model M, DevStat
 {
     __shared__ uint32_t s_v[4], s_n[4], s_f[4];
     __shared__ uint32_t s_hole[12], s_dead[2];          // empty slots of this block: 6 alive words (lo, hi), 2 tiles
+    __shared__ uint32_t s_tag[FB_SLOTS], s_box[FB_SLOTS * 8];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x < 12) s_hole[threadIdx.x] = 0u;
     if (threadIdx.x < 2) s_dead[threadIdx.x] = 0u;
@@ -2257,8 +2319,9 @@ __global__ __launch_bounds__(PIX_BLOCK) void k_associate_direct(Model M, DevStat
     const int q = blockIdx.x * PIX_BLOCK + threadIdx.x;
     bool is_valid, is_fused;
     LocalSurfel L;
+    FuseMove mv;
     associate_pixel(q, cur, fp, depthT, rgbsT, keyT, xs, ys, nullptr, nullptr, L, is_valid, is_fused, tb, st->first_live,
-                    SHARD ? alive : nullptr);
+                    SHARD ? alive : nullptr, &mv);
     const uint64_t vw = __ballot(is_valid), fw = __ballot(is_fused);
     if (lane == 0) { s_v[wave] = (uint32_t)__popcll(vw); s_n[wave] = (uint32_t)__popcll(vw & ~fw); s_f[wave] = (uint32_t)__popcll(fw); }
     if (SHARD && lane == 0) {
@@ -2292,6 +2355,7 @@ __global__ __launch_bounds__(PIX_BLOCK) void k_associate_direct(Model M, DevStat
         if (nn) atomicAdd(&frame_sub[2 * SUB_SET + (blockIdx.x & 63u) * SUB_STRIDE], nn);
         if (nf) atomicAdd(&frame_sub[3 * SUB_SET + (blockIdx.x & 63u) * SUB_STRIDE], nf);
     }
+    fuse_bounds_block(tb, is_fused, mv, s_f[0] + s_f[1] + s_f[2] + s_f[3], s_tag, s_box);
     uint32_t rank = (uint32_t)__popcll(vw & ((1ull << lane) - 1ull));
     for (int w = 0; w < wave; ++w) rank += s_v[w];
     const uint32_t slot = offset + pre + rank;
