@@ -351,6 +351,8 @@ struct sm_ctx {
     void *ss_comm = nullptr;           // ncclComm_t when the built-in RCCL binding is used
     uint64_t *d_galive = nullptr, *d_new_alive = nullptr, *d_gmask = nullptr;
     uint32_t *d_ss_info = nullptr;
+    bool ss_settle_pending = false;    // the last sharded frame's k_shard_settle work rides on the next k_prep (or runs stand-alone first)
+    ShardSettle ss_settle{};
     int n_pix_blocks = 0;
     uint32_t n_odd_pixels = 0;
     // export staging
@@ -458,6 +460,11 @@ int push_state(sm_ctx *s)
 // frame's k_pass_fixup; everything else that reads them asks for the completion first
 int finalize_if_pending(sm_ctx *s)
 {
+    if (s->ss_settle_pending) {          // a sharded frame whose settle step has not run yet: stand-alone, before anything reads its results
+        s->ss_settle_pending = false;
+        hipLaunchKernelGGL(k_shard_settle, dim3(s->ss_settle.n), dim3(PIX_BLOCK), 0, s->stream, s->ss_settle);
+        HIPCK(hipGetLastError());
+    }
     if (!s->pend_finalize) return SM_OK;
     s->pend_finalize = false;
     hipLaunchKernelGGL(k_frame_finalize, dim3(1), dim3(256), 0, s->stream, s->d_state, s->d_frame_sub,
@@ -518,9 +525,13 @@ int launch_prep(sm_ctx *s, const uint8_t *rgb, const uint16_t *raw, const uint8_
         tp.st = s->d_state; tp.tb = s->d_tb; tp.tile_flags = s->d_tile_flags; tp.wave_cnt = s->d_wave_cnt; tp.prep_part = s->d_prep_part;
         s->n_prep_blocks = tp.nfb;
     }
+    // the previous frame of a sharded stream is finished by extra workgroups of this launch (on the main stream only)
+    ShardSettle ss;
+    memset(&ss, 0, sizeof ss);
+    if (s->ss_settle_pending && (!st || st == s->stream)) { ss = s->ss_settle; s->ss_settle_pending = false; }
     // a frame's k_prep (clear_keys) also zeroes the conflict sub-counters of that frame (set chosen by begin_frame)
-    hipLaunchKernelGGL(k_prep, dim3(tiles + tp.nfb), dim3(1024), 0, st ? st : s->stream, rgb, raw, sem, dm, s->d_depthT, s->d_rgbsT,
-                       clear_keys ? s->d_keyT : nullptr, fp, s->d_dcT, clear_keys ? s->d_conf_sub + SUB_SET * s->conf_sub_set : nullptr, tp);
+    hipLaunchKernelGGL(k_prep, dim3(tiles + tp.nfb + (ss.n + 3u) / 4u), dim3(1024), 0, st ? st : s->stream, rgb, raw, sem, dm, s->d_depthT, s->d_rgbsT,
+                       clear_keys ? s->d_keyT : nullptr, fp, s->d_dcT, clear_keys ? s->d_conf_sub + SUB_SET * s->conf_sub_set : nullptr, tp, ss);
     HIPCK(hipGetLastError());
     return SM_OK;
 }
@@ -1612,9 +1623,11 @@ int sm_set_frame(sm_ctx *s, const uint8_t *rgb, const float *depth_metric, const
     const int tiles = ((s->W + 31) / 32) * ((s->H + 31) / 32);
     TilePrep tp;
     memset(&tp, 0, sizeof tp);
+    ShardSettle ss;
+    memset(&ss, 0, sizeof ss);
     hipLaunchKernelGGL(k_prep, dim3(tiles), dim3(1024), 0, s->stream, s->d_rgb, (const uint16_t *)nullptr, s->d_sem,
                        depth_metric ? s->d_depth_f32 : nullptr, depth_metric ? s->d_depthT : nullptr, s->d_rgbsT,
-                       (uint64_t *)nullptr, fp, s->d_dcT, (uint32_t *)nullptr, tp);
+                       (uint64_t *)nullptr, fp, s->d_dcT, (uint32_t *)nullptr, tp, ss);
     HIPCK(hipGetLastError());
     HIPCK(hipStreamSynchronize(s->stream));
     return SM_OK;
@@ -2231,10 +2244,14 @@ int sm_shard_frame_device(sm_ctx *s, const uint8_t *d_rgb, const uint16_t *d_dep
     HIPCK(hipGetLastError());
     if ((rc = mark(s, 5, true))) return rc;
     if ((rc = ss_collective(s, s->d_gmask, s->d_gmask, (size_t)sh.nwords + 4, SM_COLL_SUM))) return rc;   // in place, like the key map
-    hipLaunchKernelGGL(k_shard_settle, dim3(s->n_pix_blocks), dim3(PIX_BLOCK), 0, s->stream, s->d_state, fp, s->d_validmask, s->d_fusedmask,
-                       s->d_gmask, sh.nwords, s->d_blk_cand, s->d_grp_cand, s->d_frame_sub, s->d_alive, s->d_tile_dead, sh.owner,
-                       s->cfg.conflict_cap ? (uint32_t)s->P : 0xFFFFFFFFu);
-    HIPCK(hipGetLastError());
+    // the frame's last step (counts from the reduced mask, the owner's foreign-fused slots, the totals over the ranks) is
+    // only needed by the next frame's surfel pass: it rides on that frame's k_prep (finalize_if_pending runs it earlier if asked)
+    ShardSettle &ss = s->ss_settle;
+    ss.n = (uint32_t)s->n_pix_blocks; ss.st = s->d_state; ss.validmask = s->d_validmask; ss.ownmask = s->d_fusedmask; ss.gmask = s->d_gmask;
+    ss.nwords = sh.nwords; ss.blk_cand = s->d_blk_cand; ss.grp_cand = s->d_grp_cand; ss.frame_sub = s->d_frame_sub; ss.alive = s->d_alive;
+    ss.tile_dead = s->d_tile_dead; ss.owner = sh.owner; ss.cap_pixels = s->cfg.conflict_cap ? (uint32_t)s->P : 0xFFFFFFFFu; ss.max_vertices = s->cap;
+    s->ss_settle_pending = true;
+    if (std::getenv("SM_SHARD_SETTLE_NOW")) { s->pend_finalize = false; if ((rc = finalize_if_pending(s))) return rc; }   // A/B: settle as its own launch
     if ((rc = mark(s, 6, true)) || (rc = mark(s, 7, true))) return rc;
     s->lazy_part_live = false;
     s->fix_part_live = false;

@@ -182,6 +182,99 @@ __device__ __forceinline__ void tile_prep_block(const FrameParams &fp, const Til
     }
 }
 
+constexpr int CAND_GROUP = 16;      // association blocks per candidate-counting workgroup (16 pixels per thread, all loads in flight together)
+
+// ---------------------------------------------------------------------------------------------
+// Slot-addressed sharding, the end of a frame: after the fused masks of all ranks were sum-reduced (gmask),
+// every rank counts the frame's fused / new pixels from the same two planes (so DevState stays identical on all ranks), the
+// owner of the frame's segment empties the slots of candidates that ANOTHER rank fused (it wrote them speculatively in
+// k_associate_direct<true>: each candidate owns its slot, so that write disturbed nothing), and block 0 replaces this
+// rank's share of the pass counters by the totals over the ranks.  The W*H conflict cap (src/GlobalModel.cpp:54-57)
+// is defined on the conflicts of ALL ranks in slot order and is not evaluated per shard: a frame that exceeds it is
+// flagged (sticky SM_E_UNSUPPORTED) instead of producing a model that could differ.
+// Nothing but the NEXT frame's surfel pass needs this done, so it normally runs as extra workgroups of that frame's
+// k_prep (one launch less per frame); k_shard_settle is the stand-alone form for everything that reads the counters first.
+// ---------------------------------------------------------------------------------------------
+struct ShardSettle {
+    uint32_t n;                       // pixel blocks to settle (0: nothing pending) -- as extra workgroups of the next frame's k_prep, or k_shard_settle
+    DevState *st;
+    const uint64_t *validmask, *ownmask, *gmask;
+    uint32_t nwords;
+    const uint32_t *blk_cand, *grp_cand;
+    uint32_t *frame_sub;
+    uint64_t *alive;
+    uint32_t *tile_dead;
+    int owner;
+    uint32_t cap_pixels, max_vertices;
+};
+
+// NSUB pixel blocks per workgroup (blockDim.x == NSUB * 256): sub-block = threadIdx.x / 256.  No early exit: every thread
+// reaches every barrier.
+template <int NSUB>
+__device__ __forceinline__ void shard_settle_body(const ShardSettle &a, uint32_t wg)
+{
+    __shared__ uint32_t s_v[NSUB][4], s_any[NSUB];
+    __shared__ uint32_t s_hole[NSUB][12], s_dead[NSUB][2];
+    const uint32_t sub = threadIdx.x >> 8, tid = threadIdx.x & 255u;
+    const int lane = (int)(tid & 63u), wave = (int)(tid >> 6);
+    const uint32_t blk = wg * (uint32_t)NSUB + sub;                 // pixel block of k_associate_direct's geometry
+    if (tid < 12u) s_hole[sub][tid] = 0u;
+    if (tid < 2u) s_dead[sub][tid] = 0u;
+    if (tid == 0u) s_any[sub] = 0u;
+    const uint32_t word = blk * (PIX_BLOCK / 64) + (uint32_t)wave;
+    const bool in = blk < a.n && word < a.nwords;
+    const uint64_t vw = in ? a.validmask[word] : 0ull, gw = in ? a.gmask[word] : 0ull, ow = in ? a.ownmask[word] : 0ull;
+    const uint64_t foreign = gw & ~ow & vw;                       // fused by another rank
+    const uint32_t grp = blk / CAND_GROUP, in_grp = blk % CAND_GROUP;
+    uint32_t pre = 0;
+    const bool need = a.owner != 0 && blk < a.n;                  // only the owner has slots to empty
+    if (need) {
+        pre = (lane < (int)in_grp) ? a.blk_cand[grp * CAND_GROUP + lane] : 0u;
+        for (uint32_t g = lane; g < grp; g += 64u) pre += a.grp_cand[g];
+    }
+    const uint32_t offset = a.st->offset;
+    __syncthreads();
+    if (lane == 0) {
+        s_v[sub][wave] = (uint32_t)__popcll(vw);
+        if (foreign) s_any[sub] = 1u;
+    }
+    if (blk == 0u && tid == 0u) {
+        const uint64_t conf = a.gmask[a.nwords], vis = a.gmask[a.nwords + 1], kill = a.gmask[a.nwords + 2];
+        a.st->conflict_count = (uint32_t)conf;
+        a.st->visible_count = (uint32_t)vis;
+        a.st->n_kill = (uint32_t)kill;
+        if (conf > (uint64_t)a.cap_pixels) a.st->error = -3;      // SM_E_UNSUPPORTED: the conflict cap would bind
+    }
+    if (lane == 0 && in) {
+        const uint32_t nf = (uint32_t)__popcll(gw & vw), nn = (uint32_t)__popcll(vw & ~gw);
+        if (nn) atomicAdd(&a.frame_sub[2 * SUB_SET + (word & 63u) * SUB_STRIDE], nn);
+        if (nf) atomicAdd(&a.frame_sub[3 * SUB_SET + (word & 63u) * SUB_STRIDE], nf);
+    }
+    __syncthreads();
+    const bool holes = need && s_any[sub] != 0u;                  // uniform per sub-block
+    pre = wave_sum_u32(pre);
+    uint32_t rank = (uint32_t)__popcll(vw & ((1ull << lane) - 1ull));
+    for (int w = 0; w < wave; ++w) rank += s_v[sub][w];
+    const uint32_t slot = offset + pre + rank;
+    const uint32_t blk_first = offset + pre, w_first = blk_first >> 6, t_first = blk_first / (uint32_t)TILE;
+    if (holes && ((foreign >> lane) & 1ull) && (uint64_t)slot < (uint64_t)a.max_vertices) {
+        const uint32_t w = (slot >> 6) - w_first, bit = slot & 63u;
+        atomicOr(&s_hole[sub][w * 2u + (bit >> 5)], 1u << (bit & 31u));
+        atomicAdd(&s_dead[sub][slot / (uint32_t)TILE - t_first], 1u);
+    }
+    __syncthreads();
+    if (holes) {
+        if (tid < 6u) {
+            const uint64_t m = (uint64_t)s_hole[sub][tid * 2u] | ((uint64_t)s_hole[sub][tid * 2u + 1u] << 32);
+            if (m) atomicAnd((unsigned long long *)&a.alive[w_first + tid], ~m);
+        } else if (tid < 8u) {
+            const uint32_t d = s_dead[sub][tid - 6u];
+            if (d) atomicAdd(&a.tile_dead[t_first + tid - 6u], d);
+        }
+    }
+}
+
+
 // ---------------------------------------------------------------------------------------------
 // p0a metricise (depth_metric.frag:15-35) + u8 RGB/semantic pack + LDS-tiled transpose to the
 // column-major frame layout + key-map clear.  32x32 pixel tile per 1024-thread workgroup.
@@ -194,10 +287,13 @@ __global__ __launch_bounds__(1024) void k_prep(const uint8_t *__restrict__ rgb,
                                                uint64_t *__restrict__ keyT, FrameParams fp,
                                                uint2 *__restrict__ dcT /* (depth bits, rgbs) per pixel: one 8-byte gather for the conflict test */,
                                                uint32_t *__restrict__ conf_sub /* this frame's 64 conflict sub-counters, or null */,
-                                               TilePrep tp /* the first tp.nfb workgroups build the frame's tile flags + active-tile list */)
+                                               TilePrep tp /* the first tp.nfb workgroups build the frame's tile flags */,
+                                               ShardSettle ss /* then ceil(ss.n / 4) workgroups finish the previous frame of a sharded stream */)
 {
     if (blockIdx.x < tp.nfb) { tile_prep_block(fp, tp); return; }       // workgroup-uniform
-    const uint32_t bid = blockIdx.x - tp.nfb;
+    const uint32_t nsb = (ss.n + 3u) / 4u;
+    if (blockIdx.x < tp.nfb + nsb) { shard_settle_body<4>(ss, blockIdx.x - tp.nfb); return; }
+    const uint32_t bid = blockIdx.x - tp.nfb - nsb;
     __shared__ float s_d[32][33];
     if (conf_sub && bid == 0 && threadIdx.x < 64) conf_sub[threadIdx.x * SUB_STRIDE] = 0u;
     __shared__ uint32_t s_c[32][33];
@@ -1423,7 +1519,6 @@ __device__ __forceinline__ bool candidate_pixel(int q, const FrameParams &fp, co
 // k_associate_direct writes new surfels straight there -- the order of the reference's append (src/GlobalModel.cpp:67-74,
 // unstable.vert) with no count that depends on the association itself -- and marks the slots of pixels that fuse instead
 // as dead, which the deferred compaction squeezes out like any other dead slot.
-constexpr int CAND_GROUP = 16;      // association blocks per counting workgroup (16 pixels per thread, all loads in flight together)
 
 __device__ __forceinline__ void cand_count_block(uint32_t cg, const FrameParams &fp, const float *__restrict__ depthT,
                                                  const float *__restrict__ xs, const float *__restrict__ ys, int nblocks,
@@ -2390,79 +2485,10 @@ __global__ __launch_bounds__(PIX_BLOCK) void k_associate_direct(Model M, DevStat
     if (is_valid && !room) st->error = -2;
 }
 
-// ---------------------------------------------------------------------------------------------
-// Slot-addressed sharding, last kernel of a frame: after the fused masks of all ranks were sum-reduced (gmask), every
-// rank counts the frame's fused / new pixels from the same two planes (so DevState stays identical on all ranks), the
-// owner of the frame's segment empties the slots of candidates that ANOTHER rank fused (it wrote them speculatively in
-// k_associate_direct<true>: each candidate owns its slot, so that write disturbed nothing), and block 0 replaces this
-// rank's share of the pass counters by the totals over the ranks.  The W*H conflict cap (src/GlobalModel.cpp:54-57)
-// is defined on the conflicts of ALL ranks in slot order and is not evaluated per shard: a frame that exceeds it is
-// flagged (sticky SM_E_UNSUPPORTED) instead of producing a model that could differ.
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(PIX_BLOCK) void k_shard_settle(DevState *__restrict__ st, FrameParams fp,
-                                                            const uint64_t *__restrict__ validmask,
-                                                            const uint64_t *__restrict__ ownmask,
-                                                            const uint64_t *__restrict__ gmask, uint32_t nwords,
-                                                            const uint32_t *__restrict__ blk_cand,
-                                                            const uint32_t *__restrict__ grp_cand,
-                                                            uint32_t *__restrict__ frame_sub, uint64_t *__restrict__ alive,
-                                                            uint32_t *__restrict__ tile_dead, int owner, uint32_t cap_pixels)
+// stand-alone form (when something reads the frame's counters before the next frame's k_prep has run)
+__global__ __launch_bounds__(PIX_BLOCK) void k_shard_settle(ShardSettle a)
 {
-    __shared__ uint32_t s_v[4], s_any;
-    __shared__ uint32_t s_hole[12], s_dead[2];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x < 12) s_hole[threadIdx.x] = 0u;
-    if (threadIdx.x < 2) s_dead[threadIdx.x] = 0u;
-    if (threadIdx.x == 0) s_any = 0u;
-    const uint32_t word = blockIdx.x * (PIX_BLOCK / 64) + (uint32_t)wave;
-    const bool in = word < nwords;
-    const uint64_t vw = in ? validmask[word] : 0ull, gw = in ? gmask[word] : 0ull, ow = in ? ownmask[word] : 0ull;
-    const uint64_t foreign = gw & ~ow & vw;                       // fused by another rank
-    const uint32_t grp = blockIdx.x / CAND_GROUP, in_grp = blockIdx.x % CAND_GROUP;
-    uint32_t pre = 0;
-    const bool need = owner != 0;                                 // (uniform) only the owner has slots to empty
-    if (need) {
-        pre = (lane < (int)in_grp) ? blk_cand[grp * CAND_GROUP + lane] : 0u;
-        for (uint32_t g = lane; g < grp; g += 64u) pre += grp_cand[g];
-    }
-    const uint32_t offset = st->offset;
-    __syncthreads();
-    if (lane == 0) {
-        s_v[wave] = (uint32_t)__popcll(vw);
-        if (foreign) s_any = 1u;
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        const uint64_t conf = gmask[nwords], vis = gmask[nwords + 1], kill = gmask[nwords + 2];
-        st->conflict_count = (uint32_t)conf;
-        st->visible_count = (uint32_t)vis;
-        st->n_kill = (uint32_t)kill;
-        if (conf > (uint64_t)cap_pixels) st->error = -3;          // SM_E_UNSUPPORTED: the conflict cap would bind
-    }
-    if (lane == 0) {
-        const uint32_t nf = (uint32_t)__popcll(gw & vw), nn = (uint32_t)__popcll(vw & ~gw);
-        if (nn) atomicAdd(&frame_sub[2 * SUB_SET + (word & 63u) * SUB_STRIDE], nn);
-        if (nf) atomicAdd(&frame_sub[3 * SUB_SET + (word & 63u) * SUB_STRIDE], nf);
-    }
-    __syncthreads();
-    if (!need || s_any == 0u) return;                             // workgroup-uniform
-    pre = wave_sum_u32(pre);
-    uint32_t rank = (uint32_t)__popcll(vw & ((1ull << lane) - 1ull));
-    for (int w = 0; w < wave; ++w) rank += s_v[w];
-    const uint32_t slot = offset + pre + rank;
-    const uint32_t blk_first = offset + pre, w_first = blk_first >> 6, t_first = blk_first / (uint32_t)TILE;
-    if (((foreign >> lane) & 1ull) && (uint64_t)slot < (uint64_t)fp.max_vertices) {
-        const uint32_t w = (slot >> 6) - w_first, bit = slot & 63u;
-        atomicOr(&s_hole[w * 2u + (bit >> 5)], 1u << (bit & 31u));
-        atomicAdd(&s_dead[slot / (uint32_t)TILE - t_first], 1u);
-    }
-    __syncthreads();
-    if (threadIdx.x < 6) {
-        const uint64_t m = (uint64_t)s_hole[threadIdx.x * 2u] | ((uint64_t)s_hole[threadIdx.x * 2u + 1u] << 32);
-        if (m) atomicAnd((unsigned long long *)&alive[w_first + threadIdx.x], ~m);
-    } else if (threadIdx.x < 8) {
-        const uint32_t d = s_dead[threadIdx.x - 6u];
-        if (d) atomicAdd(&tile_dead[t_first + threadIdx.x - 6u], d);
-    }
+    shard_settle_body<1>(a, blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------
