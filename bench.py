@@ -529,6 +529,10 @@ def main():
                                  f"against all {world} latest views (cleanPoints per view, {sum(view_conflicts)} conflicts), RCCL all-gather into a single "
                                  f"GlobalModel of {global_count} surfels ({gather_ms:.1f} ms, not in `value`)") if dist else "single stream",
                    "host_sync": "per frame" if args.sync_every_frame else "none inside the timed region",
+                   "frame_form": ("four launches per frame" if (args.preprocess or args.sync_every_frame or os.environ.get("SM_DEFER_ASSOC", "1") == "0") else
+                                  "value: three launches per frame (k_assoc_prep = the previous frame's association + this frame's image "
+                                  "preparation, then k_surfel_pass, k_pass_fixup; DESIGN.md 4); kernels / roofline: the same frames on a context "
+                                  "with per-kernel events, which launches k_prep and k_associate_direct separately"),
                    "compaction": (f"deferred: culled surfels keep their slots, every {args.compact_period}th cull compacts "
                                   f"({int((log['n_static'] < log['n_slots']).sum()) if len(log) else 0} of {K} timed frames moved surfels)")
                                  if args.compact_period > 1 else "every frame",

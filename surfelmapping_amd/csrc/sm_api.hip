@@ -351,6 +351,12 @@ struct sm_ctx {
     void *ss_comm = nullptr;           // ncclComm_t when the built-in RCCL binding is used
     uint64_t *d_galive = nullptr, *d_new_alive = nullptr, *d_gmask = nullptr;
     uint32_t *d_ss_info = nullptr;
+    // deferred association (k_assoc_prep): the association of an asynchronous frame is held back until the next frame's images
+    // arrive and then shares that frame's k_prep launch (three launches per frame instead of four)
+    bool defer_ok = false;             // this context may defer (plain stream, no depth filter chain, no per-kernel timing)
+    bool assoc_pending = false;
+    AssocArgs assoc_args{};            // the held-back association (its FrameParams and that frame's planes)
+    bool merge_assoc = false;          // set by enqueue_frame: the k_prep launch of this call carries assoc_args
     bool ss_settle_pending = false;    // the last sharded frame's k_shard_settle work rides on the next k_prep (or runs stand-alone first)
     ShardSettle ss_settle{};
     int n_pix_blocks = 0;
@@ -458,8 +464,11 @@ int push_state(sm_ctx *s)
 
 // a direct-append frame leaves its new / fused totals, the dead-slot total and its log entry to be completed by the next
 // frame's k_pass_fixup; everything else that reads them asks for the completion first
+int flush_assoc(sm_ctx *s);
+
 int finalize_if_pending(sm_ctx *s)
 {
+    if (flush_assoc(s)) return SM_E_HIP;      // a held-back association comes first: everything below reads its results
     if (s->ss_settle_pending) {          // a sharded frame whose settle step has not run yet: stand-alone, before anything reads its results
         s->ss_settle_pending = false;
         hipLaunchKernelGGL(k_shard_settle, dim3(s->ss_settle.n), dim3(PIX_BLOCK), 0, s->stream, s->ss_settle);
@@ -524,6 +533,25 @@ int launch_prep(sm_ctx *s, const uint8_t *rgb, const uint16_t *raw, const uint8_
         tp.nfb = (uint32_t)std::min<uint64_t>(std::max<uint64_t>((ntl + 127) / 128, 1), 64);
         tp.st = s->d_state; tp.tb = s->d_tb; tp.tile_flags = s->d_tile_flags; tp.wave_cnt = s->d_wave_cnt; tp.prep_part = s->d_prep_part;
         s->n_prep_blocks = tp.nfb;
+    }
+    if (s->merge_assoc) {
+        // the held-back association of the previous frame + this frame's tile flags + its image tiles in one launch
+        s->merge_assoc = false;
+        s->assoc_pending = false;
+        if (tp.nfb) {
+            const uint64_t ntl = ((uint64_t)s->count_bound + TILE - 1) / TILE;
+            tp.nfb = (uint32_t)std::min<uint64_t>(std::max<uint64_t>((ntl + 31) / 32, 1), 256);     // 32 tiles per 256-thread workgroup and round
+            tp.grp_cand = s->assoc_args.grp_cand; tp.n_grp = s->assoc_args.n_grp; tp.prev_time = s->assoc_args.fp.time;
+            s->n_prep_blocks = tp.nfb;
+        }
+        PrepArgs pa;
+        pa.rgb = rgb; pa.depth_raw = raw; pa.sem = sem; pa.depth_f32 = dm; pa.depthT = s->d_depthT; pa.rgbsT = s->d_rgbsT;
+        pa.keyT = clear_keys ? s->d_keyT : nullptr; pa.dcT = s->d_dcT;
+        pa.conf_sub = clear_keys ? s->d_conf_sub + SUB_SET * s->conf_sub_set : nullptr;
+        hipLaunchKernelGGL(k_assoc_prep, dim3(tp.nfb + (uint32_t)s->n_pix_blocks + (uint32_t)tiles), dim3(PIX_BLOCK), 0, s->stream, s->assoc_args, pa, fp, tp,
+                           (uint32_t)s->n_pix_blocks, (uint32_t)tiles);
+        HIPCK(hipGetLastError());
+        return SM_OK;
     }
     // the previous frame of a sharded stream is finished by extra workgroups of this launch (on the main stream only)
     ShardSettle ss;
@@ -633,20 +661,46 @@ int launch_surfel_pass(sm_ctx *s, const FrameParams &fp, bool timed, bool direct
     return SM_OK;
 }
 
+void fill_assoc_args(const sm_ctx *s, const FrameParams &fp, AssocArgs &a)
+{
+    a.M = s->M; a.st = s->d_state; a.fp = fp;
+    a.depthT = s->d_depthT; a.rgbsT = s->d_rgbsT; a.keyT = s->d_keyT; a.xs = s->d_xs; a.ys = s->d_ys;
+    a.blk_cand = s->d_blk_cand; a.grp_cand = s->d_grp_cand; a.frame_sub = s->d_frame_sub; a.tb = s->d_tb;
+    a.alive = s->d_alive; a.tile_dead = s->d_tile_dead; a.n_grp = s->n_grp; a.host_stat = s->d_stat;
+}
+
 // association + in-place fuse + direct append (the frame's last kernel; its statistics are completed later)
 int launch_associate_direct(sm_ctx *s, const FrameParams &fp, bool timed)
 {
     ShardArgs sh;
     memset(&sh, 0, sizeof sh);
-    hipLaunchKernelGGL(k_associate_direct<false>, dim3(s->n_pix_blocks), dim3(PIX_BLOCK), 0, s->stream, s->M, s->d_state, fp, s->d_depthT, s->d_rgbsT,
-                       s->d_keyT, s->d_xs, s->d_ys, s->d_blk_cand, s->d_grp_cand, s->d_frame_sub, s->d_tb, s->d_alive, s->d_tile_dead, s->n_grp,
-                       s->d_stat, sh);
-    HIPCK(hipGetLastError());
+    AssocArgs a;
+    fill_assoc_args(s, fp, a);
+    if (s->defer_ok && timed) {
+        // asynchronous plain stream: hold the association back; the next frame's k_prep launch carries it (k_assoc_prep),
+        // anything else that needs its results launches it first (flush_assoc, reached through finalize_if_pending)
+        s->assoc_args = a;
+        s->assoc_pending = true;
+    } else {
+        hipLaunchKernelGGL(k_associate_direct<false>, dim3(s->n_pix_blocks), dim3(PIX_BLOCK), 0, s->stream, a, sh);
+        HIPCK(hipGetLastError());
+    }
     s->lazy_part_live = false;
     s->fix_part_live = false;
     s->pend_finalize = true;
     s->frames_enq++;
     if (mark(s, 5, timed) || mark(s, 6, timed) || mark(s, 7, timed)) return SM_E_HIP;
+    return SM_OK;
+}
+
+int flush_assoc(sm_ctx *s)
+{
+    if (!s->assoc_pending) return SM_OK;
+    s->assoc_pending = false;
+    ShardArgs sh;
+    memset(&sh, 0, sizeof sh);
+    hipLaunchKernelGGL(k_associate_direct<false>, dim3(s->n_pix_blocks), dim3(PIX_BLOCK), 0, s->stream, s->assoc_args, sh);
+    HIPCK(hipGetLastError());
     return SM_OK;
 }
 
@@ -908,7 +962,7 @@ int begin_frame(sm_ctx *s, const uint8_t *d_rgb, const uint16_t *d_raw, const ui
     // sets, so that the pre-processing of frame f+1 never touches what frame f still reads
     s->plane_set ^= 1;
     s->conf_sub_set = s->plane_set;
-    if (s->overlap_capable) {
+    if (s->overlap_capable || s->defer_ok) {
         std::swap(s->d_depthT, s->d_depthT_nx); std::swap(s->d_rgbsT, s->d_rgbsT_nx);
         std::swap(s->d_dcT, s->d_dcT_nx);
         if (will_splat) std::swap(s->d_keyT, s->d_keyT_nx);
@@ -1009,8 +1063,14 @@ int enqueue_frame(sm_ctx *s, const uint8_t *d_rgb, const uint16_t *d_raw, const 
     const bool fusing = s->ref_set && s->tick != 0 && !s->pending_cull;
     const bool compact_now = fusing ? decide_compact(s) : true;
     s->want_list = fusing && !compact_now && s->one_pass && s->use_list && !s->use_fused_assoc && !s->overlap;
-    int rc = begin_frame(s, d_rgb, d_raw, d_sem, pose, &fp);
+    // a held-back association rides on this frame's k_prep launch if this is again a frame of the one-pass form; anything else
+    // (a compacting frame, the frame after reset, ...) needs its results first
+    s->merge_assoc = s->assoc_pending && s->want_list && s->defer_ok;
+    int rc = SM_OK;
+    if (s->assoc_pending && !s->merge_assoc && (rc = flush_assoc(s))) return rc;
+    rc = begin_frame(s, d_rgb, d_raw, d_sem, pose, &fp);
     s->want_list = false;
+    s->merge_assoc = false;
     if (rc <= 0) return rc;
     fp.compact_now = compact_now ? 1u : 0u;
     note_cull(s, fp.compact_now != 0u);
@@ -1178,7 +1238,12 @@ sm_ctx *sm_create(const sm_config *c)
     ok = ok && dalloc(&s->d_depthT, P) == SM_OK && dalloc(&s->d_filteredT, P) == SM_OK && dalloc(&s->d_lastT, P) == SM_OK;
     ok = ok && dalloc(&s->d_rgbsT, P) == SM_OK && dalloc(&s->d_keyT, P) == SM_OK && dalloc(&s->d_dcT, P) == SM_OK &&
          hipMemset(s->d_dcT, 0, P * 8) == hipSuccess;
-    if (s->overlap_capable)
+    // deferred association: only plain asynchronous streams without the depth filter chain and without per-kernel timing
+    {
+        const char *e = std::getenv("SM_DEFER_ASSOC");                    // "0": every frame launches its own association
+        s->defer_ok = c->preprocess == 0 && !c->enable_timing && !(e && e[0] == '0');
+    }
+    if (s->overlap_capable || s->defer_ok)
         ok = ok && dalloc(&s->d_depthT_nx, P) == SM_OK && dalloc(&s->d_rgbsT_nx, P) == SM_OK && dalloc(&s->d_keyT_nx, P) == SM_OK &&
              dalloc(&s->d_dcT_nx, P) == SM_OK && hipMemset(s->d_depthT_nx, 0, P * 4) == hipSuccess &&
              hipMemset(s->d_rgbsT_nx, 0, P * 4) == hipSuccess && hipMemset(s->d_dcT_nx, 0, P * 8) == hipSuccess;
@@ -1197,7 +1262,7 @@ sm_ctx *sm_create(const sm_config *c)
     ok = ok && dalloc(&s->d_conf_part, (size_t)MAX_GRID * 4) == SM_OK && dalloc(&s->d_compact_part, (size_t)MAX_GRID) == SM_OK &&
          dalloc(&s->d_lazy_part, (size_t)MAX_GRID) == SM_OK && dalloc(&s->d_fix_part, (size_t)MAX_GRID * 2 + 2) == SM_OK &&
          dalloc(&s->d_wave_cnt, ntiles) == SM_OK && dalloc(&s->d_undo, cap + TILE) == SM_OK && dalloc(&s->d_conf_sub, (size_t)2 * SUB_SET) == SM_OK &&
-         dalloc(&s->d_prep_part, (size_t)64) == SM_OK &&
+         dalloc(&s->d_prep_part, (size_t)256) == SM_OK &&
          hipMemset(s->d_conf_sub, 0, (size_t)2 * SUB_SET * 4) == hipSuccess;
     ok = ok && dalloc(&s->d_tb, (size_t)s->tb_tiles * 8) == SM_OK && dalloc(&s->d_tile_flags, (size_t)s->tb_tiles) == SM_OK &&
          hipMemset(s->d_tile_flags, 0, s->tb_tiles) == hipSuccess;
@@ -1278,6 +1343,7 @@ sm_ctx *sm_create(const sm_config *c)
         if (const char *e = std::getenv("SM_TILE_FLAGS_IN_PREP")) s->use_list = e[0] != '0';
         if (const char *e = std::getenv("SM_DIRECT_APPEND")) s->direct = e[0] != '0';
         if (const char *e = std::getenv("SM_PASS_NW")) { const int v = std::atoi(e); if (v == 1 || v == 2 || v == 4) s->pass_nw = v; }
+        s->defer_ok = s->defer_ok && s->one_pass && s->use_list && s->direct && !s->use_fused_assoc;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess && cus > 0 &&
             hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_compact<true>, 256, 0) == hipSuccess && per_cu > 0) {
             // the occupancy API can over-report by one block per CU (MI355X_MICROARCH.md): stay at <= 4 and below it
@@ -1615,8 +1681,9 @@ int sm_set_frame(sm_ctx *s, const uint8_t *rgb, const float *depth_metric, const
 {
     if (!s) return SM_E_ARG;
     HIPCK(hipSetDevice(s->cfg.device));
-    int rc = upload_inputs(s, rgb, nullptr, semantic);
+    int rc = finalize_if_pending(s);             // (a held-back association still reads the planes this call rewrites)
     if (rc) return rc;
+    if ((rc = upload_inputs(s, rgb, nullptr, semantic))) return rc;
     if (depth_metric) HIPCK(hipMemcpyAsync(s->d_depth_f32, depth_metric, (size_t)s->P * 4, hipMemcpyHostToDevice, s->stream));
     FrameParams fp = make_params(s, s->curr_pose);
     // re-pack every plane from the staged inputs; depth only when given (else keep depthT)
@@ -1636,6 +1703,9 @@ int sm_set_frame(sm_ctx *s, const uint8_t *rgb, const float *depth_metric, const
 int sm_set_tick(sm_ctx *s, int32_t tick)
 {
     if (!s) return SM_E_ARG;
+    HIPCK(hipSetDevice(s->cfg.device));
+    int rc = finalize_if_pending(s);
+    if (rc) return rc;
     s->tick = tick;
     s->ref_set = true;
     return SM_OK;
@@ -1900,6 +1970,7 @@ int sm_shard_configure(sm_ctx *s, int rank, int world)
     HIPCK(hipSetDevice(s->cfg.device));
     int rcc = ensure_compact(s);
     if (rcc) return rcc;
+    s->defer_ok = false;
     s->sh_rank = rank; s->sh_world = world;
     s->sh_nseg = 0; s->sh_ngseg = 0; s->sh_exempt = 0; s->sh_in_frame = false;
     return ensure_seg(s, 64);
@@ -2136,6 +2207,7 @@ int sm_shard_stream_configure(sm_ctx *s, int rank, int world)
         return rc;
     HIPCK(hipMemset(s->d_ss_info, 0, 16));
     s->ss_on = true; s->ss_rank = rank; s->ss_world = world; s->ss_frames = 0;
+    s->defer_ok = false;                       // the association of a sharded frame sits between two collectives
     return SM_OK;
 }
 
@@ -2238,9 +2310,9 @@ int sm_shard_frame_device(sm_ctx *s, const uint8_t *d_rgb, const uint16_t *d_dep
     ShardArgs sh;
     sh.validmask = s->d_validmask; sh.ownmask = s->d_fusedmask; sh.gmask = s->d_gmask; sh.nwords = (uint32_t)((s->P + 63) / 64);
     sh.owner = (int)(s->ss_frames % (uint32_t)s->ss_world) == s->ss_rank ? 1 : 0;
-    hipLaunchKernelGGL(k_associate_direct<true>, dim3(s->n_pix_blocks), dim3(PIX_BLOCK), 0, s->stream, s->M, s->d_state, fp, s->d_depthT, s->d_rgbsT,
-                       s->d_keyT, s->d_xs, s->d_ys, s->d_blk_cand, s->d_grp_cand, s->d_frame_sub, s->d_tb, s->d_alive, s->d_tile_dead, s->n_grp,
-                       s->d_stat, sh);
+    AssocArgs aa;
+    fill_assoc_args(s, fp, aa);
+    hipLaunchKernelGGL(k_associate_direct<true>, dim3(s->n_pix_blocks), dim3(PIX_BLOCK), 0, s->stream, aa, sh);
     HIPCK(hipGetLastError());
     if ((rc = mark(s, 5, true))) return rc;
     if ((rc = ss_collective(s, s->d_gmask, s->d_gmask, (size_t)sh.nwords + 4, SM_COLL_SUM))) return rc;   // in place, like the key map

@@ -122,17 +122,33 @@ struct TilePrep {
     uint4 *wave_cnt;
     uint2 *prep_part;         // [nfb] (conflict-skipped, splat-skipped) surfels
     uint32_t nfb;             // workgroups of k_prep that do this (0: none)
+    // k_assoc_prep: the previous frame's association runs in the SAME launch, so its appends / fuses are not in the bounds yet
+    const uint32_t *grp_cand; // candidate pixels of that frame per group (its new slot count = offset + their sum), or null
+    uint32_t n_grp;
+    int prev_time;            // that frame's time stamp
 };
 
-__device__ __forceinline__ void tile_prep_block(const FrameParams &fp, const TilePrep &tp)
+__device__ __forceinline__ void tile_prep_block(const FrameParams &fp, const TilePrep &tp, uint32_t first_block = 0u)
 {
     __shared__ uint32_t s_sk[2][16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane >> 3, c = lane & 7;                       // tile within the wave's 8, box corner
-    const uint32_t N = tp.st->count;
+    // Concurrent with the previous frame's association (k_assoc_prep): the slot count that association will publish is
+    // offset + (its candidate pixels); tiles it can still change must not be skipped on stale bounds.  Those are the tiles
+    // from the old end on (appends) and the tiles that frame drew into the index map (a fuse moves a surfel: its box may
+    // grow) -- k_surfel_pass stamped exactly those with the frame's time, so "stamped last frame" means "do not skip".
+    uint32_t N = tp.st->count, first_new_tile = 0xFFFFFFFFu;
+    if (tp.grp_cand) {
+        uint32_t d = 0;
+        for (uint32_t g = lane; g < tp.n_grp; g += 64u) d += tp.grp_cand[g];
+        const uint32_t off = tp.st->offset;
+        N = off + wave_sum_u32(d);
+        first_new_tile = off / (uint32_t)TILE;
+    }
     const uint32_t ntiles = (N + TILE - 1) / TILE;
+    const uint32_t per_wg = (blockDim.x >> 6) * 8u, blk = blockIdx.x - first_block;
     uint32_t cskip = 0, sskip = 0;                               // lane c == 0 of every tile accumulates
-    for (uint32_t base = blockIdx.x * 128u; base < ntiles; base += tp.nfb * 128u) {   // workgroup-uniform
+    for (uint32_t base = blk * per_wg; base < ntiles; base += tp.nfb * per_wg) {   // workgroup-uniform
         const uint32_t t = base + (uint32_t)wave * 8u + (uint32_t)j;
         const bool in = t < ntiles;
         const uint32_t *bd = tp.tb + (size_t)(in ? t : 0u) * 8;
@@ -165,6 +181,7 @@ __device__ __forceinline__ void tile_prep_block(const FrameParams &fp, const Til
                     f |= 2u;
             }
         }
+        if (tp.grp_cand && (t >= first_new_tile || ((b0 | b4) != 0u && ord2f(b7) >= (float)tp.prev_time))) f = 0u;
         if (in && c == 0) {
             const uint32_t tn = min((uint32_t)TILE, N - t * TILE);
             tp.tile_flags[t] = (uint8_t)f;
@@ -177,8 +194,8 @@ __device__ __forceinline__ void tile_prep_block(const FrameParams &fp, const Til
     __syncthreads();
     if (threadIdx.x == 0) {
         uint32_t a = 0, b = 0;
-        for (int w = 0; w < 16; ++w) { a += s_sk[0][w]; b += s_sk[1][w]; }
-        tp.prep_part[blockIdx.x] = make_uint2(a, b);
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) { a += s_sk[0][w]; b += s_sk[1][w]; }
+        tp.prep_part[blk] = make_uint2(a, b);
     }
 }
 
@@ -279,29 +296,29 @@ __device__ __forceinline__ void shard_settle_body(const ShardSettle &a, uint32_t
 // p0a metricise (depth_metric.frag:15-35) + u8 RGB/semantic pack + LDS-tiled transpose to the
 // column-major frame layout + key-map clear.  32x32 pixel tile per 1024-thread workgroup.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_prep(const uint8_t *__restrict__ rgb,
-                                               const uint16_t *__restrict__ depth_raw,
-                                               const uint8_t *__restrict__ sem,
-                                               const float *__restrict__ depth_f32,  // optional: metric depth given directly
-                                               float *__restrict__ depthT, uint32_t *__restrict__ rgbsT,
-                                               uint64_t *__restrict__ keyT, FrameParams fp,
-                                               uint2 *__restrict__ dcT /* (depth bits, rgbs) per pixel: one 8-byte gather for the conflict test */,
-                                               uint32_t *__restrict__ conf_sub /* this frame's 64 conflict sub-counters, or null */,
-                                               TilePrep tp /* the first tp.nfb workgroups build the frame's tile flags */,
-                                               ShardSettle ss /* then ceil(ss.n / 4) workgroups finish the previous frame of a sharded stream */)
+struct PrepArgs {
+    const uint8_t *rgb; const uint16_t *depth_raw; const uint8_t *sem; const float *depth_f32;
+    float *depthT; uint32_t *rgbsT; uint64_t *keyT; uint2 *dcT; uint32_t *conf_sub;
+};
+
+// one 32x32-pixel tile per workgroup of NT = 1024 (one round) or 256 threads (four rounds of 8 rows, unrolled: all loads of
+// a thread are in flight together)
+template <int NT>
+__device__ __forceinline__ void prep_image_block(const PrepArgs &a, const FrameParams &fp, uint32_t bid)
 {
-    if (blockIdx.x < tp.nfb) { tile_prep_block(fp, tp); return; }       // workgroup-uniform
-    const uint32_t nsb = (ss.n + 3u) / 4u;
-    if (blockIdx.x < tp.nfb + nsb) { shard_settle_body<4>(ss, blockIdx.x - tp.nfb); return; }
-    const uint32_t bid = blockIdx.x - tp.nfb - nsb;
+    const uint8_t *__restrict__ rgb = a.rgb; const uint16_t *__restrict__ depth_raw = a.depth_raw; const uint8_t *__restrict__ sem = a.sem;
+    const float *__restrict__ depth_f32 = a.depth_f32; float *__restrict__ depthT = a.depthT; uint32_t *__restrict__ rgbsT = a.rgbsT;
+    uint64_t *__restrict__ keyT = a.keyT; uint2 *__restrict__ dcT = a.dcT; uint32_t *__restrict__ conf_sub = a.conf_sub;
     __shared__ float s_d[32][33];
     if (conf_sub && bid == 0 && threadIdx.x < 64) conf_sub[threadIdx.x * SUB_STRIDE] = 0u;
     __shared__ uint32_t s_c[32][33];
     const int W = fp.W, H = fp.H;
     const int tiles_x = (W + 31) >> 5;
     const int i0 = (bid % tiles_x) << 5, j0 = (bid / tiles_x) << 5;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    {
+    constexpr int ROWS = NT / 32, ROUNDS = 32 / ROWS;
+    const int tx = threadIdx.x & 31, ty0 = (int)(threadIdx.x >> 5);
+    if (ROUNDS == 1) {
+        const int ty = ty0;
         const int i = i0 + tx, j = j0 + ty;          // read: lanes along the image row
         float d = 0.0f;
         uint32_t c = 0;
@@ -324,9 +341,39 @@ __global__ __launch_bounds__(1024) void k_prep(const uint8_t *__restrict__ rgb,
         }
         s_d[ty][tx] = d;
         s_c[ty][tx] = c;
+    } else {
+        // several rows per thread: every load unconditional (clamped address) and issued before the first use
+        uint32_t v[ROUNDS], sv[ROUNDS], cr[ROUNDS], cg[ROUNDS], cb[ROUNDS];
+        float df[ROUNDS];
+        const int ic = min(i0 + tx, W - 1);
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {
+            const size_t p = (size_t)min(j0 + ty0 + r * ROWS, H - 1) * W + ic;
+            v[r] = (depth_raw && !depth_f32) ? depth_raw[p] : 0u;
+            df[r] = depth_f32 ? depth_f32[p] : 0.0f;
+            sv[r] = sem ? (uint32_t)sem[p] : 0u;
+            cr[r] = rgb ? rgb[p * 3] : 0u; cg[r] = rgb ? rgb[p * 3 + 1] : 0u; cb[r] = rgb ? rgb[p * 3 + 2] : 0u;
+        }
+        const uint32_t lo = (uint32_t)(fp.min_depth * 1000.0f);
+        const uint32_t hi = (uint32_t)((fp.max_depth - 0.001f) * 1000.0f);
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {
+            const int ty = ty0 + r * ROWS;
+            const int i = i0 + tx, j = j0 + ty;
+            float d = 0.0f;
+            uint32_t c = 0;
+            if (i < W && j < H) {
+                if (depth_f32) d = df[r];
+                else if (depth_raw && !((float)i + 0.5f < fp.stereo_border) && v[r] > lo && v[r] < hi) d = (float)v[r] / 1000.0f;
+                c = (sv[r] << 24) | (cr[r] << 16) | (cg[r] << 8) | cb[r];
+            }
+            s_d[ty][tx] = d;
+            s_c[ty][tx] = c;
+        }
     }
     __syncthreads();
-    {
+#pragma unroll
+    for (int ty = ty0; ty < 32; ty += ROWS) {
         const int i = i0 + ty, j = j0 + tx;          // write: lanes along the image column
         if (i < W && j < H) {
             const size_t q = (size_t)i * H + j;
@@ -337,6 +384,26 @@ __global__ __launch_bounds__(1024) void k_prep(const uint8_t *__restrict__ rgb,
             if (keyT) keyT[q] = KEY_EMPTY;
         }
     }
+}
+
+__global__ __launch_bounds__(1024) void k_prep(const uint8_t *__restrict__ rgb,
+                                               const uint16_t *__restrict__ depth_raw,
+                                               const uint8_t *__restrict__ sem,
+                                               const float *__restrict__ depth_f32,  // optional: metric depth given directly
+                                               float *__restrict__ depthT, uint32_t *__restrict__ rgbsT,
+                                               uint64_t *__restrict__ keyT, FrameParams fp,
+                                               uint2 *__restrict__ dcT /* (depth bits, rgbs) per pixel: one 8-byte gather for the conflict test */,
+                                               uint32_t *__restrict__ conf_sub /* this frame's 64 conflict sub-counters, or null */,
+                                               TilePrep tp /* the first tp.nfb workgroups build the frame's tile flags */,
+                                               ShardSettle ss /* then ceil(ss.n / 4) workgroups finish the previous frame of a sharded stream */)
+{
+    if (blockIdx.x < tp.nfb) { tile_prep_block(fp, tp); return; }       // workgroup-uniform
+    const uint32_t nsb = (ss.n + 3u) / 4u;
+    if (blockIdx.x < tp.nfb + nsb) { shard_settle_body<4>(ss, blockIdx.x - tp.nfb); return; }
+    PrepArgs pa;
+    pa.rgb = rgb; pa.depth_raw = depth_raw; pa.sem = sem; pa.depth_f32 = depth_f32; pa.depthT = depthT; pa.rgbsT = rgbsT; pa.keyT = keyT;
+    pa.dcT = dcT; pa.conf_sub = conf_sub;
+    prep_image_block<1024>(pa, fp, blockIdx.x - tp.nfb - nsb);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2385,19 +2452,25 @@ struct ShardArgs {
     int owner;                // 1: this rank owns the frame's new surfels (frame's segment index % world == rank)
 };
 
+struct AssocArgs {
+    Model M; DevState *st; FrameParams fp;
+    const float *depthT; const uint32_t *rgbsT; const uint64_t *keyT; const float *xs, *ys;
+    const uint32_t *blk_cand /* candidate pixels per block ... */, *grp_cand /* ... and per group of CAND_GROUP blocks */;
+    uint32_t *frame_sub /* sets 2, 3: new, fused -- 64 sub-counters each */, *tb;
+    uint64_t *alive; uint32_t *tile_dead; uint32_t n_grp; unsigned long long *host_stat;
+};
+
+// one association block (PIX_BLOCK pixels, 256 threads); blk = its index in pixel order
 template <bool SHARD>
-__global__ __launch_bounds__(PIX_BLOCK) void k_associate_direct(Model M, DevState *__restrict__ st, FrameParams fp,
-                                                                const float *__restrict__ depthT,
-                                                                const uint32_t *__restrict__ rgbsT,
-                                                                const uint64_t *__restrict__ keyT,
-                                                                const float *__restrict__ xs, const float *__restrict__ ys,
-                                                                const uint32_t *__restrict__ blk_cand /* candidate pixels per block ... */,
-                                                                const uint32_t *__restrict__ grp_cand /* ... and per group of CAND_GROUP blocks */,
-                                                                uint32_t *__restrict__ frame_sub /* sets 2, 3: new, fused -- 64 sub-counters each */,
-                                                                uint32_t *__restrict__ tb, uint64_t *__restrict__ alive,
-                                                                uint32_t *__restrict__ tile_dead, uint32_t n_grp,
-                                                                unsigned long long *__restrict__ host_stat, ShardArgs sh)
+__device__ __forceinline__ void associate_direct_block(const AssocArgs &a, const ShardArgs &sh, const uint32_t blk)
 {
+    const Model &M = a.M; DevState *__restrict__ st = a.st; const FrameParams &fp = a.fp;
+    const float *__restrict__ depthT = a.depthT; const uint32_t *__restrict__ rgbsT = a.rgbsT; const uint64_t *__restrict__ keyT = a.keyT;
+    const float *__restrict__ xs = a.xs, *__restrict__ ys = a.ys;
+    const uint32_t *__restrict__ blk_cand = a.blk_cand, *__restrict__ grp_cand = a.grp_cand;
+    uint32_t *__restrict__ frame_sub = a.frame_sub, *__restrict__ tb = a.tb;
+    uint64_t *__restrict__ alive = a.alive; uint32_t *__restrict__ tile_dead = a.tile_dead;
+    const uint32_t n_grp = a.n_grp; unsigned long long *__restrict__ host_stat = a.host_stat;
     __shared__ uint32_t s_v[4], s_n[4], s_f[4];
     __shared__ uint32_t s_hole[12], s_dead[2];          // empty slots of this block: 6 alive words (lo, hi), 2 tiles
     __shared__ uint32_t s_tag[FB_SLOTS], s_box[FB_SLOTS * 8];
@@ -2406,12 +2479,12 @@ __global__ __launch_bounds__(PIX_BLOCK) void k_associate_direct(Model M, DevStat
     if (threadIdx.x < 2) s_dead[threadIdx.x] = 0u;
     // candidates before this block = the groups before its group + the blocks of its group before it: a few loads per lane,
     // issued together with DevState, one wave reduction (every wave computes it for itself)
-    const uint32_t grp = blockIdx.x / CAND_GROUP, in_grp = blockIdx.x % CAND_GROUP;
+    const uint32_t grp = blk / CAND_GROUP, in_grp = blk % CAND_GROUP;
     uint32_t pre = (lane < (int)in_grp) ? blk_cand[grp * CAND_GROUP + lane] : 0u;
     for (uint32_t g = lane; g < grp; g += 64u) pre += grp_cand[g];
     const SurfelSet cur = M.s[st->cur];
     const uint32_t offset = st->offset;
-    const int q = blockIdx.x * PIX_BLOCK + threadIdx.x;
+    const int q = blk * PIX_BLOCK + threadIdx.x;
     bool is_valid, is_fused;
     LocalSurfel L;
     FuseMove mv;
@@ -2420,17 +2493,17 @@ __global__ __launch_bounds__(PIX_BLOCK) void k_associate_direct(Model M, DevStat
     const uint64_t vw = __ballot(is_valid), fw = __ballot(is_fused);
     if (lane == 0) { s_v[wave] = (uint32_t)__popcll(vw); s_n[wave] = (uint32_t)__popcll(vw & ~fw); s_f[wave] = (uint32_t)__popcll(fw); }
     if (SHARD && lane == 0) {
-        const uint32_t word = blockIdx.x * (PIX_BLOCK / 64) + (uint32_t)wave;
+        const uint32_t word = blk * (PIX_BLOCK / 64) + (uint32_t)wave;
         if (word < sh.nwords) { sh.validmask[word] = vw; sh.ownmask[word] = fw; sh.gmask[word] = fw; }
     }
     pre = wave_sum_u32(pre);
     __syncthreads();
-    if (SHARD && blockIdx.x == 0 && threadIdx.x == 0) {
+    if (SHARD && blk == 0 && threadIdx.x == 0) {
         // this rank's share of the frame's counters travels with the mask (k_pass_fixup published them)
         sh.gmask[sh.nwords] = st->conflict_count; sh.gmask[sh.nwords + 1] = st->visible_count;
         sh.gmask[sh.nwords + 2] = st->n_kill; sh.gmask[sh.nwords + 3] = 0ull;
     }
-    if (blockIdx.x == 0 && wave == 0) {
+    if (blk == 0 && wave == 0) {
         // every candidate pixel of the frame owns a slot: the new count (the host never lets a frame of this form start
         // without room for all of them), published for the next frame's kernels and for the host's capacity bound
         uint32_t d = 0;
@@ -2447,8 +2520,8 @@ __global__ __launch_bounds__(PIX_BLOCK) void k_associate_direct(Model M, DevStat
     }
     if (!SHARD && threadIdx.x == 0) {                    // (sharded: k_shard_settle counts, from the masks of all ranks)
         const uint32_t nn = s_n[0] + s_n[1] + s_n[2] + s_n[3], nf = s_f[0] + s_f[1] + s_f[2] + s_f[3];
-        if (nn) atomicAdd(&frame_sub[2 * SUB_SET + (blockIdx.x & 63u) * SUB_STRIDE], nn);
-        if (nf) atomicAdd(&frame_sub[3 * SUB_SET + (blockIdx.x & 63u) * SUB_STRIDE], nf);
+        if (nn) atomicAdd(&frame_sub[2 * SUB_SET + (blk & 63u) * SUB_STRIDE], nn);
+        if (nf) atomicAdd(&frame_sub[3 * SUB_SET + (blk & 63u) * SUB_STRIDE], nf);
     }
     fuse_bounds_block(tb, is_fused, mv, s_f[0] + s_f[1] + s_f[2] + s_f[3], s_tag, s_box);
     uint32_t rank = (uint32_t)__popcll(vw & ((1ull << lane) - 1ull));
@@ -2483,6 +2556,35 @@ __global__ __launch_bounds__(PIX_BLOCK) void k_associate_direct(Model M, DevStat
         }
     }
     if (is_valid && !room) st->error = -2;
+}
+
+template <bool SHARD>
+__global__ __launch_bounds__(PIX_BLOCK) void k_associate_direct(AssocArgs a, ShardArgs sh)
+{
+    associate_direct_block<SHARD>(a, sh, blockIdx.x);
+}
+
+// ---------------------------------------------------------------------------------------------
+// The previous frame's association and this frame's image preparation in ONE launch (plain asynchronous streams,
+// DESIGN.md 4 "Three launches per frame"): the two are independent -- the association of frame f-1 reads that frame's
+// planes and key map, the preparation of frame f writes the other set -- so the host holds the association back until
+// the next frame's images arrive and saves a launch, and the small k_prep runs in the shadow of the association.
+// Block ranges: the 32x32-pixel image tiles, the frame's tile flags (tile_prep_block with the "may still change" rule),
+// the association blocks.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(PIX_BLOCK) void k_assoc_prep(AssocArgs a, PrepArgs p, FrameParams fp_new, TilePrep tp, uint32_t n_assoc,
+                                                          uint32_t n_img)
+{
+    // dispatch order: the short, streaming image tiles first.  (The chip holds ~2 048 workgroups of this size at once and the
+    // three parts together are ~2 300 at KITTI size, so the launch takes 16.4 us where the association alone takes 12.2 and
+    // k_prep alone 8.5: the parts overlap only partly.  Letting each image workgroup do four tiles in turn, so that
+    // everything is resident at once, made those workgroups the long pole: 25 us.)
+    if (blockIdx.x < n_img) { prep_image_block<PIX_BLOCK>(p, fp_new, blockIdx.x); return; }       // workgroup-uniform
+    const uint32_t b = blockIdx.x - n_img;
+    if (b < tp.nfb) { tile_prep_block(fp_new, tp, n_img); return; }
+    ShardArgs none;
+    none.validmask = nullptr; none.ownmask = nullptr; none.gmask = nullptr; none.nwords = 0u; none.owner = 1;
+    associate_direct_block<false>(a, none, b - tp.nfb);
 }
 
 // stand-alone form (when something reads the frame's counters before the next frame's k_prep has run)

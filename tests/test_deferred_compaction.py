@@ -200,3 +200,40 @@ def test_conflict_cap_binds_in_asynchronous_frames(period):
     assert (log["conflict_count"] == P).sum() >= 3, log["conflict_count"]
     assert_models_equal(o.download_model(), h.download_model(), "async, cap binding")
     np.testing.assert_array_equal(o.download_index_map()[0], h.download_index_map()[0])
+
+
+@pytest.mark.parametrize("period,thresh", [(3, 0.05), (8, 0.0), (1000, 0.05)])
+def test_async_frames_hand_their_association_to_the_next_frame(period, thresh):
+    """Asynchronous plain streams hold a frame's association back and launch it together with the next frame's image
+    preparation (k_assoc_prep); compacting frames, synchronisations and downloads in between take it out first.  Counters
+    of every frame (device-side frame log), a model in the middle and the model at the end against the oracle."""
+    seq = synth.make_sequence(SMALL, wavy(40), seed=31, noise_mm=3.0)
+    o, h = pair(SMALL, stereo_border=20.0, max_sqrt_vertices=900, fuse_thresh=thresh, compact_period=period)
+    P = SMALL["width"] * SMALL["height"]
+    bufs = []
+    for rgb, d, s_, p in seq:
+        dr, dd, ds = h.device_alloc(P * 3), h.device_alloc(P * 2), h.device_alloc(P)
+        h.device_upload(dr, rgb); h.device_upload(dd, d); h.device_upload(ds, s_)
+        bufs.append((dr, dd, ds, p))
+    ref = []
+    for k, fr in enumerate(seq):
+        o.process_frame(*fr)
+        ref.append(o.counts())
+        if k == 17:
+            mid = o.download_model()
+    for k, b in enumerate(bufs):
+        h.process_frame_device(*b)
+        if k == 9:
+            h.sync()                                   # a wait in the middle: the held-back association runs alone
+            assert all(h.counts()[x] == ref[9][x] for x in ("count", "offset", "unstable_count", "fused_count", "conflict_count"))
+        if k == 17:
+            assert_models_equal(mid, h.download_model(), "in the middle")
+    h.sync()
+    same_counts(o, h, "end")
+    log = h.read_frame_log(64)
+    assert len(log) == len(seq) - 1                    # every fusing frame
+    for e, r in zip(log, ref[1:]):
+        assert (e["unstable_count"], e["fused_count"], e["conflict_count"]) == (r["unstable_count"], r["fused_count"], r["conflict_count"])
+    assert_models_equal(o.download_model(), h.download_model(), "end")
+    if thresh > 0:
+        assert sum(r["fused_count"] for r in ref) > 1000
