@@ -136,7 +136,11 @@ void sm_destroy(sm_ctx *s);
  * 4x4 camera->world (Eigen::Matrix4f storage).  Inputs are borrowed for the call only. */
 int sm_process_frame(sm_ctx *s, const uint8_t *rgb, const uint16_t *depth_mm,
                      const uint8_t *semantic, const float *pose16);
-/* Same, inputs already resident in device memory of this ctx's GPU; enqueue only.  (One bounded exception: when the model
+/* Same, inputs already resident in device memory of this ctx's GPU; enqueue only.  Without the depth filter chain the
+ * frame's last kernel (association + append) is held back and launched together with the NEXT call's image preparation
+ * (one launch less per frame); sm_sync and every entry point that reads the model launch it first, so the only visible
+ * effect is that a caller who never calls anything again must call sm_sync to have the last frame finished.
+ * SM_DEFER_ASSOC=0 turns this off.  (One bounded exception to "enqueue only": when the model
  * is within one frame of MAX_VERTICES and the host has run ahead of the device, the call waits up to SM_CAPACITY_WAIT_US
  * (default 2000) microseconds for the device's slot count before deciding whether this frame's cull must compact.) */
 int sm_process_frame_device(sm_ctx *s, const uint8_t *d_rgb, const uint16_t *d_depth_mm,
