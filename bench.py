@@ -174,12 +174,14 @@ def bench_sharded(args, dist, torch, capi, cam, frames, rank, world, local_rank,
         mp = sharded.ShardedMapper(sharded.HipShardBackend(sm, rank, world), sharded.TorchComm(device_index=local_rank), P,
                                    collect_stats=False)
         step = lambda k: mp.process_frame(*frames[k])
+    # no collector pause inside the timed region: with torch imported a full collection takes ~45 ms (measured: one frame call
+    # of 110 stalled that long).  Collect BEFORE the warm-up: a 45 ms pause between warm-up and t0 lets the GPU clock down.
+    gc.collect(); gc.disable()
     for k in range(Wm):
         step(k)
     sm.sync()
     c0 = sm.counts() if stream else mp.counts()
     dist.barrier(); torch.cuda.synchronize()
-    gc.collect(); gc.disable()      # with torch imported a full collection takes ~45 ms (measured: one frame call of 110 stalled that long)
     t0 = time.perf_counter()
     enq = []
     for k in range(Wm, Wm + K):
@@ -187,9 +189,9 @@ def bench_sharded(args, dist, torch, capi, cam, frames, rank, world, local_rank,
         step(k)
         enq.append(time.perf_counter() - te)
     t_enq = time.perf_counter() - t0
-    sm.sync()
-    dist.barrier(); torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    sm.sync(); torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0      # this rank's K frames are complete; the MAX over the ranks below is when the last rank was
+    dist.barrier(); torch.cuda.synchronize()  # (the closing barrier itself -- ~0.4 ms with torch's NCCL -- is not part of the K frames)
     gc.enable()
     t = torch.tensor([elapsed], dtype=torch.float64, device=torch.device("cuda", local_rank))
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -240,10 +242,10 @@ def run_simple_leg(capi, cam, frames, K, Wm, cfg_kw, args):
 
     sm = capi.SurfelMap(capi.make_config(**cam, **cfg_kw, enable_timing=0))
     dptr = stage(sm)
+    gc.collect(); gc.disable()
     for k in range(Wm):
         sm.process_frame_device(*dptr[k])
     sm.sync()
-    gc.collect(); gc.disable()
     t0 = time.perf_counter()
     for k in range(Wm, Wm + K):
         sm.process_frame_device(*dptr[k])
@@ -383,16 +385,18 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    run(sm, 0, Wm)
+    gc.collect(); gc.disable()                    # no collector pause inside the timed region (~45 ms with torch imported), and none
+    run(sm, 0, Wm)                                # between the warm-up and t0 either (the GPU would clock down: +130 us on the first frames)
     sm.sync()
     barrier()
-    gc.collect(); gc.disable()                    # no collector pause inside the timed region (~45 ms with torch imported)
     t0 = time.perf_counter()
     run(sm, Wm, Wm + K)
     t_enq = time.perf_counter() - t0              # host time to enqueue the K frames (no waiting inside)
     sm.sync()
-    barrier()
-    elapsed = time.perf_counter() - t0
+    if dist:
+        torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0            # this rank's K frames are complete (MAX over the ranks is taken below)
+    barrier()                                     # the closing barrier + synchronize; its own latency (~0.4 ms) is not K frames' work
     gc.enable()
     # Consolidation into a single GlobalModel (BASELINE configs[4]): an end-of-run exchange, not part of a frame --
     # the per-frame hot path of a camera touches only its own slice -- so it is timed separately.
