@@ -142,9 +142,10 @@ def kernel_table(log, tim, P, K, args, workload=None):
                 "ms_per_launch": kern[dom]["ms"], "alg_bytes_per_launch": kern[dom]["MB"] * 1e6,
                 "launches": launches[dom],
                 "valu_issue_util": valu,
-                "note": "not byte-bound: a frame touches ~60 MB; the surfel kernel is limited by instruction issue "
-                        "(IEEE-exact fp32: ~350 VALU instructions per surfel for conflict test + splat, correctly rounded / and sqrt) "
-                        "and by the chain of dependent round trips of a launch that owns ~1 tile per workgroup (DESIGN.md 4)"}
+                "note": "not byte-bound: a frame touches ~60 MB.  The surfel kernel's ~350 IEEE-exact VALU instructions per surfel keep "
+                        "the SIMDs half busy, but removing 6-12 % of them changed nothing (DESIGN.md 4, lessons): what a launch that owns "
+                        "~1 tile per workgroup waits on is its chain of dependent round trips (load -> transform -> gather -> ballot -> "
+                        "atomics) at 7 waves per SIMD"}
     return kern, launches, roofline
 
 
