@@ -1063,9 +1063,9 @@ int enqueue_frame(sm_ctx *s, const uint8_t *d_rgb, const uint16_t *d_raw, const 
     const bool fusing = s->ref_set && s->tick != 0 && !s->pending_cull;
     const bool compact_now = fusing ? decide_compact(s) : true;
     s->want_list = fusing && !compact_now && s->one_pass && s->use_list && !s->use_fused_assoc && !s->overlap;
-    // a held-back association rides on this frame's k_prep launch if this is again a frame of the one-pass form; anything else
-    // (a compacting frame, the frame after reset, ...) needs its results first
-    s->merge_assoc = s->assoc_pending && s->want_list && s->defer_ok;
+    // a held-back association rides on this frame's k_prep launch if this is again a fusing frame; anything else (the frame
+    // after reset, ...) needs its results first
+    s->merge_assoc = s->assoc_pending && fusing && s->defer_ok;       // (a compacting frame too: its k_prep launch has no tile flags to make)
     int rc = SM_OK;
     if (s->assoc_pending && !s->merge_assoc && (rc = flush_assoc(s))) return rc;
     rc = begin_frame(s, d_rgb, d_raw, d_sem, pose, &fp);
