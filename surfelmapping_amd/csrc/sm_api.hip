@@ -317,7 +317,7 @@ struct sm_ctx {
     bool direct = true;                // SM_DIRECT_APPEND=0: k_associate + k_append_scan on every frame
     uint32_t *d_blk_cand = nullptr, *d_grp_cand = nullptr;
     uint32_t *d_frame_sub = nullptr;   // 4 x 64 sub-counters: visible, killed (k_surfel_pass), new, fused (k_associate_direct)
-    uint32_t n_grp = 0;
+    uint32_t n_grp = 0, cand_group = 16;
     bool pend_finalize = false;        // the last frame's statistics are completed by the next k_pass_fixup or by k_frame_finalize
     int fix_set = 0;                   // k_pass_fixup's partials alternate between two sets (the previous frame's are read one frame later)
     int pass_nw = 2;                   // 64-slot words a wave of k_surfel_pass settles at a time (SM_PASS_NW = 1, 2, 4)
@@ -646,7 +646,7 @@ int launch_surfel_pass(sm_ctx *s, const FrameParams &fp, bool timed, bool direct
     DirectArgs da;
     memset(&da, 0, sizeof da);
     da.on = direct ? 1 : 0;
-    da.blk_cand = s->d_blk_cand; da.grp_cand = s->d_grp_cand; da.n_grp = s->n_grp; da.n_pix_blocks = s->n_pix_blocks;
+    da.blk_cand = s->d_blk_cand; da.grp_cand = s->d_grp_cand; da.n_grp = s->n_grp; da.cg = s->cand_group; da.n_pix_blocks = s->n_pix_blocks;
     da.depthT = s->d_depthT; da.xs = s->d_xs; da.ys = s->d_ys;
     da.frame_sub = s->d_frame_sub;
     // (the previous frame's fixup partials: only if it appended directly and nothing has completed its statistics since)
@@ -666,7 +666,7 @@ void fill_assoc_args(const sm_ctx *s, const FrameParams &fp, AssocArgs &a)
     a.M = s->M; a.st = s->d_state; a.fp = fp;
     a.depthT = s->d_depthT; a.rgbsT = s->d_rgbsT; a.keyT = s->d_keyT; a.xs = s->d_xs; a.ys = s->d_ys;
     a.blk_cand = s->d_blk_cand; a.grp_cand = s->d_grp_cand; a.frame_sub = s->d_frame_sub; a.tb = s->d_tb;
-    a.alive = s->d_alive; a.tile_dead = s->d_tile_dead; a.n_grp = s->n_grp; a.host_stat = s->d_stat;
+    a.alive = s->d_alive; a.tile_dead = s->d_tile_dead; a.n_grp = s->n_grp; a.cg = s->cand_group; a.host_stat = s->d_stat;
 }
 
 // association + in-place fuse + direct append (the frame's last kernel; its statistics are completed later)
@@ -1268,8 +1268,12 @@ sm_ctx *sm_create(const sm_config *c)
          hipMemset(s->d_tile_flags, 0, s->tb_tiles) == hipSuccess;
     ok = ok && dalloc(&s->d_validmask, (P + 63) / 64 + 4) == SM_OK && dalloc(&s->d_fusedmask, (P + 63) / 64 + 4) == SM_OK;
     ok = ok && dalloc(&s->d_blk_cnt, (size_t)s->n_pix_blocks) == SM_OK;
-    s->n_grp = (uint32_t)((s->n_pix_blocks + CAND_GROUP - 1) / CAND_GROUP);
-    ok = ok && dalloc(&s->d_blk_cand, (size_t)s->n_grp * CAND_GROUP) == SM_OK && dalloc(&s->d_grp_cand, (size_t)s->n_grp) == SM_OK &&
+    // candidate groups: small groups make the counting workgroups short (k_pass_fixup 3.5 -> 2.5 us at 1242x375 with 4
+    // instead of 16 blocks per group) but every association wave sums all groups before its own: keep ~250-500 groups
+    s->cand_group = s->n_pix_blocks <= 2048 ? 4u : s->n_pix_blocks <= 4096 ? 8u : 16u;
+    if (const char *e = std::getenv("SM_CAND_GROUP")) { const int v = std::atoi(e); if (v == 4 || v == 8 || v == 16) s->cand_group = (uint32_t)v; }
+    s->n_grp = (uint32_t)((s->n_pix_blocks + s->cand_group - 1) / s->cand_group);
+    ok = ok && dalloc(&s->d_blk_cand, (size_t)s->n_grp * CAND_GROUP_MAX) == SM_OK && dalloc(&s->d_grp_cand, (size_t)s->n_grp) == SM_OK &&
          dalloc(&s->d_frame_sub, (size_t)4 * SUB_SET) == SM_OK && hipMemset(s->d_frame_sub, 0, (size_t)4 * SUB_SET * 4) == hipSuccess;
     ok = ok && dalloc(&s->d_blk_prefix, (size_t)s->n_pix_blocks) == SM_OK && dalloc(&s->d_desc, (size_t)s->n_pix_blocks) == SM_OK &&
          hipMemset(s->d_desc, 0, (size_t)s->n_pix_blocks * 8) == hipSuccess;
@@ -2321,7 +2325,7 @@ int sm_shard_frame_device(sm_ctx *s, const uint8_t *d_rgb, const uint16_t *d_dep
     ShardSettle &ss = s->ss_settle;
     ss.n = (uint32_t)s->n_pix_blocks; ss.st = s->d_state; ss.validmask = s->d_validmask; ss.ownmask = s->d_fusedmask; ss.gmask = s->d_gmask;
     ss.nwords = sh.nwords; ss.blk_cand = s->d_blk_cand; ss.grp_cand = s->d_grp_cand; ss.frame_sub = s->d_frame_sub; ss.alive = s->d_alive;
-    ss.tile_dead = s->d_tile_dead; ss.owner = sh.owner; ss.cap_pixels = s->cfg.conflict_cap ? (uint32_t)s->P : 0xFFFFFFFFu; ss.max_vertices = s->cap;
+    ss.tile_dead = s->d_tile_dead; ss.owner = sh.owner; ss.cap_pixels = s->cfg.conflict_cap ? (uint32_t)s->P : 0xFFFFFFFFu; ss.max_vertices = s->cap; ss.cg = s->cand_group;
     s->ss_settle_pending = true;
     if (std::getenv("SM_SHARD_SETTLE_NOW")) { s->pend_finalize = false; if ((rc = finalize_if_pending(s))) return rc; }   // A/B: settle as its own launch
     if ((rc = mark(s, 6, true)) || (rc = mark(s, 7, true))) return rc;

@@ -199,7 +199,7 @@ __device__ __forceinline__ void tile_prep_block(const FrameParams &fp, const Til
     }
 }
 
-constexpr int CAND_GROUP = 16;      // association blocks per candidate-counting workgroup (16 pixels per thread, all loads in flight together)
+constexpr int CAND_GROUP_MAX = 16;  // association blocks per candidate-counting workgroup: 4, 8 or 16, chosen per image size (sm_create: ~250-500 groups)
 
 // ---------------------------------------------------------------------------------------------
 // Slot-addressed sharding, the end of a frame: after the fused masks of all ranks were sum-reduced (gmask),
@@ -223,6 +223,7 @@ struct ShardSettle {
     uint32_t *tile_dead;
     int owner;
     uint32_t cap_pixels, max_vertices;
+    uint32_t cg;                      // association blocks per candidate group
 };
 
 // NSUB pixel blocks per workgroup (blockDim.x == NSUB * 256): sub-block = threadIdx.x / 256.  No early exit: every thread
@@ -242,11 +243,11 @@ __device__ __forceinline__ void shard_settle_body(const ShardSettle &a, uint32_t
     const bool in = blk < a.n && word < a.nwords;
     const uint64_t vw = in ? a.validmask[word] : 0ull, gw = in ? a.gmask[word] : 0ull, ow = in ? a.ownmask[word] : 0ull;
     const uint64_t foreign = gw & ~ow & vw;                       // fused by another rank
-    const uint32_t grp = blk / CAND_GROUP, in_grp = blk % CAND_GROUP;
+    const uint32_t grp = blk / a.cg, in_grp = blk % a.cg;
     uint32_t pre = 0;
     const bool need = a.owner != 0 && blk < a.n;                  // only the owner has slots to empty
     if (need) {
-        pre = (lane < (int)in_grp) ? a.blk_cand[grp * CAND_GROUP + lane] : 0u;
+        pre = (lane < (int)in_grp) ? a.blk_cand[grp * a.cg + lane] : 0u;
         for (uint32_t g = lane; g < grp; g += 64u) pre += a.grp_cand[g];
     }
     const uint32_t offset = a.st->offset;
@@ -1579,7 +1580,7 @@ __device__ __forceinline__ bool candidate_pixel(int q, const FrameParams &fp, co
     return (zl != 0.0f) & (zu != 0.0f) & (zr != 0.0f) & (zd != 0.0f) & (z > fp.min_depth) & (z < fp.max_depth) & (par == 1);
 }
 
-// Candidate pixels per association block (256 pixels) and per group of CAND_GROUP blocks, counted by the otherwise idle
+// Candidate pixels per association block (256 pixels) and per group of CAND_GROUP (4, 8 or 16) blocks, counted by the otherwise idle
 // worker workgroups of k_pass_fixup (they only depend on the frame).  (Inside k_surfel_pass, as extra workgroups, the
 // counting cost that kernel its register allocation: 194 v_readlane SGPR spills, 16.5 -> 19.5 us.)  With them every
 // candidate pixel owns a model slot before the association runs: slot = offset + (candidates before it in pixel order).
@@ -1587,6 +1588,7 @@ __device__ __forceinline__ bool candidate_pixel(int q, const FrameParams &fp, co
 // unstable.vert) with no count that depends on the association itself -- and marks the slots of pixels that fuse instead
 // as dead, which the deferred compaction squeezes out like any other dead slot.
 
+template <int CAND_GROUP>
 __device__ __forceinline__ void cand_count_block(uint32_t cg, const FrameParams &fp, const float *__restrict__ depthT,
                                                  const float *__restrict__ xs, const float *__restrict__ ys, int nblocks,
                                                  uint32_t *__restrict__ blk_cand, uint32_t *__restrict__ grp_cand)
@@ -1849,7 +1851,7 @@ __device__ __forceinline__ uint64_t ineffective_conflicts(uint64_t c, uint32_t b
 struct DirectArgs {
     int on;                              // 1: this frame appends directly (k_associate_direct follows; no k_append_scan)
     uint32_t *blk_cand, *grp_cand;       // out: candidate pixels per association block / per group of CAND_GROUP blocks (this frame)
-    uint32_t n_grp;
+    uint32_t n_grp, cg;                  // groups; association blocks per group (4, 8 or 16)
     int n_pix_blocks;
     const float *depthT, *xs, *ys;
     uint32_t *frame_sub;                 // 4 x 64 sub-counters: visible, killed (this frame's pass); new, fused (the PREVIOUS frame's association)
@@ -2072,7 +2074,11 @@ __global__ __launch_bounds__(256) void k_pass_fixup(Model M, DevState *__restric
     const uint32_t wi = blockIdx.x - 1u;
     // ---- direct append: the candidate pixels of the frame, per association block and per group (workgroup-uniform loop)
     if (da.on)
-        for (uint32_t g = wi; g < da.n_grp; g += nwg) cand_count_block(g, fp, da.depthT, da.xs, da.ys, da.n_pix_blocks, da.blk_cand, da.grp_cand);
+        for (uint32_t g = wi; g < da.n_grp; g += nwg) {          // (da.cg is uniform)
+            if (da.cg == 4u) cand_count_block<4>(g, fp, da.depthT, da.xs, da.ys, da.n_pix_blocks, da.blk_cand, da.grp_cand);
+            else if (da.cg == 8u) cand_count_block<8>(g, fp, da.depthT, da.xs, da.ys, da.n_pix_blocks, da.blk_cand, da.grp_cand);
+            else cand_count_block<16>(g, fp, da.depthT, da.xs, da.ys, da.n_pix_blocks, da.blk_cand, da.grp_cand);
+        }
     if (!cap_binds) return;
     // ---- the cap binds: take the conflicts beyond the first `cap` back
     const SurfelSet set = M.s[st->cur];
@@ -2457,7 +2463,7 @@ struct AssocArgs {
     const float *depthT; const uint32_t *rgbsT; const uint64_t *keyT; const float *xs, *ys;
     const uint32_t *blk_cand /* candidate pixels per block ... */, *grp_cand /* ... and per group of CAND_GROUP blocks */;
     uint32_t *frame_sub /* sets 2, 3: new, fused -- 64 sub-counters each */, *tb;
-    uint64_t *alive; uint32_t *tile_dead; uint32_t n_grp; unsigned long long *host_stat;
+    uint64_t *alive; uint32_t *tile_dead; uint32_t n_grp, cg; unsigned long long *host_stat;
 };
 
 // one association block (PIX_BLOCK pixels, 256 threads); blk = its index in pixel order
@@ -2479,8 +2485,8 @@ __device__ __forceinline__ void associate_direct_block(const AssocArgs &a, const
     if (threadIdx.x < 2) s_dead[threadIdx.x] = 0u;
     // candidates before this block = the groups before its group + the blocks of its group before it: a few loads per lane,
     // issued together with DevState, one wave reduction (every wave computes it for itself)
-    const uint32_t grp = blk / CAND_GROUP, in_grp = blk % CAND_GROUP;
-    uint32_t pre = (lane < (int)in_grp) ? blk_cand[grp * CAND_GROUP + lane] : 0u;
+    const uint32_t grp = blk / a.cg, in_grp = blk % a.cg;
+    uint32_t pre = (lane < (int)in_grp) ? blk_cand[grp * a.cg + lane] : 0u;
     for (uint32_t g = lane; g < grp; g += 64u) pre += grp_cand[g];
     const SurfelSet cur = M.s[st->cur];
     const uint32_t offset = st->offset;
