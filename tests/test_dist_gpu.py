@@ -118,11 +118,12 @@ def test_other_process_on_the_gpu_is_detected(tmp_path):
     p = subprocess.Popen([sys.executable, str(f)], stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True)
     try:
         assert "HOLDING" in p.stdout.readline()
-        assert sm.gpu_process_count() == alone + 1
+        during = sm.gpu_process_count()
+        assert during >= alone + 1          # (>=: a monitoring tool may open the device at any time)
     finally:
         try:
             p.communicate(input="\n", timeout=60)
         except subprocess.TimeoutExpired:
             p.kill()
     time.sleep(0.2)
-    assert sm.gpu_process_count() == alone
+    assert sm.gpu_process_count() <= during - 1
