@@ -1742,10 +1742,10 @@ __device__ __forceinline__ void pass_quarter(const SurfelSet &set, DevState *__r
                                              uint4 *__restrict__ wave_cnt, uint64_t *__restrict__ alive,
                                              uint32_t *__restrict__ tile_dead, uint64_t *__restrict__ keyT, float *__restrict__ undo,
                                              uint32_t N, uint32_t exempt, uint32_t tile, uint32_t quarter, bool sk0, bool sk1,
-                                             bool any_dead, int lane, PassAcc &acc)
+                                             bool any_dead, int lane, PassAcc &acc, uint32_t *__restrict__ tb)
 {
     const uint32_t word0 = tile * TILE_WORDS + quarter * 4u;
-    const uint32_t k0 = acc.killed;
+    const uint32_t k0 = acc.killed, v0 = acc.vis;
     uint32_t cwave = 0;
 #pragma unroll 1
     for (int h = 0; h < 4; h += NW)
@@ -1753,6 +1753,12 @@ __device__ __forceinline__ void pass_quarter(const SurfelSet &set, DevState *__r
     if (lane == 0) reinterpret_cast<uint32_t *>(wave_cnt)[(size_t)tile * 4 + quarter] = cwave;
     const uint32_t killed = acc.killed - k0;
     if (killed && lane == 0) atomicAdd(&tile_dead[tile], killed);
+    // Something of this quarter tile went into the index map, so it can be fused in this frame: stamp the tile's box with the
+    // frame's time.  (k_associate_direct leaves the time word to this kernel; "drawn at t" is never older than the last update
+    // of any surfel of the tile.  Stamping every VISITED tile would do for that, but the stamp also tells the next frame's
+    // tile flags -- computed while this frame's association may still be moving surfels, k_assoc_prep -- which tiles not to
+    // skip: a tile that merely keeps being visited must not keep itself alive that way.)
+    if (acc.vis != v0 && lane == 0) atomicMax(&tb[(size_t)tile * 8 + 7], f2ord((float)fp.time));
     acc.nconf += cwave;
 }
 
@@ -1820,11 +1826,8 @@ __global__ __launch_bounds__(256) void k_surfel_pass(Model M, DevState *__restri
             if (!READY && threadIdx.x == 0) wave_cnt[tile] = make_uint4(0u, 0u, 0u, 0u);
             continue;
         }
-        // the tile can reach the index map, so its surfels can be fused in this frame (k_associate_direct leaves the box's time
-        // word to this kernel): stamp it -- "in view now" is never older than the last update of any of its surfels
-        if (!sk1 && threadIdx.x == 0) atomicMax(&tb[(size_t)tile * 8 + 7], f2ord((float)fp.time));
         pass_quarter<NW>(set, st, fp, dcT, cm, km, wave_cnt, alive, tile_dead, keyT, undo, N, exempt, tile, wave, sk0, sk1,
-                         lane_bcast(m_dead, sl) != 0u, lane, acc);
+                         lane_bcast(m_dead, sl) != 0u, lane, acc, tb);
     }
     __syncthreads();
     if (lane == 0) { s_a[wave] = acc.vis; s_b[wave] = acc.killed; s_c[wave] = acc.nconf; }
