@@ -102,10 +102,18 @@ def kernel_table(log, tim, P, K, args, workload=None):
     # (one-pass <=> not compacted on the default path; direct <=> one-pass and k_prep evaluated the tile flags)
     sel_op = ~moved if n_op else np.zeros(len(log), bool)
     sel_dir = sel_op if n_dir == n_op else np.zeros(len(log), bool)
-    rows = [("k_prep", tim["k_prep"], np.ones(len(log), bool), K),
+    # asynchronous plain streams: a frame's association is held back and runs in the NEXT frame's preparation launch (k_assoc_prep)
+    n_mrg, n_alone = int(tim.get("frames_merged", 0)), int(tim.get("frames_assoc_alone", n_dir))
+    sel_mrg = np.zeros(len(log), bool)
+    if n_mrg and len(log):
+        sel_mrg[1:] = sel_dir[:-1]                        # frame k's launch carries frame k-1's association
+        sel_mrg[0] = n_mrg > int(sel_mrg.sum())           # (the last warm-up frame's, if the counts say so)
+        kb["k_assoc_prep"] = kb["k_prep"] + np.concatenate([kb["k_associate_direct"][:1], kb["k_associate_direct"][:-1]])
+    rows = [("k_prep", tim.get("k_prep_own", tim["k_prep"]) if n_mrg else tim["k_prep"], ~sel_mrg, K - n_mrg),
+            ("k_assoc_prep", tim.get("k_assoc_prep", 0.0), sel_mrg, n_mrg),
             ("k_surfel_pass", tim.get("k_surfel_pass", 0.0), sel_op, n_op),
             ("k_pass_fixup", tim.get("k_pass_fixup", 0.0), sel_op, n_op),
-            ("k_associate_direct", tim.get("k_associate_direct", 0.0), sel_dir, n_dir),
+            ("k_associate_direct", tim.get("k_associate_direct", 0.0), sel_dir, n_alone),
             ("k_conflict", tim.get("k_conflict_own", 0.0), ~sel_op, K - n_op),
             ("k_compact", tim.get("k_compact_own", 0.0), moved, n_comp),
             ("k_associate", tim.get("k_associate_own", 0.0), ~sel_dir, K - n_dir),
@@ -535,9 +543,8 @@ def main():
                                  f"GlobalModel of {global_count} surfels ({gather_ms:.1f} ms, not in `value`)") if dist else "single stream",
                    "host_sync": "per frame" if args.sync_every_frame else "none inside the timed region",
                    "frame_form": ("four launches per frame" if (args.preprocess or args.sync_every_frame or os.environ.get("SM_DEFER_ASSOC", "1") == "0") else
-                                  "value: three launches per frame (k_assoc_prep = the previous frame's association + this frame's image "
-                                  "preparation, then k_surfel_pass, k_pass_fixup; DESIGN.md 4); kernels / roofline: the same frames on a context "
-                                  "with per-kernel events, which launches k_prep and k_associate_direct separately"),
+                                  "three launches per frame (k_assoc_prep = the previous frame's association + this frame's image "
+                                  "preparation, then k_surfel_pass, k_pass_fixup; DESIGN.md 4)"),
                    "compaction": (f"deferred: culled surfels keep their slots, every {args.compact_period}th cull compacts "
                                   f"({int((log['n_static'] < log['n_slots']).sum()) if len(log) else 0} of {K} timed frames moved surfels)")
                                  if args.compact_period > 1 else "every frame",

@@ -96,6 +96,10 @@ typedef struct sm_timings {
     float k_surfel_pass, k_pass_fixup, k_conflict_own;
     float k_associate_direct, k_associate_own, k_append_own;
     uint32_t frames_one_pass, frames_direct;
+    /* asynchronous plain streams: frames whose preparation launch also carried the previous frame's association
+     * (k_assoc_prep); k_prep_own / k_associate_direct then average only over the frames that launched those kernels alone */
+    float k_assoc_prep, k_prep_own;
+    uint32_t frames_merged, frames_assoc_alone;
 } sm_timings;
 
 /* Per-frame counters written by the device at the end of every fusing frame (ring of

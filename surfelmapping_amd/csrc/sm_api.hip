@@ -308,6 +308,8 @@ struct sm_ctx {
     uint32_t n_fix_part = 0;           // worker workgroups of the last k_pass_fixup
     bool ev_one_pass[EV_RING] = {};    // which frames of the event ring ran the one-pass kernels
     bool ev_direct[EV_RING] = {};      // ... and appended directly
+    bool ev_merged[EV_RING] = {};      // the frame's preparation launch was k_assoc_prep (it carried the previous frame's association)
+    bool ev_deferred[EV_RING] = {};    // the frame's own association was held back (no kernel between its marks 4 and 5)
     // tile skip flags of the frame, evaluated by extra workgroups of k_prep (when k_prep runs after the previous frame: no second stream)
     uint2 *d_prep_part = nullptr;
     uint32_t n_prep_blocks = 0;        // flag workgroups the frame's k_prep ran (0: the pass kernel evaluates the flags itself)
@@ -534,6 +536,7 @@ int launch_prep(sm_ctx *s, const uint8_t *rgb, const uint16_t *raw, const uint8_
         tp.st = s->d_state; tp.tb = s->d_tb; tp.tile_flags = s->d_tile_flags; tp.wave_cnt = s->d_wave_cnt; tp.prep_part = s->d_prep_part;
         s->n_prep_blocks = tp.nfb;
     }
+    if (s->ev_ok) s->ev_merged[s->ev_frames % EV_RING] = s->merge_assoc;
     if (s->merge_assoc) {
         // the held-back association of the previous frame + this frame's tile flags + its image tiles in one launch
         s->merge_assoc = false;
@@ -676,6 +679,7 @@ int launch_associate_direct(sm_ctx *s, const FrameParams &fp, bool timed)
     memset(&sh, 0, sizeof sh);
     AssocArgs a;
     fill_assoc_args(s, fp, a);
+    if (s->ev_ok && timed) s->ev_deferred[s->ev_frames % EV_RING] = s->defer_ok;
     if (s->defer_ok && timed) {
         // asynchronous plain stream: hold the association back; the next frame's k_prep launch carries it (k_assoc_prep),
         // anything else that needs its results launches it first (flush_assoc, reached through finalize_if_pending)
@@ -1241,7 +1245,7 @@ sm_ctx *sm_create(const sm_config *c)
     // deferred association: only plain asynchronous streams without the depth filter chain and without per-kernel timing
     {
         const char *e = std::getenv("SM_DEFER_ASSOC");                    // "0": every frame launches its own association
-        s->defer_ok = c->preprocess == 0 && !c->enable_timing && !(e && e[0] == '0');
+        s->defer_ok = c->preprocess == 0 && !(e && e[0] == '0');
     }
     if (s->overlap_capable || s->defer_ok)
         ok = ok && dalloc(&s->d_depthT_nx, P) == SM_OK && dalloc(&s->d_rgbsT_nx, P) == SM_OK && dalloc(&s->d_keyT_nx, P) == SM_OK &&
@@ -1801,7 +1805,8 @@ int sm_stage_timings(sm_ctx *s, sm_timings *out)
     if (s->ev_frames - first > EV_RING) first = s->ev_frames - EV_RING;
     double seg[7] = {0}, run = 0, ovh = 0, cull[2] = {0, 0};
     double own[6] = {0};          // pass, fixup (one-pass frames) | conflict (others) | associate (direct) | associate, append (others)
-    uint32_t nfr = 0, ncls[2] = {0, 0}, n_op = 0, n_dir = 0;
+    double prep2[2] = {0, 0};     // k_prep alone | k_assoc_prep
+    uint32_t nfr = 0, ncls[2] = {0, 0}, n_op = 0, n_dir = 0, n_merged = 0, n_alone = 0;
     for (uint64_t f = first; f < s->ev_frames; ++f) {
         const int slot = (int)(f % EV_RING);
         float ms = 0;
@@ -1819,7 +1824,9 @@ int sm_stage_timings(sm_ctx *s, sm_timings *out)
         cull[s->ev_compacted[slot] ? 1 : 0] += loc[3];
         ncls[s->ev_compacted[slot] ? 1 : 0]++;
         if (s->ev_one_pass[slot]) { own[0] += loc[1]; own[1] += loc[3]; n_op++; } else own[2] += loc[1];
-        if (s->ev_direct[slot]) { own[3] += loc[4]; n_dir++; } else { own[4] += loc[4]; own[5] += loc[6]; }
+        if (s->ev_direct[slot]) { n_dir++; if (!s->ev_deferred[slot]) { own[3] += loc[4]; n_alone++; } } else { own[4] += loc[4]; own[5] += loc[6]; }
+        prep2[s->ev_merged[slot] ? 1 : 0] += loc[0];
+        if (s->ev_merged[slot]) n_merged++;
         run += ms;
         ovh += o;
         nfr++;
@@ -1841,8 +1848,10 @@ int sm_stage_timings(sm_ctx *s, sm_timings *out)
         out->frames_compact = ncls[1];
         auto avg = [&](double sum, uint32_t n) { return n ? (float)std::max(0.0, sum / n - oh) : 0.0f; };
         out->k_surfel_pass = avg(own[0], n_op); out->k_pass_fixup = avg(own[1], n_op); out->k_conflict_own = avg(own[2], nfr - n_op);
-        out->k_associate_direct = avg(own[3], n_dir); out->k_associate_own = avg(own[4], nfr - n_dir); out->k_append_own = avg(own[5], nfr - n_dir);
+        out->k_associate_direct = avg(own[3], n_alone); out->k_associate_own = avg(own[4], nfr - n_dir); out->k_append_own = avg(own[5], nfr - n_dir);
         out->frames_one_pass = n_op; out->frames_direct = n_dir;
+        out->k_assoc_prep = avg(prep2[1], n_merged); out->k_prep_own = avg(prep2[0], nfr - n_merged);
+        out->frames_merged = n_merged; out->frames_assoc_alone = n_alone;
         out->preprocess = out->k_prep;
         out->conflict = out->k_conflict + out->k_scan_cull + out->k_compact;
         out->index_map = 0.0f;

@@ -8,8 +8,8 @@
   pmc_sq/     --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY ... -> VALU issue utilisation
 
 `--last K` restricts every average to the launches of the last K frames, i.e. of bench.py's timed region (the earlier
-launches belong to its warm-up frames and to its un-instrumented pass): a frame starts with a `k_prep` launch, so
-everything dispatched from the K-th last `k_prep` on is averaged -- kernels that run only on some frames
+launches belong to its warm-up frames and to its un-instrumented pass): a frame starts with a `k_prep` or `k_assoc_prep`
+launch, so everything dispatched from the K-th last of those on is averaged -- kernels that run only on some frames
 (`k_compact` on compacting frames, `k_cull_lazy` on the others) are averaged over their own launches in that window.  gfx950 correction
 (/opt/skills/guides/MI355X_MICROARCH.md, HBM): FETCH_SIZE (KB) reports exactly 1/2 of the bytes
 of a wide coalesced streaming read -> doubled; WRITE_SIZE (KB) is exact.
@@ -89,9 +89,11 @@ def main():
 
     def window(per):
         """per: kernel -> sorted [(order key, value)]; returns kernel -> values inside the last `--last` frames"""
-        if not a.last or "k_prep" not in per or len(per["k_prep"]) < a.last:
+        # a frame starts with its preparation launch: k_prep, or k_assoc_prep when it also carries the previous frame's association
+        starts = sorted(x[0] for name in ("k_prep", "k_assoc_prep") for x in per.get(name, []))
+        if not a.last or len(starts) < a.last:
             return {k: [x[1] for x in v] for k, v in per.items()}
-        t0 = per["k_prep"][-a.last][0]
+        t0 = starts[-a.last]
         return {k: [x[1] for x in v if x[0] >= t0] for k, v in per.items()}
 
     tr = glob.glob(os.path.join(a.dir, "trace", "*", "*_kernel_trace.csv"))
