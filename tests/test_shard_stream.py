@@ -252,3 +252,57 @@ def test_stream_shards_kitti_size():
             assert all(a[k] == b[k] for k in KEYS), (r, f, {k: (a[k], b[k]) for k in KEYS})
     union = sharded.StreamShard.union([x[0] for x in out])
     assert union.shape == ref.shape and np.array_equal(union.view(np.uint32), ref.view(np.uint32))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(10))
+def test_stream_shards_random_configurations(seed):
+    """seeded random image sizes, thresholds, noise, compaction periods, rank counts, filter chain on / off, one export in the
+    middle: the union and the counters of every frame against the oracle"""
+    rng = np.random.default_rng(1000 + seed)
+    W, H = int(rng.integers(96, 260)), int(rng.integers(48, 130))
+    cam = dict(width=W, height=H, fx=float(rng.uniform(80, 160)), fy=float(rng.uniform(80, 160)), cx=W / 2 - 0.5, cy=H / 2 - 0.5)
+    G = int(rng.integers(1, 5))
+    over = dict(preprocess=int(rng.integers(0, 2)), stereo_border=float(rng.choice([0.0, 8.0, 20.0])), max_sqrt_vertices=420,
+                fuse_thresh=float(rng.choice([0.0, 0.03, 0.08])))
+    period = int(rng.choice([1, 2, 3, 5, 8, 1000]))
+    n = int(rng.integers(6, 13))
+    seq = synth.make_sequence(cam, synth.kitti_trajectory(n), seed=int(rng.integers(1, 1000)), noise_mm=float(rng.choice([0.0, 2.0, 6.0])))
+    mid_at = int(rng.integers(1, n - 1))
+    o = ol.Oracle(ol.make_config(**cam, **over))
+    ref_counts, mid_ref = [], None
+    for k, fr in enumerate(seq):
+        o.process_frame(*fr)
+        ref_counts.append(o.counts())
+        if k == mid_at:
+            mid_ref = o.download_model()
+    ref = o.download_model()
+    grp = sharded.ThreadGroup(G)
+    out, errs = [None] * G, []
+
+    def work(r):
+        try:
+            sm = capi.SurfelMap(capi.make_config(**cam, **over, compact_period=period))
+            mp = sharded.StreamShard(sm, r, G, sharded.ThreadCollective(grp, r, sm) if G > 1 else None)
+            cs, mid = [], None
+            for k, fr in enumerate(seq):
+                cs.append(mp.process_frame(*fr))
+                if k == mid_at:
+                    mid = mp.export_dense()
+            out[r] = (mp.export_dense(), cs, mid)
+            sm.close()
+        except Exception as e:
+            errs.append((r, repr(e)))
+            grp.barrier.abort()
+
+    ts = [threading.Thread(target=work, args=(r,)) for r in range(G)]
+    [t.start() for t in ts]
+    [t.join(600) for t in ts]
+    assert not errs, (errs, cam, G, over, period)
+    for r in range(G):
+        for f, (a, b) in enumerate(zip(out[r][1], ref_counts)):
+            assert all(a[k] == b[k] for k in KEYS), (seed, r, f, {k: (a[k], b[k]) for k in KEYS}, cam, G, over, period)
+    mid = sharded.StreamShard.union([x[2] for x in out])
+    fin = sharded.StreamShard.union([x[0] for x in out])
+    assert mid.shape == mid_ref.shape and np.array_equal(mid.view(np.uint32), mid_ref.view(np.uint32)), (seed, "mid")
+    assert fin.shape == ref.shape and np.array_equal(fin.view(np.uint32), ref.view(np.uint32)), (seed, "end")
