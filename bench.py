@@ -415,12 +415,18 @@ def main():
         sm_global = capi.SurfelMap(capi.make_config(**cam, preprocess=0, device=local_rank, max_sqrt_vertices=10000 if (hd or world > 2) else 5000))
         rig = smd.RigMapper(sm, smsh.TorchComm(device_index=local_rank), P)
         rig.last = (frames[Wm + K - 1][1], frames[Wm + K - 1][2], frames[Wm + K - 1][3])     # the camera's latest view
+        # the consolidation runs inside the HIP core (sm_rig_consolidate), its exchanges on RCCL bound by the core itself;
+        # torch.distributed only hands the communicator id round
+        ids = [capi.rccl_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        rig.enable_native("rccl", ids[0])
         barrier()
         g0 = time.perf_counter()
-        # every slice cleaned against every camera's latest view (cleanPoints per view), then the RCCL gather on device buffers
-        global_count, gcounts, view_conflicts = rig.consolidate(device_index=local_rank, sm_global=sm_global)
+        # every slice cleaned against every camera's latest view (cleanPoints per view), then the slices gathered in rank order
+        global_count, view_conflicts = rig.consolidate_native(sm_global)
         barrier()
         gather_ms = (time.perf_counter() - g0) * 1e3
+        sm.shard_rccl_finalize()
     log = sm.read_frame_log(K)
     counts = sm.counts()
 
@@ -539,8 +545,8 @@ def main():
                                + f"depth noise {args.noise_mm} mm, metricise+conflict+cull+splat+associate+fuse+append per frame"
                                + (" + depth pre-processing p0b..p0e" if args.preprocess else ""),
                    "frames": f"{Wm}..{Wm + K - 1}", "multi_gpu": (f"{world}-camera rig, one stream per GPU; consolidation after the timed frames: every slice cleaned "
-                                 f"against all {world} latest views (cleanPoints per view, {sum(view_conflicts)} conflicts), RCCL all-gather into a single "
-                                 f"GlobalModel of {global_count} surfels ({gather_ms:.1f} ms, not in `value`)") if dist else "single stream",
+                                 f"against all {world} latest views (cleanPoints per view, {sum(view_conflicts)} conflicts), slices gathered in rank order into a single "
+                                 f"GlobalModel of {global_count} surfels, all inside the HIP core over RCCL (sm_rig_consolidate: {gather_ms:.1f} ms, not in `value`)") if dist else "single stream",
                    "host_sync": "per frame" if args.sync_every_frame else "none inside the timed region",
                    "frame_form": ("four launches per frame" if (args.preprocess or args.sync_every_frame or os.environ.get("SM_DEFER_ASSOC", "1") == "0") else
                                   "three launches per frame (k_assoc_prep = the previous frame's association + this frame's image "

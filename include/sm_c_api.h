@@ -296,6 +296,18 @@ int sm_shard_compact(sm_ctx *s);
  * in the other ranks' slots -- the integer (u32) sum over the ranks is the single GlobalModel in the reference's order */
 int sm_shard_export_dense_device(sm_ctx *s, const float **d_out12, uint32_t *count);
 
+/* ---- BASELINE configs[4]: a rig of `world` cameras, one context per rank (GPU), consolidated into a single GlobalModel.
+ * Frames use sm_process_frame[_device] (no collective).  sm_rig_consolidate is collective: every rank passes its camera's
+ * latest view; the union of the slices in rank order is cleaned against every view in rank order with
+ * SurfelMapping::cleanPoints (src/SurfelMapping.cpp:496-532), each rank cleaning its own slice, and the cleaned slices are
+ * appended in rank order to `global` (another context on the same GPU) on every rank.  The collective is the one installed
+ * with sm_shard_rccl_init / sm_shard_set_collective after sm_rig_configure (world 1: none needed).
+ * view_conflicts[world] (may be null): conflicts per view over all slices; a view with more conflicts than pixels fails with
+ * SM_E_UNSUPPORTED (the reference's conflict cap acts in global surfel order). */
+int sm_rig_configure(sm_ctx *s, int rank, int world);
+int sm_rig_consolidate(sm_ctx *s, const uint16_t *depth_mm, const uint8_t *semantic, const float *pose16, sm_ctx *global,
+                       uint32_t *view_conflicts, uint32_t *total);
+
 #ifdef __cplusplus
 }
 #endif

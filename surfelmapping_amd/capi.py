@@ -29,7 +29,7 @@ SYMBOLS = (
     "sm_shard_conflict", "sm_shard_cull_splat", "sm_shard_associate", "sm_shard_append",
     "sm_shard_stream_configure", "sm_shard_set_collective", "sm_shard_rccl_unique_id", "sm_shard_rccl_init",
     "sm_shard_rccl_finalize", "sm_shard_frame_device", "sm_shard_frame", "sm_shard_compact", "sm_shard_export_dense_device",
-    "sm_gpu_process_count",
+    "sm_gpu_process_count", "sm_rig_configure", "sm_rig_consolidate",
 )
 
 SM_COLL_SUM, SM_COLL_MIN = 0, 1
@@ -210,6 +210,8 @@ def load():
     L.sm_shard_compact.argtypes = [vp]
     L.sm_shard_export_dense_device.argtypes = [vp, C.POINTER(vp), u32p]
     L.sm_gpu_process_count.argtypes = [vp]
+    L.sm_rig_configure.argtypes = [vp, C.c_int, C.c_int]
+    L.sm_rig_consolidate.argtypes = [vp, vp, vp, vp, vp, u32p, u32p]
     L.sm_key_map_device_ptr.restype = vp
     L.sm_key_map_device_ptr.argtypes = [vp]
     for name in SYMBOLS:
@@ -512,6 +514,25 @@ class SurfelMap:
         if n == 0:
             return np.zeros((0, 12), np.float32)
         return self.device_download(p, n * 48, np.float32).reshape(n, 12)
+
+    # -- rig mode (configs[4]): consolidation into a single GlobalModel inside the core
+    def rig_configure(self, rank, world):
+        self._chk(self._L.sm_rig_configure(self._h, rank, world), "sm_rig_configure")
+        self._rig_world = world
+
+    def rig_consolidate(self, depth, sem, pose, sm_global):
+        """collective: -> (surfels in the single GlobalModel now appended to `sm_global`, conflicts per view)"""
+        depth = np.ascontiguousarray(depth, np.uint16)
+        sem = np.ascontiguousarray(sem, np.uint8)
+        pose = np.ascontiguousarray(pose, np.float32)
+        per_view = (C.c_uint32 * max(getattr(self, "_rig_world", 1), 1))()
+        total = C.c_uint32()
+        rc = self._L.sm_rig_consolidate(self._h, _ptr(depth), _ptr(sem), _ptr(pose), sm_global._h, per_view, C.byref(total))
+        if rc and getattr(self, "_coll_error", None) is not None:
+            e, self._coll_error = self._coll_error, None
+            raise e
+        self._chk(rc, "sm_rig_consolidate")
+        return total.value, [int(x) for x in per_view]
 
     def gpu_process_count(self) -> int:
         """processes with compute queues on this context's GPU per the KFD tables (this one included); -1 if unreadable"""

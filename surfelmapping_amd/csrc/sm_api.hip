@@ -346,6 +346,7 @@ struct sm_ctx {
     bool sh_in_frame = false;
     // slot-addressed sharding of one stream, in-stream form (sm_shard_stream_*)
     bool ss_on = false;
+    bool rig_on = false;               // sm_rig_configure: rank / world / collective are used by sm_rig_consolidate only
     int ss_rank = 0, ss_world = 1;
     uint32_t ss_frames = 0;            // fusing frames so far = index of the next segment (its owner: index % world)
     sm_collective_fn ss_coll = nullptr;
@@ -1444,19 +1445,21 @@ int sm_clean_points(sm_ctx *s, const uint16_t *depth_mm, const uint8_t *semantic
     return sm_clean_points_ex(s, depth_mm, semantic, pose16, 1);
 }
 
-int sm_clean_points_ex(sm_ctx *s, const uint16_t *depth_mm, const uint8_t *semantic, const float *pose16, int exempt_first)
+}  // extern "C"
+
+namespace {
+// SurfelMapping::cleanPoints with the view already in device memory (sm_clean_points_ex uploads it; sm_rig_consolidate
+// takes it from the gathered views of the rig)
+int clean_points_device(sm_ctx *s, const uint16_t *d_depth_mm, const uint8_t *d_semantic, const float *pose16, int exempt_first)
 {
-    if (!s || !depth_mm || !semantic || !pose16) { g_err = "sm_clean_points: null argument"; return SM_E_ARG; }
-    HIPCK(hipSetDevice(s->cfg.device));
     if (s->pending_cull) { g_err = "sm_stage_conflict without sm_stage_cull"; return SM_E_ARG; }
     // cleanPoints culls without redrawing the index map (src/SurfelMapping.cpp:496-532): the map keeps ids of the model
     // as it was, so they are settled (slot -> position) before this cull changes the positions
     int rc = ensure_compact(s);
     if (rc) return rc;
-    if ((rc = upload_inputs(s, nullptr, depth_mm, semantic))) return rc;
     memcpy(s->curr_pose, pose16, 64);
     FrameParams fp = make_params(s, pose16);
-    if ((rc = launch_prep(s, s->d_rgb, s->d_depth_raw, s->d_sem, nullptr, fp, false))) return rc;   // metriciseDepth only
+    if ((rc = launch_prep(s, s->d_rgb, d_depth_mm, d_semantic, nullptr, fp, false))) return rc;   // metriciseDepth only
     fp.max_depth = s->cfg.far_clip - 15.0f;     // src/SurfelMapping.cpp:515
     fp.conflict_thresh = 0.1f;                  // :516
     fp.is_clean = 1;                            // :517
@@ -1467,6 +1470,20 @@ int sm_clean_points_ex(sm_ctx *s, const uint16_t *depth_mm, const uint8_t *seman
     if ((rc = launch_compact(s, fp, false, false))) return rc;
     if ((rc = launch_post_fill(s))) return rc;
     return sm_sync(s);
+}
+}  // namespace
+
+extern "C" {
+
+int sm_clean_points_ex(sm_ctx *s, const uint16_t *depth_mm, const uint8_t *semantic, const float *pose16, int exempt_first)
+{
+    if (!s || !depth_mm || !semantic || !pose16) { g_err = "sm_clean_points: null argument"; return SM_E_ARG; }
+    HIPCK(hipSetDevice(s->cfg.device));
+    if (s->pending_cull) { g_err = "sm_stage_conflict without sm_stage_cull"; return SM_E_ARG; }
+    int rc = finalize_if_pending(s);             // (a held-back association still reads the staging buffers' frame planes)
+    if (rc) return rc;
+    if ((rc = upload_inputs(s, nullptr, depth_mm, semantic))) return rc;
+    return clean_points_device(s, s->d_depth_raw, s->d_sem, pose16, exempt_first);
 }
 
 int sm_reset(sm_ctx *s)
@@ -2226,7 +2243,7 @@ int sm_shard_stream_configure(sm_ctx *s, int rank, int world)
 
 int sm_shard_set_collective(sm_ctx *s, sm_collective_fn fn, void *user)
 {
-    if (!s || !s->ss_on) { g_err = "sm_shard_set_collective: call sm_shard_stream_configure first"; return SM_E_ARG; }
+    if (!s || !(s->ss_on || s->rig_on)) { g_err = "sm_shard_set_collective: call sm_shard_stream_configure or sm_rig_configure first"; return SM_E_ARG; }
     s->ss_coll = fn; s->ss_user = user;
     return SM_OK;
 }
@@ -2246,7 +2263,7 @@ int sm_shard_rccl_unique_id(void *out128)
 
 int sm_shard_rccl_init(sm_ctx *s, const void *id128)
 {
-    if (!s || !id128 || !s->ss_on) { g_err = "sm_shard_rccl_init: call sm_shard_stream_configure first"; return SM_E_ARG; }
+    if (!s || !id128 || !(s->ss_on || s->rig_on)) { g_err = "sm_shard_rccl_init: call sm_shard_stream_configure or sm_rig_configure first"; return SM_E_ARG; }
     HIPCK(hipSetDevice(s->cfg.device));
     if (hip_runtime_conflict("sm_shard_rccl_init")) return SM_E_HIP;
     int rc = load_rccl();
@@ -2377,6 +2394,100 @@ int sm_shard_export_dense_device(sm_ctx *s, const float **d_out12, uint32_t *cou
     *d_out12 = (const float *)s->d_export;
     *count = n;
     return SM_OK;
+}
+
+
+// ---- BASELINE configs[4]: a rig of `world` cameras, one per rank, consolidated into a single GlobalModel ----
+// Frames go through the ordinary entry points (no collective).  sm_rig_consolidate is the definition of DESIGN.md 6 --
+// union in rank order, cleanPoints against every camera's latest view in rank order -- entirely on the device: the views,
+// the slice sizes, the per-view conflict totals and the cleaned slices cross the ranks through the installed collective
+// (RCCL's all-reduce, or a callback); an all-gather is the sum of buffers that are zero outside the sender's part.
+
+int sm_rig_configure(sm_ctx *s, int rank, int world)
+{
+    if (!s || world < 1 || rank < 0 || rank >= world) return SM_E_ARG;
+    if (s->ss_on || s->sh_world > 1) { g_err = "sm_rig_configure: the context is configured for sharding"; return SM_E_ARG; }
+    s->rig_on = true; s->ss_rank = rank; s->ss_world = world;
+    return SM_OK;
+}
+
+int sm_rig_consolidate(sm_ctx *s, const uint16_t *depth_mm, const uint8_t *semantic, const float *pose16, sm_ctx *global,
+                       uint32_t *view_conflicts, uint32_t *total_out)
+{
+    if (!s || !depth_mm || !semantic || !pose16 || !global || !s->rig_on) { g_err = "sm_rig_consolidate: bad argument (sm_rig_configure first)"; return SM_E_ARG; }
+    HIPCK(hipSetDevice(s->cfg.device));
+    if (hip_runtime_conflict("sm_rig_consolidate")) return SM_E_HIP;
+    const int W = s->ss_world, r = s->ss_rank;
+    const size_t P = (size_t)s->P;
+    const size_t off_sem = 2 * P, off_pose = (3 * P + 7) / 8 * 8, row = off_pose + 64;        // bytes of one view (a multiple of 8)
+    int rc = finalize_if_pending(s);
+    if (rc) return rc;
+    uint8_t *d_views = nullptr;
+    unsigned long long *d_cnt = nullptr;
+    HIPCK(hipMalloc((void **)&d_views, row * (size_t)W));
+    HIPCK(hipMalloc((void **)&d_cnt, 8 * (size_t)(W + 1)));
+    auto fail = [&](int code) { (void)hipFree(d_views); (void)hipFree(d_cnt); return code; };
+    // 1. every rank learns every camera's latest view
+    if (hipMemsetAsync(d_views, 0, row * (size_t)W, s->stream) != hipSuccess ||
+        hipMemcpyAsync(d_views + row * r, depth_mm, 2 * P, hipMemcpyHostToDevice, s->stream) != hipSuccess ||
+        hipMemcpyAsync(d_views + row * r + off_sem, semantic, P, hipMemcpyHostToDevice, s->stream) != hipSuccess ||
+        hipMemcpyAsync(d_views + row * r + off_pose, pose16, 64, hipMemcpyHostToDevice, s->stream) != hipSuccess) { g_err = "sm_rig_consolidate: staging the view failed"; return fail(SM_E_HIP); }
+    if ((rc = ss_collective(s, d_views, d_views, row * (size_t)W / 8, SM_COLL_SUM))) return fail(rc);
+    std::vector<float> poses((size_t)W * 16);
+    for (int v = 0; v < W; ++v)
+        if (hipMemcpyAsync(&poses[(size_t)v * 16], d_views + row * v + off_pose, 64, hipMemcpyDeviceToHost, s->stream) != hipSuccess) return fail(SM_E_HIP);
+    if (hipStreamSynchronize(s->stream) != hipSuccess) return fail(SM_E_HIP);
+    // slice sizes of all ranks (own count at index rank, summed)
+    std::vector<unsigned long long> h_cnt((size_t)W + 1);
+    auto exchange_counts = [&](unsigned long long extra) -> int {
+        int rcx = pull_state(s);
+        if (rcx) return rcx;
+        std::fill(h_cnt.begin(), h_cnt.end(), 0ull);
+        h_cnt[(size_t)r] = s->counts.count;
+        h_cnt[(size_t)W] = extra;
+        if (hipMemcpyAsync(d_cnt, h_cnt.data(), 8 * (size_t)(W + 1), hipMemcpyHostToDevice, s->stream) != hipSuccess) return SM_E_HIP;
+        if ((rcx = ss_collective(s, d_cnt, d_cnt, (size_t)W + 1, SM_COLL_SUM))) return rcx;
+        if (hipMemcpyAsync(h_cnt.data(), d_cnt, 8 * (size_t)(W + 1), hipMemcpyDeviceToHost, s->stream) != hipSuccess) return SM_E_HIP;
+        return hipStreamSynchronize(s->stream) == hipSuccess ? SM_OK : SM_E_HIP;
+    };
+    // 2. the union cleaned against every view, in rank order: each rank cleans ITS slice (the test is per surfel and view)
+    for (int v = 0; v < W; ++v) {
+        if ((rc = exchange_counts(0ull))) return fail(rc);
+        int first = -1;
+        for (int q = 0; q < W && first < 0; ++q) if (h_cnt[(size_t)q] > 0) first = q;
+        // surfel id 0 never conflicts (conflict.geom:15): the exemption belongs to the rank that holds the union's first surfel
+        if ((rc = clean_points_device(s, reinterpret_cast<const uint16_t *>(d_views + row * v), d_views + row * v + off_sem,
+                                      &poses[(size_t)v * 16], first == r ? 1 : 0))) return fail(rc);
+        if ((rc = exchange_counts(s->counts.conflict_count))) return fail(rc);
+        const unsigned long long conf = h_cnt[(size_t)W];
+        if (view_conflicts) view_conflicts[v] = (uint32_t)conf;
+        // at most W*H conflicts take effect per view, in global surfel order (src/GlobalModel.cpp:54-57): not reproducible per slice
+        if (s->cfg.conflict_cap && conf > (unsigned long long)s->P) {
+            g_err = "sm_rig_consolidate: a view has more conflicts than pixels over all slices: the reference's conflict cap would truncate them in "
+                    "global surfel order";
+            return fail(SM_E_UNSUPPORTED);
+        }
+    }
+    // 3. the cleaned slices, concatenated in rank order, appended to `global` on every rank
+    unsigned long long T = 0, base = 0;
+    for (int q = 0; q < W; ++q) { if (q < r) base += h_cnt[(size_t)q]; T += h_cnt[(size_t)q]; }
+    if (total_out) *total_out = (uint32_t)T;
+    (void)hipFree(d_views); d_views = nullptr;
+    if (T == 0) { (void)hipFree(d_cnt); return SM_OK; }
+    float *d_union = nullptr;
+    if (hipMalloc((void **)&d_union, (size_t)T * 48) != hipSuccess) { g_err = "sm_rig_consolidate: out of device memory for the union"; return fail(SM_E_HIP); }
+    auto fail2 = [&](int code) { (void)hipFree(d_union); (void)hipFree(d_cnt); return code; };
+    if ((rc = ensure_compact(s))) return fail2(rc);
+    if ((rc = pull_state(s))) return fail2(rc);
+    const uint32_t cnt = s->h_state->count;
+    if (hipMemsetAsync(d_union, 0, (size_t)T * 48, s->stream) != hipSuccess) return fail2(SM_E_HIP);
+    if (cnt) hipLaunchKernelGGL(k_export_aos, dim3((cnt + 255) / 256), dim3(256), 0, s->stream, s->M, s->d_state, d_union + (size_t)base * 12, 0u, cnt);
+    if (hipGetLastError() != hipSuccess) return fail2(SM_E_HIP);
+    if ((rc = ss_collective(s, d_union, d_union, (size_t)T * 6, SM_COLL_SUM))) return fail2(rc);
+    if (hipStreamSynchronize(s->stream) != hipSuccess) return fail2(SM_E_HIP);
+    rc = sm_append_model_aos_device(global, d_union, (uint32_t)T);
+    (void)hipFree(d_union); (void)hipFree(d_cnt);
+    return rc;
 }
 
 }  // extern "C"

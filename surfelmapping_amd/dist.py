@@ -146,3 +146,22 @@ class RigMapper:
         counts = [int(x.shape[0]) for x in slices]
         model = np.concatenate(slices, axis=0) if slices else np.zeros((0, 12), np.float32)
         return model, counts, per_view
+
+
+    # -- the same consolidation inside the HIP core (sm_rig_consolidate): views, sizes, conflict totals and slices cross the
+    #    ranks through the collective installed in the core (RCCL on its stream, or a callback); nothing is staged through Python
+    def enable_native(self, collective=None, rccl_id: bytes | None = None):
+        """collective: None (world 1), "rccl" with the id of capi.rccl_unique_id() handed to all ranks, or a callable
+        (send_ptr, recv_ptr, count_u64, op) -> 0 (sharded.ThreadCollective for ranks that are threads of one process)"""
+        self.be.rig_configure(self.comm.rank, self.comm.world)
+        if collective == "rccl":
+            self.be.shard_rccl_init(rccl_id)
+        elif collective is not None:
+            self.be.shard_set_collective(collective)
+        self._native = True
+
+    def consolidate_native(self, sm_global):
+        """-> (surfels of the single GlobalModel, now in `sm_global`; conflicts per view); collective"""
+        assert getattr(self, "_native", False), "enable_native() first"
+        depth, sem, pose = self.last
+        return self.be.rig_consolidate(depth, sem, pose, sm_global)

@@ -139,6 +139,63 @@ def test_rig_two_cameras_at_1920x1080():
     check(run_threads(2, lambda r: capi.SurfelMap(capi.make_config(**cam, **over)), cam, 3), 2, cam, over, 3)
 
 
+def run_threads_native(world, cam=None, over=None, n_frames=None, collective="threads"):
+    """the consolidation inside the HIP core (sm_rig_consolidate): G contexts on the one GPU, ranks = threads"""
+    from surfelmapping_amd import capi
+    group = sharded.ThreadGroup(world)
+    out, err = [None] * world, []
+    CAM_, OVER_ = cam or CAM, over or OVER
+
+    def work(r):
+        try:
+            sm = capi.SurfelMap(capi.make_config(**CAM_, **OVER_))
+            glob = capi.SurfelMap(capi.make_config(**CAM_, **dict(OVER_, max_sqrt_vertices=int(OVER_["max_sqrt_vertices"] * math.sqrt(world)) + 8)))
+            mp = smd.RigMapper(sm, sharded.ThreadComm(group, r), CAM_["width"] * CAM_["height"])
+            if collective == "rccl":
+                mp.enable_native("rccl", capi.rccl_unique_id())
+            else:
+                mp.enable_native(sharded.ThreadCollective(group, r, sm) if world > 1 else None)
+            for fr in rank_stream(r, world, CAM_, n_frames):
+                mp.process_frame(*fr)
+            total, per_view = mp.consolidate_native(glob)
+            out[r] = (glob.download_model(), total, per_view)
+            if collective == "rccl":
+                sm.shard_rccl_finalize()
+        except BaseException as e:
+            err.append(e)
+            group.barrier.abort()
+
+    ts = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    [t.start() for t in ts]
+    [t.join(600) for t in ts]
+    if err:
+        raise err[0]
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 4])
+def test_rig_consolidation_inside_the_core(world):
+    """sm_rig_consolidate: the whole consolidation in the HIP core, the ranks' data crossing through the installed
+    collective; every rank ends with the single GlobalModel of the one-oracle definition in its second context"""
+    model, sizes, conflicts = definition(world)
+    out = run_threads_native(world)
+    for r in range(world):
+        got, total, per_view = out[r]
+        assert per_view == conflicts and total == model.shape[0]
+        assert np.array_equal(got.view(np.uint32), model.view(np.uint32)), f"rank {r}"
+
+
+@pytest.mark.gpu
+def test_rig_consolidation_inside_the_core_rccl_world1():
+    """the production binding (RCCL on the core's stream), one rank: the model cleaned against its own last view"""
+    model, sizes, conflicts = definition(1)
+    out = run_threads_native(1, collective="rccl")
+    got, total, per_view = out[0]
+    assert per_view == conflicts and total == model.shape[0]
+    assert np.array_equal(got.view(np.uint32), model.view(np.uint32))
+
+
 # ---------------------------------------------------------------- 2 gloo processes (torch.distributed on host arrays)
 def _free_port():
     s = socket.socket()
