@@ -1,3 +1,11 @@
+#!/usr/bin/env python3
+"""Frame-time diagnostic without torch / bench.py's machinery: 110 KITTI-size frames through the plain path or the in-stream
+sharded path (one rank, no communicator), synchronising every CHUNK frames and printing the host enqueue time and the total
+time per frame of each chunk.  (Used in round 2 to tell a GPU-side slowdown from a host-side stall: the 45 ms "stall" of
+bench.py's sharded leg turned out to be Python's garbage collector with torch imported.)
+
+    python tools/shard_diag.py {plain|shard} CHUNK
+"""
 import sys, time, os
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
 import numpy as np
