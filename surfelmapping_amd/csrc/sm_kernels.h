@@ -2444,7 +2444,8 @@ __global__ __launch_bounds__(PIX_BLOCK) void k_associate(Model M, const DevState
 // ---------------------------------------------------------------------------------------------
 // Direct-append form of p8..p11 (the default on frames whose cull only marks the dead): association + in-place fuse, and
 // every NEW surfel written straight to its final slot = offset + (candidate pixels before it in pixel order) -- the
-// candidate counts per block and per group come from k_surfel_pass's extra workgroups (cand_count_block), so nothing here waits for another block and no append kernel follows.  A candidate pixel that fuses
+// candidate counts per block and per group come from k_pass_fixup's worker workgroups (cand_count_block), so nothing here
+// waits for another block and no append kernel follows.  A candidate pixel that fuses
 // leaves its slot empty: marked dead (alive bit, per-tile dead count) like a culled surfel.  Survivor order and new-
 // surfel order are the reference's (stable cull; column-major append, src/GlobalModel.cpp:67-74), ids handed out by
 // the API are positions among the live surfels as with any deferred compaction.
