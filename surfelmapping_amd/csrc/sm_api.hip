@@ -360,6 +360,7 @@ struct sm_ctx {
     bool assoc_pending = false;
     AssocArgs assoc_args{};            // the held-back association (its FrameParams and that frame's planes)
     bool merge_assoc = false;          // set by enqueue_frame: the k_prep launch of this call carries assoc_args
+    bool assoc_pair = true;            // k_associate_direct / k_assoc_prep take two consecutive pixels per thread (SM_ASSOC_PAIR=0: one)
     bool ss_settle_pending = false;    // the last sharded frame's k_shard_settle work rides on the next k_prep (or runs stand-alone first)
     ShardSettle ss_settle{};
     int n_pix_blocks = 0;
@@ -523,6 +524,13 @@ int take_error(sm_ctx *s)
 
 // ---- launches ----
 
+// workgroups of the direct association (k_associate_direct<false, .> / k_assoc_prep): one per association block, or one per
+// two blocks when every thread takes two consecutive pixels
+static inline uint32_t assoc_wgs(const sm_ctx *s)
+{
+    return s->assoc_pair ? (uint32_t)(s->n_pix_blocks + 1) / 2u : (uint32_t)s->n_pix_blocks;
+}
+
 int launch_prep(sm_ctx *s, const uint8_t *rgb, const uint16_t *raw, const uint8_t *sem, const float *dm,
                 const FrameParams &fp, bool clear_keys, hipStream_t st = nullptr)
 {
@@ -552,8 +560,13 @@ int launch_prep(sm_ctx *s, const uint8_t *rgb, const uint16_t *raw, const uint8_
         pa.rgb = rgb; pa.depth_raw = raw; pa.sem = sem; pa.depth_f32 = dm; pa.depthT = s->d_depthT; pa.rgbsT = s->d_rgbsT;
         pa.keyT = clear_keys ? s->d_keyT : nullptr; pa.dcT = s->d_dcT;
         pa.conf_sub = clear_keys ? s->d_conf_sub + SUB_SET * s->conf_sub_set : nullptr;
-        hipLaunchKernelGGL(k_assoc_prep, dim3(tp.nfb + (uint32_t)s->n_pix_blocks + (uint32_t)tiles), dim3(PIX_BLOCK), 0, s->stream, s->assoc_args, pa, fp, tp,
-                           (uint32_t)s->n_pix_blocks, (uint32_t)tiles);
+        const uint32_t n_assoc = assoc_wgs(s);
+        if (s->assoc_pair)
+            hipLaunchKernelGGL(k_assoc_prep<true>, dim3(tp.nfb + n_assoc + (uint32_t)tiles), dim3(PIX_BLOCK), 0, s->stream, s->assoc_args, pa, fp, tp,
+                               n_assoc, (uint32_t)tiles);
+        else
+            hipLaunchKernelGGL(k_assoc_prep<false>, dim3(tp.nfb + n_assoc + (uint32_t)tiles), dim3(PIX_BLOCK), 0, s->stream, s->assoc_args, pa, fp, tp,
+                               n_assoc, (uint32_t)tiles);
         HIPCK(hipGetLastError());
         return SM_OK;
     }
@@ -687,7 +700,8 @@ int launch_associate_direct(sm_ctx *s, const FrameParams &fp, bool timed)
         s->assoc_args = a;
         s->assoc_pending = true;
     } else {
-        hipLaunchKernelGGL(k_associate_direct<false>, dim3(s->n_pix_blocks), dim3(PIX_BLOCK), 0, s->stream, a, sh);
+        if (s->assoc_pair) hipLaunchKernelGGL((k_associate_direct<false, true>), dim3(assoc_wgs(s)), dim3(PIX_BLOCK), 0, s->stream, a, sh);
+        else hipLaunchKernelGGL((k_associate_direct<false, false>), dim3(assoc_wgs(s)), dim3(PIX_BLOCK), 0, s->stream, a, sh);
         HIPCK(hipGetLastError());
     }
     s->lazy_part_live = false;
@@ -704,7 +718,8 @@ int flush_assoc(sm_ctx *s)
     s->assoc_pending = false;
     ShardArgs sh;
     memset(&sh, 0, sizeof sh);
-    hipLaunchKernelGGL(k_associate_direct<false>, dim3(s->n_pix_blocks), dim3(PIX_BLOCK), 0, s->stream, s->assoc_args, sh);
+    if (s->assoc_pair) hipLaunchKernelGGL((k_associate_direct<false, true>), dim3(assoc_wgs(s)), dim3(PIX_BLOCK), 0, s->stream, s->assoc_args, sh);
+    else hipLaunchKernelGGL((k_associate_direct<false, false>), dim3(assoc_wgs(s)), dim3(PIX_BLOCK), 0, s->stream, s->assoc_args, sh);
     HIPCK(hipGetLastError());
     return SM_OK;
 }
@@ -1351,6 +1366,7 @@ sm_ctx *sm_create(const sm_config *c)
         if (const char *e = std::getenv("SM_ONE_PASS")) s->one_pass = e[0] != '0';
         if (const char *e = std::getenv("SM_TILE_FLAGS_IN_PREP")) s->use_list = e[0] != '0';
         if (const char *e = std::getenv("SM_DIRECT_APPEND")) s->direct = e[0] != '0';
+        if (const char *e = std::getenv("SM_ASSOC_PAIR")) s->assoc_pair = e[0] != '0';
         if (const char *e = std::getenv("SM_PASS_NW")) { const int v = std::atoi(e); if (v == 1 || v == 2 || v == 4) s->pass_nw = v; }
         s->defer_ok = s->defer_ok && s->one_pass && s->use_list && s->direct && !s->use_fused_assoc;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess && cus > 0 &&
@@ -2342,7 +2358,7 @@ int sm_shard_frame_device(sm_ctx *s, const uint8_t *d_rgb, const uint16_t *d_dep
     sh.owner = (int)(s->ss_frames % (uint32_t)s->ss_world) == s->ss_rank ? 1 : 0;
     AssocArgs aa;
     fill_assoc_args(s, fp, aa);
-    hipLaunchKernelGGL(k_associate_direct<true>, dim3(s->n_pix_blocks), dim3(PIX_BLOCK), 0, s->stream, aa, sh);
+    hipLaunchKernelGGL((k_associate_direct<true, false>), dim3(s->n_pix_blocks), dim3(PIX_BLOCK), 0, s->stream, aa, sh);
     HIPCK(hipGetLastError());
     if ((rc = mark(s, 5, true))) return rc;
     if ((rc = ss_collective(s, s->d_gmask, s->d_gmask, (size_t)sh.nwords + 4, SM_COLL_SUM))) return rc;   // in place, like the key map

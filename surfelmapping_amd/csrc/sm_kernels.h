@@ -2199,10 +2199,10 @@ __device__ __forceinline__ float3 get_vertex(float z, float x, float y, const Fr
 
 __device__ __forceinline__ bool local_surfel(int q, const FrameParams &fp, const float *__restrict__ depthT,
                                              const uint32_t *__restrict__ rgbsT, const float *__restrict__ xs,
-                                             const float *__restrict__ ys, LocalSurfel &L)
+                                             const float *__restrict__ ys, LocalSurfel &L, int qi = -1, int qj = 0)
 {
     const int H = fp.H, W = fp.W;
-    const int i = q / H, j = q - i * H;
+    const int i = qi >= 0 ? qi : q / H, j = qi >= 0 ? qj : q - i * H;     // (qi, qj): the caller knows the column / row of q already
     // init_mode: xs/ys hold the FeedbackBuffer's own pixel coordinates (src/FeedbackBuffer.cpp:47-53); they
     // follow the association tables in the same arrays at offsets W and H
     const float x = fp.init_mode ? xs[W + i] : xs[i], y = fp.init_mode ? ys[H + j] : ys[j];
@@ -2313,13 +2313,14 @@ __device__ __forceinline__ void associate_pixel(int q, const SurfelSet &cur, con
                                                 const uint32_t *__restrict__ seg_lstart, LocalSurfel &L, bool &is_valid,
                                                 bool &is_fused, uint32_t *__restrict__ tb, uint32_t first_live,
                                                 const uint64_t *__restrict__ own_alive = nullptr /* slot-addressed sharding: this rank's alive bits */,
-                                                FuseMove *mv = nullptr /* given: the caller grows the tile boxes (fuse_bounds_block) */)
+                                                FuseMove *mv = nullptr /* given: the caller grows the tile boxes (fuse_bounds_block) */,
+                                                int qi = -1, int qj = 0 /* column / row of q, if the caller has them */)
 {
     is_valid = false;
     is_fused = false;
     uint32_t f_id = 0;                        // the surfel this lane fused into, and where it moved
     float f_x = 0.f, f_y = 0.f, f_z = 0.f;
-    if (q < fp.P && local_surfel(q, fp, depthT, rgbsT, xs, ys, L)) {
+    if (q < fp.P && local_surfel(q, fp, depthT, rgbsT, xs, ys, L, qi, qj)) {
         is_valid = true;
         const uint64_t key = keyT[q];
         const int32_t gid = (int32_t)(uint32_t)(key & 0xFFFFFFFFull);
@@ -2470,10 +2471,20 @@ struct AssocArgs {
     uint64_t *alive; uint32_t *tile_dead; uint32_t n_grp, cg; unsigned long long *host_stat;
 };
 
-// one association block (PIX_BLOCK pixels, 256 threads); blk = its index in pixel order
-template <bool SHARD>
-__device__ __forceinline__ void associate_direct_block(const AssocArgs &a, const ShardArgs &sh, const uint32_t blk)
+// one association workgroup (256 threads); wg = its index in pixel order.
+// PAIR = false: one pixel per thread, the workgroup is association block `wg` (PIX_BLOCK pixels).
+// PAIR = true: TWO consecutive pixels per thread, the workgroup covers blocks 2 wg and 2 wg + 1.  data.vert:88 keeps only
+// the pixels with (int)x + (int)y odd -- half of every wave sat out the whole association with one pixel per lane -- and
+// sm_create refuses image sizes where (int)xs[i] != i or (int)ys[j] != j, so the test is "(i + j) odd": of the pixels q0
+// (even) and q0 + 1 in column-major order exactly one passes it, whatever H is (same column: j and j + 1; across the end
+// of a column only if H is odd, (i, H - 1) and (i + 1, 0): i + H - 1 and i + 1 differ in parity; with H even an even q0
+// never is the last pixel of a column).  The lane takes that one: every lane of the wave holds a pixel of the
+// checkerboard, in pixel order, so ballots, ranks and slots are what they were -- with half the waves.
+template <bool SHARD, bool PAIR>
+__device__ __forceinline__ void associate_direct_block(const AssocArgs &a, const ShardArgs &sh, const uint32_t wg)
 {
+    static_assert(!(SHARD && PAIR), "the mask planes of the sharded form are one bit per lane");
+    const uint32_t blk = PAIR ? wg * 2u : wg;            // first association block of the workgroup (an even one: same group as the next)
     const Model &M = a.M; DevState *__restrict__ st = a.st; const FrameParams &fp = a.fp;
     const float *__restrict__ depthT = a.depthT; const uint32_t *__restrict__ rgbsT = a.rgbsT; const uint64_t *__restrict__ keyT = a.keyT;
     const float *__restrict__ xs = a.xs, *__restrict__ ys = a.ys;
@@ -2494,12 +2505,18 @@ __device__ __forceinline__ void associate_direct_block(const AssocArgs &a, const
     for (uint32_t g = lane; g < grp; g += 64u) pre += grp_cand[g];
     const SurfelSet cur = M.s[st->cur];
     const uint32_t offset = st->offset;
-    const int q = blk * PIX_BLOCK + threadIdx.x;
+    int q = (int)blk * PIX_BLOCK + (int)threadIdx.x, qi = -1, qj = 0;
+    if (PAIR) {
+        const int q0 = (int)blk * PIX_BLOCK + 2 * (int)threadIdx.x;
+        qi = q0 / fp.H; qj = q0 - qi * fp.H;
+        if (((qi + qj) & 1) == 0) { q = q0 + 1; if (++qj == fp.H) { qj = 0; ++qi; } }     // q0 is off the checkerboard: its successor is on it
+        else q = q0;
+    }
     bool is_valid, is_fused;
     LocalSurfel L;
     FuseMove mv;
     associate_pixel(q, cur, fp, depthT, rgbsT, keyT, xs, ys, nullptr, nullptr, L, is_valid, is_fused, tb, st->first_live,
-                    SHARD ? alive : nullptr, &mv);
+                    SHARD ? alive : nullptr, &mv, qi, qj);
     const uint64_t vw = __ballot(is_valid), fw = __ballot(is_fused);
     if (lane == 0) { s_v[wave] = (uint32_t)__popcll(vw); s_n[wave] = (uint32_t)__popcll(vw & ~fw); s_f[wave] = (uint32_t)__popcll(fw); }
     if (SHARD && lane == 0) {
@@ -2508,12 +2525,12 @@ __device__ __forceinline__ void associate_direct_block(const AssocArgs &a, const
     }
     pre = wave_sum_u32(pre);
     __syncthreads();
-    if (SHARD && blk == 0 && threadIdx.x == 0) {
+    if (SHARD && wg == 0 && threadIdx.x == 0) {
         // this rank's share of the frame's counters travels with the mask (k_pass_fixup published them)
         sh.gmask[sh.nwords] = st->conflict_count; sh.gmask[sh.nwords + 1] = st->visible_count;
         sh.gmask[sh.nwords + 2] = st->n_kill; sh.gmask[sh.nwords + 3] = 0ull;
     }
-    if (blk == 0 && wave == 0) {
+    if (wg == 0 && wave == 0) {
         // every candidate pixel of the frame owns a slot: the new count (the host never lets a frame of this form start
         // without room for all of them), published for the next frame's kernels and for the host's capacity bound
         uint32_t d = 0;
@@ -2530,8 +2547,8 @@ __device__ __forceinline__ void associate_direct_block(const AssocArgs &a, const
     }
     if (!SHARD && threadIdx.x == 0) {                    // (sharded: k_shard_settle counts, from the masks of all ranks)
         const uint32_t nn = s_n[0] + s_n[1] + s_n[2] + s_n[3], nf = s_f[0] + s_f[1] + s_f[2] + s_f[3];
-        if (nn) atomicAdd(&frame_sub[2 * SUB_SET + (blk & 63u) * SUB_STRIDE], nn);
-        if (nf) atomicAdd(&frame_sub[3 * SUB_SET + (blk & 63u) * SUB_STRIDE], nf);
+        if (nn) atomicAdd(&frame_sub[2 * SUB_SET + (wg & 63u) * SUB_STRIDE], nn);
+        if (nf) atomicAdd(&frame_sub[3 * SUB_SET + (wg & 63u) * SUB_STRIDE], nf);
     }
     fuse_bounds_block(tb, is_fused, mv, s_f[0] + s_f[1] + s_f[2] + s_f[3], s_tag, s_box);
     uint32_t rank = (uint32_t)__popcll(vw & ((1ull << lane) - 1ull));
@@ -2568,10 +2585,10 @@ __device__ __forceinline__ void associate_direct_block(const AssocArgs &a, const
     if (is_valid && !room) st->error = -2;
 }
 
-template <bool SHARD>
+template <bool SHARD, bool PAIR>
 __global__ __launch_bounds__(PIX_BLOCK) void k_associate_direct(AssocArgs a, ShardArgs sh)
 {
-    associate_direct_block<SHARD>(a, sh, blockIdx.x);
+    associate_direct_block<SHARD, PAIR>(a, sh, blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2582,6 +2599,7 @@ __global__ __launch_bounds__(PIX_BLOCK) void k_associate_direct(AssocArgs a, Sha
 // Block ranges: the 32x32-pixel image tiles, the frame's tile flags (tile_prep_block with the "may still change" rule),
 // the association blocks.
 // ---------------------------------------------------------------------------------------------
+template <bool PAIR>
 __global__ __launch_bounds__(PIX_BLOCK) void k_assoc_prep(AssocArgs a, PrepArgs p, FrameParams fp_new, TilePrep tp, uint32_t n_assoc,
                                                           uint32_t n_img)
 {
@@ -2594,7 +2612,7 @@ __global__ __launch_bounds__(PIX_BLOCK) void k_assoc_prep(AssocArgs a, PrepArgs 
     if (b < tp.nfb) { tile_prep_block(fp_new, tp, n_img); return; }
     ShardArgs none;
     none.validmask = nullptr; none.ownmask = nullptr; none.gmask = nullptr; none.nwords = 0u; none.owner = 1;
-    associate_direct_block<false>(a, none, b - tp.nfb);
+    associate_direct_block<false, PAIR>(a, none, b - tp.nfb);
 }
 
 // stand-alone form (when something reads the frame's counters before the next frame's k_prep has run)
