@@ -18,6 +18,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -322,6 +323,9 @@ struct sm_ctx {
     uint32_t n_grp = 0, cand_group = 16;
     bool pend_finalize = false;        // the last frame's statistics are completed by the next k_pass_fixup or by k_frame_finalize
     int fix_set = 0;                   // k_pass_fixup's partials alternate between two sets (the previous frame's are read one frame later)
+    unsigned long long *d_pass_trace = nullptr;   // SM_PASS_TRACE=<file prefix>: per-workgroup time stamps of the last k_surfel_pass launch, dumped by sm_destroy
+    int pass_trace_grid = 0;
+    bool pass_compact = true;          // k_surfel_pass compacts the lanes that can be in view before the exact tests (SM_PASS_COMPACT=0: word by word)
     int pass_nw = 2;                   // 64-slot words a wave of k_surfel_pass settles at a time (SM_PASS_NW = 1, 2, 4)
     bool merged_finalize = true;       // SM_NO_MERGED_FINALIZE=1: keep k_cull_finalize + k_cull_lazy as separate launches
     uint32_t *d_conf_sub = nullptr;    // 2 x 64 conflict sub-counters (one set per frame parity: zeroed by that frame's k_prep)
@@ -654,10 +658,17 @@ int launch_surfel_pass(sm_ctx *s, const FrameParams &fp, bool timed, bool direct
 #define SM_LAUNCH_PASS(R, NWV)                                                                                                             \
     hipLaunchKernelGGL((k_surfel_pass<R, NWV>), dim3(grid), dim3(256), 0, s->stream, s->M, s->d_state, fp, s->d_dcT, s->d_cm, s->d_dm /* km */, \
                        s->d_wave_cnt, s->d_tb, s->d_tile_flags, s->d_lazy_part, s->d_alive, s->d_tile_dead, sub, s->d_keyT, s->d_undo, tile_bound,       \
-                       s->d_frame_sub)
-    if (ready) { if (s->pass_nw == 1) SM_LAUNCH_PASS(true, 1); else if (s->pass_nw == 2) SM_LAUNCH_PASS(true, 2); else SM_LAUNCH_PASS(true, 4); }
+                       s->d_frame_sub, s->d_pass_trace)
+#define SM_LAUNCH_PASS_C(R)                                                                                                                \
+    hipLaunchKernelGGL((k_surfel_pass<R, 2, true>), dim3(grid), dim3(256), 0, s->stream, s->M, s->d_state, fp, s->d_dcT, s->d_cm, s->d_dm /* km */, \
+                       s->d_wave_cnt, s->d_tb, s->d_tile_flags, s->d_lazy_part, s->d_alive, s->d_tile_dead, sub, s->d_keyT, s->d_undo, tile_bound,       \
+                       s->d_frame_sub, s->d_pass_trace)
+    if (s->d_pass_trace) s->pass_trace_grid = grid;
+    if (s->pass_compact) { if (ready) SM_LAUNCH_PASS_C(true); else SM_LAUNCH_PASS_C(false); }
+    else if (ready) { if (s->pass_nw == 1) SM_LAUNCH_PASS(true, 1); else if (s->pass_nw == 2) SM_LAUNCH_PASS(true, 2); else SM_LAUNCH_PASS(true, 4); }
     else       { if (s->pass_nw == 1) SM_LAUNCH_PASS(false, 1); else if (s->pass_nw == 2) SM_LAUNCH_PASS(false, 2); else SM_LAUNCH_PASS(false, 4); }
 #undef SM_LAUNCH_PASS
+#undef SM_LAUNCH_PASS_C
     HIPCK(hipGetLastError());
     if (mark(s, 2, timed) || mark(s, 3, timed)) return SM_E_HIP;
     DirectArgs da;
@@ -1368,6 +1379,8 @@ sm_ctx *sm_create(const sm_config *c)
         if (const char *e = std::getenv("SM_DIRECT_APPEND")) s->direct = e[0] != '0';
         if (const char *e = std::getenv("SM_ASSOC_PAIR")) s->assoc_pair = e[0] != '0';
         if (const char *e = std::getenv("SM_PASS_NW")) { const int v = std::atoi(e); if (v == 1 || v == 2 || v == 4) s->pass_nw = v; }
+        if (const char *e = std::getenv("SM_PASS_COMPACT")) s->pass_compact = e[0] != '0';
+        if (std::getenv("SM_PASS_TRACE") && hipMalloc((void **)&s->d_pass_trace, (size_t)MAX_GRID * 64) != hipSuccess) s->d_pass_trace = nullptr;
         s->defer_ok = s->defer_ok && s->one_pass && s->use_list && s->direct && !s->use_fused_assoc;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess && cus > 0 &&
             hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_compact<true>, 256, 0) == hipSuccess && per_cu > 0) {
@@ -1395,6 +1408,18 @@ void sm_destroy(sm_ctx *s)
     (void)hipSetDevice(s->cfg.device);
     if (s->stream2) (void)hipStreamSynchronize(s->stream2);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
+    if (s->d_pass_trace) {
+        // SM_PASS_TRACE=<prefix>: the last k_surfel_pass launch's per-workgroup record (wall_clock64 at entry / first tile /
+        // after it / exit, that tile, its compacted entries, XCC | HW_ID, tiles) -> <prefix>.<n>.bin (tools/pass_trace.py)
+        static std::atomic<int> n_dump{0};
+        std::vector<unsigned long long> h((size_t)std::max(s->pass_trace_grid, 0) * 8);
+        if (!h.empty() && hipMemcpy(h.data(), s->d_pass_trace, h.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
+            char path[512];
+            snprintf(path, sizeof path, "%s.%d.bin", std::getenv("SM_PASS_TRACE") ? std::getenv("SM_PASS_TRACE") : "pass_trace", n_dump++);
+            if (FILE *f = fopen(path, "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
+        }
+        (void)hipFree(s->d_pass_trace);
+    }
     (void)hipFree(s->d_depthT_nx); (void)hipFree(s->d_rgbsT_nx); (void)hipFree(s->d_keyT_nx); (void)hipFree(s->d_dcT_nx);
     if (s->ev_prep) (void)hipEventDestroy(s->ev_prep);
     if (s->ev_main) (void)hipEventDestroy(s->ev_main);

@@ -1762,10 +1762,204 @@ __device__ __forceinline__ void pass_quarter(const SurfelSet &set, DevState *__r
     acc.nconf += cwave;
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same tile settled with its lanes COMPACTED first (k_surfel_pass<., ., true>).  pass_words spends ~350 IEEE-exact VALU
+// instructions per 64-slot word as soon as ONE of its lanes is in view -- on a KITTI frame 61 % of the lanes of such words
+// are, on the 20 M-surfel stress model (uniformly scattered surfels: 97 % of the words hold a surfel in view, 3.5 of 64
+// lanes on average) 5 %.  So the workgroup first runs a cheap test over its 1 024 slots (one load, the 3x4 transform, one
+// v_rcp_f32 and six compares per slot) that rejects only what BOTH exact view tests are certain to reject, collects the
+// slot numbers of the rest in LDS, and then runs the exact per-surfel code -- unchanged, two entries per thread at a time
+// -- over that dense list.  Bit-exact by construction: the pre-test is a strict superset (2-pixel margin against a
+// <= 1e-3-pixel difference between x * rcp(z) and the correctly rounded quotient; every comparison is written so that a NaN
+// does NOT reject; a surfel with conf <= 0, which dies wherever it is, is always kept), the masks are assembled with LDS
+// atomicOr instead of ballots, and every global side effect (undo, confidence, alive, key map, counters) is per slot or a
+// sum.  Workgroup-uniform control flow; three barriers per tile.
+// ---------------------------------------------------------------------------------------------
+struct PassLds {
+    float4 pos[TILE];                    // their (x, y, z, confidence), parked by phase A: phase B starts without a global round trip
+    uint16_t list[TILE];                 // slots (within the tile) that need the exact tests
+    uint32_t n;                          // entries
+    uint32_t cm[2 * TILE_WORDS], km[2 * TILE_WORDS], gone[2 * TILE_WORDS];   // per word (lo, hi): conflicts; killed by a conflict; removed (dead | conflict & dies)
+    uint32_t drew;
+};
+
+__device__ __forceinline__ void pass_tile_compact(const SurfelSet &set, DevState *__restrict__ st, const FrameParams &fp,
+                                                  const uint2 *__restrict__ dcT, uint64_t *__restrict__ cm, uint64_t *__restrict__ km,
+                                                  uint4 *__restrict__ wave_cnt, uint64_t *__restrict__ alive,
+                                                  uint32_t *__restrict__ tile_dead, uint64_t *__restrict__ keyT, float *__restrict__ undo,
+                                                  uint32_t N, uint32_t exempt, uint32_t tile, uint32_t wave, bool sk0, bool sk1,
+                                                  bool any_dead, int lane, PassAcc &acc, uint32_t *__restrict__ tb, PassLds &L)
+{
+    float4 *__restrict__ pc = set.pos_conf;
+    const uint32_t tid = threadIdx.x;
+    if (tid < 2 * TILE_WORDS) { L.cm[tid] = 0u; L.km[tid] = 0u; L.gone[tid] = 0u; }
+    if (tid == 0) { L.n = 0u; L.drew = 0u; }
+    // ---- phase A: the cheap superset test over the tile's slots (wave <-> four consecutive words, loads in flight together)
+    float4 v[4];
+    uint64_t valid[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const uint32_t k = (tile * TILE_WORDS + wave * 4u + (uint32_t)r) * 64u + (uint32_t)lane;
+        v[r] = pc[min(k, N - 1u)];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const uint32_t word = tile * TILE_WORDS + wave * 4u + (uint32_t)r;
+        const uint64_t base = (uint64_t)word * 64u;
+        uint64_t range = 0ull;
+        if (base < N) { const uint64_t rem = (uint64_t)N - base; range = rem >= 64 ? ~0ull : ((1ull << rem) - 1ull); }
+        valid[r] = range & (any_dead ? alive[word] : ~0ull);
+    }
+    __syncthreads();                                   // the cleared masks and L.n
+    const float zs_max = fp.depth_cutoff * 1.5f;       // splat_one's far limit
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        bool act = false;
+        // (a wave-uniform early-out on the camera-frame depth alone -- a third of the transform, then a ballot -- was measured:
+        //  no gain at KITTI size, -5 % on the scattered 20 M-surfel model where no word is behind the camera as a whole)
+        if ((valid[r] >> lane) & 1ull) {
+            const float3 ph = xform3(fp.t_inv, v[r].x, v[r].y, v[r].z);
+            const float rz = __builtin_amdgcn_rcpf(ph.z);
+            const float ua = (fp.fx * ph.x) * rz + fp.cx, va = (fp.fy * ph.y) * rz + fp.cy;
+            const bool out_img = ua < -2.0f || ua > fp.cols + 2.0f || va < -2.0f || va > fp.rows + 2.0f;      // (false for NaN)
+            const bool rej_c = sk0 || ph.z <= fp.min_depth || ph.z >= fp.max_depth || out_img;              // conflict.vert:25-49 cannot pass
+            const bool rej_s = sk1 || ph.z >= zs_max || ph.z <= 0.0f || out_img;                             // index_map.vert:38-64 cannot pass
+            act = !rej_c || !rej_s || (!sk0 && !(v[r].w > 0.0f));
+        }
+        const uint64_t m = __ballot(act);
+        uint32_t base = 0;
+        if (lane == 0 && m) base = atomicAdd(&L.n, (uint32_t)__popcll(m));
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        if (act) {
+            const uint32_t at = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            L.list[at] = (uint16_t)((wave * 4u + (uint32_t)r) * 64u + (uint32_t)lane);
+            L.pos[at] = v[r];
+        }
+    }
+    __syncthreads();
+    const uint32_t n_act = L.n;
+    // ---- phase B: the exact tests (pass_words / splat_one, per lane) over the dense list, two entries per thread at a time
+    // (a single round of four entries per thread, staged so that a full tile pays each round trip once, was measured: 79
+    // VGPRs, 64 spilled scalars, and slower at every size but the smallest -- the launch is bound by what all its workgroups
+    // issue together, not by one workgroup's chain)
+    uint32_t my_vis = 0;
+    bool my_drew = false;
+    for (uint32_t b0 = 0; b0 + wave * 64u < n_act; b0 += 2u * 256u) {      // wave-uniform (no barrier inside): a wave without entries is through
+        bool has[2];
+        uint32_t sl[2], k[2];
+        float4 e[2];
+        float pt[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const uint32_t idx = b0 + (uint32_t)r * 256u + tid;
+            has[r] = idx < n_act;
+            sl[r] = L.list[min(idx, n_act - 1u)];
+            k[r] = tile * (uint32_t)TILE + sl[r];
+            e[r] = L.pos[min(idx, n_act - 1u)];
+            pt[r] = sk1 ? 0.0f : set.time[k[r]];
+        }
+        bool conf[2] = {false, false}, kp[2];
+        if (!sk0) {
+            float zc[2], lam[2];
+            uint32_t qq[2];
+            bool inview[2];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                inview[r] = false; zc[r] = 0.f; lam[r] = 0.f; qq[r] = 0u;
+                if (has[r]) {
+                    const float3 ph = xform3(fp.t_inv, e[r].x, e[r].y, e[r].z);
+                    if (!(ph.z <= fp.min_depth || ph.z >= fp.max_depth)) {
+                        const float xl = ph.x / ph.z;
+                        const float yl = ph.y / ph.z;
+                        const float u = fp.fx * xl + fp.cx;
+                        const float vv = fp.fy * yl + fp.cy;
+                        if (!(u < fp.stereo_border || u > fp.cols || vv < 0.0f || vv > fp.rows)) {
+                            const int ti = tex_idx(u / fp.cols, fp.W), tj = tex_idx(vv / fp.rows, fp.H);
+                            qq[r] = (uint32_t)(ti * fp.H + tj);
+                            lam[r] = sqrtf((xl * xl + yl * yl) + 1.0f);
+                            zc[r] = ph.z;
+                            inview[r] = true;
+                        }
+                    }
+                }
+            }
+            uint2 g[2];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) g[r] = dcT[qq[r]];          // unconditional (pixel 0 for the others)
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                if (inview[r]) {
+                    float depth = __uint_as_float(g[r].x);
+                    if ((g[r].y >> 24) == 10u) depth = fp.max_depth + 1.0f;
+                    if (fp.is_clean == 0 && depth == 0.0f) depth = fp.max_depth + 20.0f;
+                    conf[r] = (depth * lam[r] - zc[r] * lam[r] > fp.conflict_thresh * zc[r]) && (k[r] != exempt);
+                }
+                const bool dies = has[r] && !(e[r].w - 1.0f > 0.0f);
+                const bool dead = has[r] && !(e[r].w > 0.0f);
+                kp[r] = has[r] && !(dead || (conf[r] && dies));
+                const uint32_t wi = (sl[r] >> 6) * 2u + ((sl[r] >> 5) & 1u), bit = 1u << (sl[r] & 31u);
+                if (conf[r]) atomicOr(&L.cm[wi], bit);
+                if (conf[r] && dies && !dead) atomicOr(&L.km[wi], bit);
+                if (has[r] && !kp[r]) {
+                    atomicOr(&L.gone[wi], bit);
+                    if (k[r] == exempt) st->fl_dirty = 1u;               // "id 0" died: the fixup searches its successor
+                }
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 2; ++r) kp[r] = has[r];                  // a tile outside the conflict volume holds no dead surfel either
+        }
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            if (kp[r] && conf[r]) {
+                undo[k[r]] = e[r].w;
+                pc[k[r]].w = e[r].w - 1.0f;                              // conflict.vert:72
+            }
+            if (!sk1 && kp[r] && splat_one(fp, e[r].x, e[r].y, e[r].z, pt[r], k[r], keyT)) { ++my_vis; my_drew = true; }
+        }
+    }
+    if (my_drew) L.drew = 1u;
+    acc.vis += wave_sum_u32(my_vis);
+    __syncthreads();
+    // ---- the tile's masks, alive words, dead count and quarter-tile conflict counts (wave 0: one lane per word)
+    if (wave == 0) {
+        uint32_t nc = 0, ng = 0;
+        if (lane < TILE_WORDS) {
+            const uint32_t word = tile * TILE_WORDS + (uint32_t)lane;
+            const uint64_t c = (uint64_t)L.cm[2 * lane] | ((uint64_t)L.cm[2 * lane + 1] << 32);
+            const uint64_t kk = (uint64_t)L.km[2 * lane] | ((uint64_t)L.km[2 * lane + 1] << 32);
+            const uint64_t gone = (uint64_t)L.gone[2 * lane] | ((uint64_t)L.gone[2 * lane + 1] << 32);
+            if (!sk0) { cm[word] = c; km[word] = kk; }
+            if (gone) {
+                const uint64_t base = (uint64_t)word * 64u;
+                const uint64_t rem = (uint64_t)N - base;                 // base < N: a slot of this word was valid
+                const uint64_t range = rem >= 64 ? ~0ull : ((1ull << rem) - 1ull);
+                const uint64_t was = range & (any_dead ? alive[word] : ~0ull);
+                alive[word] = (was & ~gone) | ~range;                    // the dead keep their slots
+            }
+            nc = (uint32_t)__popcll(c);
+            ng = (uint32_t)__popcll(gone);
+        }
+        // conflicts per quarter tile = sums over four consecutive lanes (words)
+        uint32_t q = nc;
+        q += __shfl_xor(q, 1);
+        q += __shfl_xor(q, 2);
+        const uint32_t q0 = lane_bcast(q, 0), q1 = lane_bcast(q, 4), q2 = lane_bcast(q, 8), q3 = lane_bcast(q, 12);
+        const uint32_t killed = wave_sum_u32(ng);
+        if (lane == 0) {
+            wave_cnt[tile] = make_uint4(q0, q1, q2, q3);
+            if (killed) atomicAdd(&tile_dead[tile], killed);
+            if (L.drew) atomicMax(&tb[(size_t)tile * 8 + 7], f2ord((float)fp.time));      // as pass_quarter
+        }
+        acc.killed += killed;
+        acc.nconf += q0 + q1 + q2 + q3;
+    }
+}
+
 // READY = true: k_prep evaluated the tile skip flags of the frame (one byte per tile, loaded together with DevState);
 // READY = false: the kernel evaluates them itself (frames whose k_prep ran before the previous frame had finished: the
 // depth filter chain on the second stream).  Workgroup <-> tile round-robin, wave <-> quarter tile.
-template <bool READY, int NW>
+template <bool READY, int NW, bool COMPACT = false>
 __global__ __launch_bounds__(256) void k_surfel_pass(Model M, DevState *__restrict__ st, FrameParams fp,
                                                      const uint2 *__restrict__ dcT, uint64_t *__restrict__ cm,
                                                      uint64_t *__restrict__ km, uint4 *__restrict__ wave_cnt,
@@ -1775,11 +1969,19 @@ __global__ __launch_bounds__(256) void k_surfel_pass(Model M, DevState *__restri
                                                      uint32_t *__restrict__ conf_sub, uint64_t *__restrict__ keyT,
                                                      float *__restrict__ undo,
                                                      uint32_t tile_bound /* host upper bound of the number of tiles (>= 1) */,
-                                                     uint32_t *__restrict__ frame_sub /* sets 0, 1: visible, killed -- sub-counters like conf_sub */)
+                                                     uint32_t *__restrict__ frame_sub /* sets 0, 1: visible, killed -- sub-counters like conf_sub */,
+                                                     unsigned long long *__restrict__ trace = nullptr /* SM_PASS_TRACE: 8 words per workgroup */)
 {
-    const uint32_t bid = blockIdx.x, tile_grid = gridDim.x;
+    const unsigned long long tr0 = trace ? wall_clock64() : 0ull;
+    unsigned long long tr1 = 0, tr2 = 0, tr3 = 0, tr_tile = ~0ull, tr_n = 0;
+    // Workgroups are dispatched in blockIdx order, ~2 800 per us: the last of 2 048 enters the chip ~3 us after the first.  The
+    // newest tiles -- the surfels the camera is looking at, i.e. the tiles with all the work -- are the highest ones, so the
+    // mapping is reversed: block 0 takes the highest tile of the grid, and a workgroup with several tiles starts with its
+    // highest (the flags of its first 64 tiles sit one per lane whatever the order).
+    const uint32_t tile_grid = gridDim.x, bid = gridDim.x - 1u - blockIdx.x;
     __shared__ uint8_t s_flags[64];
     __shared__ uint32_t s_a[4], s_b[4], s_c[4];
+    __shared__ PassLds s_pass;                         // (COMPACT only)
     const int lane = threadIdx.x & 63;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     // flags and dead counts of this workgroup's first 64 tiles: addresses known without DevState, issued with it
@@ -1796,17 +1998,21 @@ __global__ __launch_bounds__(256) void k_surfel_pass(Model M, DevState *__restri
     uint32_t sskip = 0, cskip = 0;
     const uint32_t ntiles = (N + TILE - 1) / TILE;
     uint64_t skip0 = 0, skip1 = 0;
-    uint32_t iter = 0;
-    for (uint32_t tile = bid; tile < ntiles; tile += tile_grid, ++iter) {
-        if ((iter & 63u) == 0u) {
-            const uint64_t tl = (uint64_t)tile + (uint64_t)lane * tile_grid;
+    const uint32_t n_it = bid < ntiles ? (ntiles - 1u - bid) / tile_grid + 1u : 0u;       // this workgroup's tiles: bid + iter * grid
+    const bool desc = n_it <= 64u;                      // (all of them fit the one-per-lane flags: highest first)
+    for (uint32_t it = 0; it < n_it; ++it) {
+        const uint32_t iter = desc ? n_it - 1u - it : it;
+        const uint32_t tile = bid + iter * tile_grid;
+        if (desc ? it == 0u : (iter & 63u) == 0u) {
+            const uint32_t tile0 = desc ? bid : tile;   // the tile lane 0's flag belongs to
+            const uint64_t tl = (uint64_t)tile0 + (uint64_t)lane * tile_grid;
             uint32_t f;
             if (READY) {
-                if (iter) { m_flag = tile_flags[min(tl, (uint64_t)ntiles - 1u)]; m_dead = tile_dead[min(tl, (uint64_t)ntiles - 1u)]; }
+                if (tile0 != bid) { m_flag = tile_flags[min(tl, (uint64_t)ntiles - 1u)]; m_dead = tile_dead[min(tl, (uint64_t)ntiles - 1u)]; }
                 f = tl < ntiles ? m_flag : 3u;
             } else {
                 __syncthreads();
-                tile_flags_batch(tile, tile_grid, ntiles, fp, tb, s_flags);
+                tile_flags_batch(tile0, tile_grid, ntiles, fp, tb, s_flags);
                 __syncthreads();
                 f = s_flags[lane];
                 if (wave == 0 && tl < ntiles) tile_flags[tl] = (uint8_t)f;      // bit 1 is read again by the fixup's repair
@@ -1826,8 +2032,18 @@ __global__ __launch_bounds__(256) void k_surfel_pass(Model M, DevState *__restri
             if (!READY && threadIdx.x == 0) wave_cnt[tile] = make_uint4(0u, 0u, 0u, 0u);
             continue;
         }
-        pass_quarter<NW>(set, st, fp, dcT, cm, km, wave_cnt, alive, tile_dead, keyT, undo, N, exempt, tile, wave, sk0, sk1,
-                         lane_bcast(m_dead, sl) != 0u, lane, acc, tb);
+        if (COMPACT) {
+            if (trace && tr_tile == ~0ull) { tr1 = wall_clock64(); tr_tile = tile; }
+            pass_tile_compact(set, st, fp, dcT, cm, km, wave_cnt, alive, tile_dead, keyT, undo, N, exempt, tile, wave, sk0, sk1,
+                              lane_bcast(m_dead, sl) != 0u, lane, acc, tb, s_pass);
+            if (trace && tr_tile == tile) { tr2 = wall_clock64(); tr_n = s_pass.n; }
+            __syncthreads();                           // s_pass is reused by the workgroup's next tile
+        } else {
+            if (trace && tr_tile == ~0ull) { tr1 = wall_clock64(); tr_tile = tile; }
+            pass_quarter<NW>(set, st, fp, dcT, cm, km, wave_cnt, alive, tile_dead, keyT, undo, N, exempt, tile, wave, sk0, sk1,
+                             lane_bcast(m_dead, sl) != 0u, lane, acc, tb);
+            if (trace && tr_tile == tile) tr2 = wall_clock64();
+        }
     }
     __syncthreads();
     if (lane == 0) { s_a[wave] = acc.vis; s_b[wave] = acc.killed; s_c[wave] = acc.nconf; }
@@ -1839,6 +2055,15 @@ __global__ __launch_bounds__(256) void k_surfel_pass(Model M, DevState *__restri
         if (nc) atomicAdd(&conf_sub[(bid & 63u) * SUB_STRIDE], nc);      // 64 counters, <= 32 adders each: one load per lane to read the total
         if (nv) atomicAdd(&frame_sub[(bid & 63u) * SUB_STRIDE], nv);
         if (nk) atomicAdd(&frame_sub[SUB_SET + (bid & 63u) * SUB_STRIDE], nk);
+        if (trace) {
+            tr3 = wall_clock64();
+            uint32_t hw;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            uint32_t xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            unsigned long long *t = trace + (size_t)blockIdx.x * 8;
+            t[0] = tr0; t[1] = tr1; t[2] = tr2; t[3] = tr3; t[4] = tr_tile; t[5] = tr_n; t[6] = ((unsigned long long)xcc << 32) | hw; t[7] = ntiles;
+        }
     }
 }
 

@@ -296,7 +296,8 @@ def test_fused_associate_append_variant_matches_oracle():
 
 @pytest.mark.parametrize("env", [{"SM_COMPACT_TICKETS": "1"}, {"SM_ONE_PASS": "0"}, {"SM_ONE_PASS": "0", "SM_NO_MERGED_FINALIZE": "1"},
                                  {"SM_DIRECT_APPEND": "0"}, {"SM_DIRECT_APPEND": "0", "SM_TILE_FLAGS_IN_PREP": "0", "SM_PASS_NW": "4"},
-                                 {"SM_DEFER_ASSOC": "0"}, {"SM_ASSOC_PAIR": "0"}, {"SM_ASSOC_PAIR": "0", "SM_DEFER_ASSOC": "0"}])
+                                 {"SM_DEFER_ASSOC": "0"}, {"SM_ASSOC_PAIR": "0"}, {"SM_ASSOC_PAIR": "0", "SM_DEFER_ASSOC": "0"},
+                                 {"SM_PASS_COMPACT": "0"}, {"SM_PASS_COMPACT": "0", "SM_TILE_FLAGS_IN_PREP": "0"}])
 def test_kernel_variants_behind_switches_stay_bit_exact(env):
     """SM_COMPACT_TICKETS=1: the in-place compaction hands its moving tiles out from a ticket counter (the form used as
     soon as two contexts share a GPU: no co-residency assumption).  SM_ONE_PASS=0: separate conflict and cull passes over
@@ -306,7 +307,8 @@ def test_kernel_variants_behind_switches_stay_bit_exact(env):
     per wave and round.  SM_DEFER_ASSOC=0: every asynchronous frame launches its own association instead of handing it to
     the next frame's k_prep launch (k_assoc_prep).  SM_ASSOC_PAIR=0: one pixel per thread in k_associate_direct / k_assoc_prep
     instead of the two consecutive pixels of which one is on data.vert's checkerboard.  All run the deferred-compaction and
-    fuzz tests in a child process."""
+    fuzz tests in a child process.  SM_PASS_COMPACT=0: k_surfel_pass runs the exact view tests word by word (every lane of
+    a 64-slot word as soon as one of them is in view) instead of first compacting the lanes that can be in view."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
