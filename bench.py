@@ -76,7 +76,10 @@ def kernel_bytes(log):
     # one-pass frames: pos_conf (16) of every slot whose tile is not skipped by BOTH tests (>= Sl - min(Cs, Ss): the
     # exact count is not logged, this is the lower bound), the time (4) of the slots whose tile reaches the index map,
     # one key atomic per drawn surfel
-    one_pass = 16.0 * np.maximum(Sl - np.minimum(Cs, Ss), 0.0) + 4.0 * np.maximum(Sl - Ss, 0.0) + 8.0 * V
+    # (lane-compacting form, the default: the time plane is read only for the slots that reach the exact tests -- not
+    #  logged; lower bound: the drawn ones.  SM_PASS_COMPACT=0, word by word: every slot of a tile that reaches the index map)
+    t_read = V if os.environ.get("SM_PASS_COMPACT", "1") != "0" else np.maximum(Sl - Ss, 0.0)
+    one_pass = 16.0 * np.maximum(Sl - np.minimum(Cs, Ss), 0.0) + 4.0 * t_read + 8.0 * V
     return {
         "k_prep": np.full_like(N, 6.0 * P + 24.0 * P),          # u8x3+u16+u8 in, f32+u32+u64+(f32,u32) out
         "k_conflict": 16.0 * np.maximum(Sl - Cs, 0.0),            # tiles skipped by their bounds are not read
@@ -150,10 +153,10 @@ def kernel_table(log, tim, P, K, args, workload=None):
                 "ms_per_launch": kern[dom]["ms"], "alg_bytes_per_launch": kern[dom]["MB"] * 1e6,
                 "launches": launches[dom],
                 "valu_issue_util": valu,
-                "note": "not byte-bound: a frame touches ~60 MB.  The surfel kernel's ~350 IEEE-exact VALU instructions per surfel keep "
-                        "the SIMDs half busy, but removing 6-12 % of them changed nothing (DESIGN.md 4, lessons): what a launch that owns "
-                        "~1 tile per workgroup waits on is its chain of dependent round trips (load -> transform -> gather -> ballot -> "
-                        "atomics) at 7 waves per SIMD"}
+                "note": "not byte-bound: a frame touches ~60 MB.  tools/pass_trace.py (per-workgroup time stamps of one launch, DESIGN.md 4): "
+                        "the 2 048 workgroups of k_surfel_pass take 5-8 us to enter the chip, every visited tile's 16 KB arrives in one "
+                        "~4 us burst at the start, and the ~240 tiles that hold most of the surfels in view then run ~350 IEEE-exact "
+                        "VALU instructions per surfel for ~6 us; k_assoc_prep is one such burst (28 MB) plus two dependent gathers"}
     return kern, launches, roofline
 
 

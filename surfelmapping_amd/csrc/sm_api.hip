@@ -325,6 +325,8 @@ struct sm_ctx {
     int fix_set = 0;                   // k_pass_fixup's partials alternate between two sets (the previous frame's are read one frame later)
     unsigned long long *d_pass_trace = nullptr;   // SM_PASS_TRACE=<file prefix>: per-workgroup time stamps of the last k_surfel_pass launch, dumped by sm_destroy
     int pass_trace_grid = 0;
+    unsigned long long *d_ap_trace = nullptr;     // the same for the last k_assoc_prep launch: (entry, exit) per workgroup
+    int ap_trace_n[3] = {0, 0, 0};                // its image / tile-flag / association workgroups
     bool pass_compact = true;          // k_surfel_pass compacts the lanes that can be in view before the exact tests (SM_PASS_COMPACT=0: word by word)
     int pass_nw = 2;                   // 64-slot words a wave of k_surfel_pass settles at a time (SM_PASS_NW = 1, 2, 4)
     bool merged_finalize = true;       // SM_NO_MERGED_FINALIZE=1: keep k_cull_finalize + k_cull_lazy as separate launches
@@ -565,9 +567,10 @@ int launch_prep(sm_ctx *s, const uint8_t *rgb, const uint16_t *raw, const uint8_
         pa.keyT = clear_keys ? s->d_keyT : nullptr; pa.dcT = s->d_dcT;
         pa.conf_sub = clear_keys ? s->d_conf_sub + SUB_SET * s->conf_sub_set : nullptr;
         const uint32_t n_assoc = assoc_wgs(s);
+        if (s->d_ap_trace) { s->ap_trace_n[0] = (int)tiles; s->ap_trace_n[1] = (int)tp.nfb; s->ap_trace_n[2] = (int)n_assoc; }
         if (s->assoc_pair)
             hipLaunchKernelGGL(k_assoc_prep<true>, dim3(tp.nfb + n_assoc + (uint32_t)tiles), dim3(PIX_BLOCK), 0, s->stream, s->assoc_args, pa, fp, tp,
-                               n_assoc, (uint32_t)tiles);
+                               n_assoc, (uint32_t)tiles, s->d_ap_trace);
         else
             hipLaunchKernelGGL(k_assoc_prep<false>, dim3(tp.nfb + n_assoc + (uint32_t)tiles), dim3(PIX_BLOCK), 0, s->stream, s->assoc_args, pa, fp, tp,
                                n_assoc, (uint32_t)tiles);
@@ -1381,6 +1384,7 @@ sm_ctx *sm_create(const sm_config *c)
         if (const char *e = std::getenv("SM_PASS_NW")) { const int v = std::atoi(e); if (v == 1 || v == 2 || v == 4) s->pass_nw = v; }
         if (const char *e = std::getenv("SM_PASS_COMPACT")) s->pass_compact = e[0] != '0';
         if (std::getenv("SM_PASS_TRACE") && hipMalloc((void **)&s->d_pass_trace, (size_t)MAX_GRID * 64) != hipSuccess) s->d_pass_trace = nullptr;
+        if (std::getenv("SM_PASS_TRACE") && hipMalloc((void **)&s->d_ap_trace, (size_t)65536 * 16) != hipSuccess) s->d_ap_trace = nullptr;
         s->defer_ok = s->defer_ok && s->one_pass && s->use_list && s->direct && !s->use_fused_assoc;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess && cus > 0 &&
             hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_compact<true>, 256, 0) == hipSuccess && per_cu > 0) {
@@ -1419,6 +1423,17 @@ void sm_destroy(sm_ctx *s)
             if (FILE *f = fopen(path, "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
         }
         (void)hipFree(s->d_pass_trace);
+    }
+    if (s->d_ap_trace) {
+        const int n = s->ap_trace_n[0] + s->ap_trace_n[1] + s->ap_trace_n[2];
+        std::vector<unsigned long long> h((size_t)std::max(std::min(n, 65536), 0) * 2 + 3);
+        if (n > 0 && hipMemcpy(h.data() + 3, s->d_ap_trace, (h.size() - 3) * 8, hipMemcpyDeviceToHost) == hipSuccess) {
+            h[0] = (unsigned long long)s->ap_trace_n[0]; h[1] = (unsigned long long)s->ap_trace_n[1]; h[2] = (unsigned long long)s->ap_trace_n[2];
+            char path[512];
+            snprintf(path, sizeof path, "%s.assoc_prep.bin", std::getenv("SM_PASS_TRACE") ? std::getenv("SM_PASS_TRACE") : "pass_trace");
+            if (FILE *f = fopen(path, "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
+        }
+        (void)hipFree(s->d_ap_trace);
     }
     (void)hipFree(s->d_depthT_nx); (void)hipFree(s->d_rgbsT_nx); (void)hipFree(s->d_keyT_nx); (void)hipFree(s->d_dcT_nx);
     if (s->ev_prep) (void)hipEventDestroy(s->ev_prep);

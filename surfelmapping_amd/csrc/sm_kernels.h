@@ -1836,6 +1836,8 @@ __device__ __forceinline__ void pass_tile_compact(const SurfelSet &set, DevState
             L.pos[at] = v[r];
         }
     }
+    // (a workgroup with several tiles prefetching its next tile's 16 KB here, behind phase B -- 88 VGPRs, 5 waves per SIMD --
+    //  was measured on the 20 M-surfel model, ~10 tiles per workgroup: 156.5 us with, 156.6 us without)
     __syncthreads();
     const uint32_t n_act = L.n;
     // ---- phase B: the exact tests (pass_words / splat_one, per lane) over the dense list, two entries per thread at a time
@@ -1972,8 +1974,10 @@ __global__ __launch_bounds__(256) void k_surfel_pass(Model M, DevState *__restri
                                                      uint32_t *__restrict__ frame_sub /* sets 0, 1: visible, killed -- sub-counters like conf_sub */,
                                                      unsigned long long *__restrict__ trace = nullptr /* SM_PASS_TRACE: 8 words per workgroup */)
 {
-    const unsigned long long tr0 = trace ? wall_clock64() : 0ull;
-    unsigned long long tr1 = 0, tr2 = 0, tr3 = 0, tr_tile = ~0ull, tr_n = 0;
+    // (stamps go straight to memory: kept in registers until the exit they cost the kernel 30 more spilled scalars)
+    unsigned long long *const tr = trace ? trace + (size_t)blockIdx.x * 8 : nullptr;
+    if (tr && threadIdx.x == 0) { tr[0] = wall_clock64(); tr[1] = 0ull; tr[2] = 0ull; tr[4] = ~0ull; tr[5] = 0ull; }
+    bool tr_first = true;
     // Workgroups are dispatched in blockIdx order, ~2 800 per us: the last of 2 048 enters the chip ~3 us after the first.  The
     // newest tiles -- the surfels the camera is looking at, i.e. the tiles with all the work -- are the highest ones, so the
     // mapping is reversed: block 0 takes the highest tile of the grid, and a workgroup with several tiles starts with its
@@ -2033,16 +2037,20 @@ __global__ __launch_bounds__(256) void k_surfel_pass(Model M, DevState *__restri
             continue;
         }
         if (COMPACT) {
-            if (trace && tr_tile == ~0ull) { tr1 = wall_clock64(); tr_tile = tile; }
+            const bool tr_now = tr && tr_first;
+            tr_first = false;
+            if (tr_now && threadIdx.x == 0) { tr[1] = wall_clock64(); tr[4] = tile; }
             pass_tile_compact(set, st, fp, dcT, cm, km, wave_cnt, alive, tile_dead, keyT, undo, N, exempt, tile, wave, sk0, sk1,
                               lane_bcast(m_dead, sl) != 0u, lane, acc, tb, s_pass);
-            if (trace && tr_tile == tile) { tr2 = wall_clock64(); tr_n = s_pass.n; }
+            if (tr_now && threadIdx.x == 0) { tr[2] = wall_clock64(); tr[5] = s_pass.n; }
             __syncthreads();                           // s_pass is reused by the workgroup's next tile
         } else {
-            if (trace && tr_tile == ~0ull) { tr1 = wall_clock64(); tr_tile = tile; }
+            const bool tr_now = tr && tr_first;
+            tr_first = false;
+            if (tr_now && threadIdx.x == 0) { tr[1] = wall_clock64(); tr[4] = tile; }
             pass_quarter<NW>(set, st, fp, dcT, cm, km, wave_cnt, alive, tile_dead, keyT, undo, N, exempt, tile, wave, sk0, sk1,
                              lane_bcast(m_dead, sl) != 0u, lane, acc, tb);
-            if (trace && tr_tile == tile) tr2 = wall_clock64();
+            if (tr_now && threadIdx.x == 0) tr[2] = wall_clock64();
         }
     }
     __syncthreads();
@@ -2055,14 +2063,12 @@ __global__ __launch_bounds__(256) void k_surfel_pass(Model M, DevState *__restri
         if (nc) atomicAdd(&conf_sub[(bid & 63u) * SUB_STRIDE], nc);      // 64 counters, <= 32 adders each: one load per lane to read the total
         if (nv) atomicAdd(&frame_sub[(bid & 63u) * SUB_STRIDE], nv);
         if (nk) atomicAdd(&frame_sub[SUB_SET + (bid & 63u) * SUB_STRIDE], nk);
-        if (trace) {
-            tr3 = wall_clock64();
+        if (tr) {
             uint32_t hw;
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
             uint32_t xcc;
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-            unsigned long long *t = trace + (size_t)blockIdx.x * 8;
-            t[0] = tr0; t[1] = tr1; t[2] = tr2; t[3] = tr3; t[4] = tr_tile; t[5] = tr_n; t[6] = ((unsigned long long)xcc << 32) | hw; t[7] = ntiles;
+            tr[3] = wall_clock64(); tr[6] = ((unsigned long long)xcc << 32) | hw; tr[7] = ntiles;
         }
     }
 }
@@ -2545,9 +2551,11 @@ __device__ __forceinline__ void associate_pixel(int q, const SurfelSet &cur, con
     is_fused = false;
     uint32_t f_id = 0;                        // the surfel this lane fused into, and where it moved
     float f_x = 0.f, f_y = 0.f, f_z = 0.f;
+    // (the key does not depend on the pixel's own surfel: its load is issued with the stencil's, not after the arithmetic)
+    const uint64_t key_q = fp.init_mode ? KEY_EMPTY : keyT[min(q, fp.P - 1)];
     if (q < fp.P && local_surfel(q, fp, depthT, rgbsT, xs, ys, L, qi, qj)) {
         is_valid = true;
-        const uint64_t key = keyT[q];
+        const uint64_t key = key_q;
         const int32_t gid = (int32_t)(uint32_t)(key & 0xFFFFFFFFull);
         uint32_t id = 0;
         // data.vert:142 "id > 0" on the GLOBAL id (single GPU: the slot of the first live surfel is id 0);
@@ -2826,8 +2834,13 @@ __global__ __launch_bounds__(PIX_BLOCK) void k_associate_direct(AssocArgs a, Sha
 // ---------------------------------------------------------------------------------------------
 template <bool PAIR>
 __global__ __launch_bounds__(PIX_BLOCK) void k_assoc_prep(AssocArgs a, PrepArgs p, FrameParams fp_new, TilePrep tp, uint32_t n_assoc,
-                                                          uint32_t n_img)
+                                                          uint32_t n_img, unsigned long long *__restrict__ trace = nullptr /* SM_PASS_TRACE */)
 {
+    struct Stamp {              // entry / exit time of every workgroup (thread 0), for tools/pass_trace.py
+        unsigned long long *t; unsigned long long t0;
+        __device__ Stamp(unsigned long long *tr) : t(tr), t0(tr ? wall_clock64() : 0ull) {}
+        __device__ ~Stamp() { if (t && threadIdx.x == 0) { t[(size_t)blockIdx.x * 2] = t0; t[(size_t)blockIdx.x * 2 + 1] = wall_clock64(); } }
+    } stamp(trace);
     // dispatch order: the short, streaming image tiles first.  (The chip holds ~2 048 workgroups of this size at once and the
     // three parts together are ~2 300 at KITTI size, so the launch takes 16.4 us where the association alone takes 12.2 and
     // k_prep alone 8.5: the parts overlap only partly.  Letting each image workgroup do four tiles in turn, so that

@@ -38,7 +38,7 @@ t = np.fromfile(prefix + ".0.bin", dtype=np.uint64).reshape(-1, 8).astype(np.int
 t0 = t[:, 0].min()
 ent, first, after, ex = (t[:, 0] - t0) / 100.0, (t[:, 1] - t0) / 100.0, (t[:, 2] - t0) / 100.0, (t[:, 3] - t0) / 100.0     # us
 tile, nact, xcc = t[:, 4], t[:, 5], t[:, 6] >> 32
-visited = t[:, 1] != 0
+visited = t[:, 4] != -1
 print(f"workgroups {len(t)}, tiles {t[0, 7]}, visiting a tile {visited.sum()}, with entries {(nact > 0).sum()}; launch span {ex.max():.2f} us")
 print("entry  (us after the first workgroup) percentiles 0/50/90/100:", np.percentile(ent, [0, 50, 90, 100]).round(2))
 print("exit   percentiles 0/50/90/99/100:", np.percentile(ex, [0, 50, 90, 99, 100]).round(2))
@@ -58,3 +58,17 @@ for x in range(8):
     m = xcc == x
     if m.any():
         print(f"xcc {x}: {m.sum()} workgroups, entries {nact[m].sum()}, last exit {ex[m].max():.2f}")
+# ---- the last k_assoc_prep launch: (entry, exit) per workgroup; block ranges: image tiles | tile flags | association
+ap = prefix + ".assoc_prep.bin"
+if os.path.exists(ap):
+    a = np.fromfile(ap, dtype=np.uint64).astype(np.int64)
+    n_img, n_flag, n_assoc = a[:3]
+    a = a[3:].reshape(-1, 2)
+    a0 = a[:, 0].min()
+    en, exi = (a[:, 0] - a0) / 100.0, (a[:, 1] - a0) / 100.0
+    print(f"k_assoc_prep: {n_img} image + {n_flag} flag + {n_assoc} association workgroups, launch span {exi.max():.2f} us")
+    for name, lo, hi in (("image", 0, n_img), ("flags", n_img, n_img + n_flag), ("assoc", n_img + n_flag, n_img + n_flag + n_assoc)):
+        e, x = en[lo:hi], exi[lo:hi]
+        print(f"  {name}: entry 0/50/100 {np.percentile(e, [0, 50, 100]).round(2)}  duration 50/90/100 {np.percentile(x - e, [50, 90, 100]).round(2)}  exit 50/90/100 {np.percentile(x, [50, 90, 100]).round(2)}")
+    last = np.argsort(-exi)[:8]
+    print("  last to leave (block, entry, exit):", [(int(b), round(float(en[b]), 2), round(float(exi[b]), 2)) for b in last])
