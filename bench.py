@@ -144,7 +144,7 @@ def kernel_table(log, tim, P, K, args, workload=None):
         # HBM bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this very
         # command (profiles/README.md), gfx950-corrected per kernel by tools/prof_summary.py
         tj = json.load(open(tpath))
-        if tj.get("steps") == K and tj.get("warmup") == max(args.warmup, 2) and tj.get("compact_period", 8) == args.compact_period:
+        if tj.get("steps") == K and tj.get("warmup") == max(args.warmup, 2) and tj.get("compact_period", 16) == args.compact_period:
             traffic = tj.get("kernels", {}).get(dom, {}).get("hbm_bytes_per_launch")
             valu = tj.get("kernels", {}).get(dom, {}).get("valu_issue_util")
             break
@@ -304,7 +304,7 @@ def main():
                     help="--mode sharded: in-stream form (RCCL from the HIP core; default) or round 1's per-stage form driven from Python")
     ap.add_argument("--no-rccl", action="store_true", help="--mode sharded with one rank: no communicator (the core's identity path) instead of RCCL")
     ap.add_argument("--no-plain-leg", action="store_true", help="--mode sharded: skip the plain single-GPU run of the same frames on rank 0")
-    ap.add_argument("--compact-period", type=int, default=8,
+    ap.add_argument("--compact-period", type=int, default=16,
                     help="deferred compaction: culled surfels keep their slots, every Nth cull squeezes them out (1: every frame)")
     ap.add_argument("--no-fuse-leg", action="store_true",
                     help="skip the second, labelled leg (same trajectory, depth noise 4 mm, fuse_thresh 0.05: frames that actually fuse)")

@@ -2704,6 +2704,24 @@ struct AssocArgs {
     uint64_t *alive; uint32_t *tile_dead; uint32_t n_grp, cg; unsigned long long *host_stat;
 };
 
+// Sum of grp_cand[0 .. n) over the lanes of a wave (each lane returns its share; wave_sum_u32 completes it): up to eight loads
+// per lane and round, all unconditional (clamped index) and in flight together.  (As `for (g = lane; g < n; g += 64) sum +=
+// grp_cand[g]` hipcc emitted a loop with a wait per pair of loads: with ~450 groups an association workgroup near the
+// end of the image spent four dependent round trips here before its first own load -- tools/pass_trace.py showed the
+// workgroups' durations growing with their index, 6.9 -> 9.2 us.)
+__device__ __forceinline__ uint32_t group_sum_lane(const uint32_t *__restrict__ grp_cand, uint32_t n, uint32_t n_alloc, int lane)
+{
+    uint32_t sum = 0;
+    for (uint32_t base = 0; base < n; base += 512u) {               // one round for every image up to 512 groups
+        uint32_t x[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) x[i] = grp_cand[min(base + (uint32_t)lane + 64u * (uint32_t)i, n_alloc - 1u)];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) sum += (base + (uint32_t)lane + 64u * (uint32_t)i < n) ? x[i] : 0u;
+    }
+    return sum;
+}
+
 // one association workgroup (256 threads); wg = its index in pixel order.
 // PAIR = false: one pixel per thread, the workgroup is association block `wg` (PIX_BLOCK pixels).
 // PAIR = true: TWO consecutive pixels per thread, the workgroup covers blocks 2 wg and 2 wg + 1.  data.vert:88 keeps only
@@ -2735,7 +2753,7 @@ __device__ __forceinline__ void associate_direct_block(const AssocArgs &a, const
     // issued together with DevState, one wave reduction (every wave computes it for itself)
     const uint32_t grp = blk / a.cg, in_grp = blk % a.cg;
     uint32_t pre = (lane < (int)in_grp) ? blk_cand[grp * a.cg + lane] : 0u;
-    for (uint32_t g = lane; g < grp; g += 64u) pre += grp_cand[g];
+    pre += group_sum_lane(grp_cand, grp, n_grp, lane);
     const SurfelSet cur = M.s[st->cur];
     const uint32_t offset = st->offset;
     int q = (int)blk * PIX_BLOCK + (int)threadIdx.x, qi = -1, qj = 0;
@@ -2767,7 +2785,7 @@ __device__ __forceinline__ void associate_direct_block(const AssocArgs &a, const
         // every candidate pixel of the frame owns a slot: the new count (the host never lets a frame of this form start
         // without room for all of them), published for the next frame's kernels and for the host's capacity bound
         uint32_t d = 0;
-        for (uint32_t g = lane; g < n_grp; g += 64u) d += grp_cand[g];
+        d = group_sum_lane(grp_cand, n_grp, n_grp, lane);
         d = wave_sum_u32(d);
         if (lane == 0) {
             st->count = offset + d;
