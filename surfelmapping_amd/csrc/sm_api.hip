@@ -2398,7 +2398,8 @@ int sm_shard_frame_device(sm_ctx *s, const uint8_t *d_rgb, const uint16_t *d_dep
     sh.owner = (int)(s->ss_frames % (uint32_t)s->ss_world) == s->ss_rank ? 1 : 0;
     AssocArgs aa;
     fill_assoc_args(s, fp, aa);
-    hipLaunchKernelGGL((k_associate_direct<true, false>), dim3(s->n_pix_blocks), dim3(PIX_BLOCK), 0, s->stream, aa, sh);
+    if (s->assoc_pair) hipLaunchKernelGGL((k_associate_direct<true, true>), dim3(assoc_wgs(s)), dim3(PIX_BLOCK), 0, s->stream, aa, sh);
+    else hipLaunchKernelGGL((k_associate_direct<true, false>), dim3(s->n_pix_blocks), dim3(PIX_BLOCK), 0, s->stream, aa, sh);
     HIPCK(hipGetLastError());
     if ((rc = mark(s, 5, true))) return rc;
     if ((rc = ss_collective(s, s->d_gmask, s->d_gmask, (size_t)sh.nwords + 4, SM_COLL_SUM))) return rc;   // in place, like the key map

@@ -2704,6 +2704,18 @@ struct AssocArgs {
     uint64_t *alive; uint32_t *tile_dead; uint32_t n_grp, cg; unsigned long long *host_stat;
 };
 
+// bit i of x -> bit 2 i (Morton spread)
+__device__ __forceinline__ uint64_t spread_bits32(uint32_t x)
+{
+    uint64_t v = x;
+    v = (v | (v << 16)) & 0x0000FFFF0000FFFFull;
+    v = (v | (v << 8)) & 0x00FF00FF00FF00FFull;
+    v = (v | (v << 4)) & 0x0F0F0F0F0F0F0F0Full;
+    v = (v | (v << 2)) & 0x3333333333333333ull;
+    v = (v | (v << 1)) & 0x5555555555555555ull;
+    return v;
+}
+
 // Sum of grp_cand[0 .. n) over the lanes of a wave (each lane returns its share; wave_sum_u32 completes it): up to eight loads
 // per lane and round, all unconditional (clamped index) and in flight together.  (As `for (g = lane; g < n; g += 64) sum +=
 // grp_cand[g]` hipcc emitted a loop with a wait per pair of loads: with ~450 groups an association workgroup near the
@@ -2734,7 +2746,6 @@ __device__ __forceinline__ uint32_t group_sum_lane(const uint32_t *__restrict__ 
 template <bool SHARD, bool PAIR>
 __device__ __forceinline__ void associate_direct_block(const AssocArgs &a, const ShardArgs &sh, const uint32_t wg)
 {
-    static_assert(!(SHARD && PAIR), "the mask planes of the sharded form are one bit per lane");
     const uint32_t blk = PAIR ? wg * 2u : wg;            // first association block of the workgroup (an even one: same group as the next)
     const Model &M = a.M; DevState *__restrict__ st = a.st; const FrameParams &fp = a.fp;
     const float *__restrict__ depthT = a.depthT; const uint32_t *__restrict__ rgbsT = a.rgbsT; const uint64_t *__restrict__ keyT = a.keyT;
@@ -2770,9 +2781,24 @@ __device__ __forceinline__ void associate_direct_block(const AssocArgs &a, const
                     SHARD ? alive : nullptr, &mv, qi, qj);
     const uint64_t vw = __ballot(is_valid), fw = __ballot(is_fused);
     if (lane == 0) { s_v[wave] = (uint32_t)__popcll(vw); s_n[wave] = (uint32_t)__popcll(vw & ~fw); s_f[wave] = (uint32_t)__popcll(fw); }
-    if (SHARD && lane == 0) {
+    if (SHARD && !PAIR && lane == 0) {
         const uint32_t word = blk * (PIX_BLOCK / 64) + (uint32_t)wave;
         if (word < sh.nwords) { sh.validmask[word] = vw; sh.ownmask[word] = fw; sh.gmask[word] = fw; }
+    }
+    if (SHARD && PAIR) {
+        // the mask planes are one bit per PIXEL: lane l holds pixel 2 l or 2 l + 1 of the wave's 128, so the ballots (one bit
+        // per lane) are spread to the even bit positions and the lanes that took the odd pixel move up by one
+        const uint64_t odd = __ballot((q & 1) != 0);
+        if (lane == 0) {
+            const uint32_t word = blk * (PIX_BLOCK / 64) + (uint32_t)wave * 2u;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const uint32_t v32 = (uint32_t)(vw >> (32 * h)), f32 = (uint32_t)(fw >> (32 * h)), o32 = (uint32_t)(odd >> (32 * h));
+                const uint64_t vm = spread_bits32(v32 & ~o32) | (spread_bits32(v32 & o32) << 1);
+                const uint64_t fm = spread_bits32(f32 & ~o32) | (spread_bits32(f32 & o32) << 1);
+                if (word + (uint32_t)h < sh.nwords) { sh.validmask[word + h] = vm; sh.ownmask[word + h] = fm; sh.gmask[word + h] = fm; }
+            }
+        }
     }
     pre = wave_sum_u32(pre);
     __syncthreads();
