@@ -11,6 +11,23 @@
 
 namespace sm {
 
+// The side planes of the two view volumes go through the camera centre, so "all 8 corners of the box are outside plane X" is a
+// statement about a linear form g(p) = c1 p.x + c2 p.z (or p.y, p.z): positive at every corner => positive on the whole box
+// => every point of it with z > 0 projects outside that image edge (by the 2-pixel margin built into c2) -- whether or not
+// part of the box is BEHIND the camera.  (Round 1 applied these tests only to boxes entirely in front, zmin > 1 mm; but the
+// boxes are thin slanted slabs -- a few image columns of one past frame, near ground to far facades -- that the camera
+// passes for ~37 frames with their near end behind it and everything in front of it already outside the image: on a KITTI
+// frame 950 tiles passed the old test, 700 pass this one, 470 hold a surfel in view.)  What a box straddling z = 0 does
+// need is a guard against rounding, because there the margin (2 pixels x z) shrinks to nothing: g must clear `guard`, a
+// bound on the rounding error of g at a corner (transformed coordinates carry ~4 ulp of S = the sum of the box's bounds and
+// the translation; the coefficients are below C = fx + fy + cols + rows).
+__device__ __forceinline__ float plane_guard(const FrameParams &fp, float lx, float ly, float lz, float hx, float hy, float hz)
+{
+    const float S = (fabsf(lx) + fabsf(hx)) + (fabsf(ly) + fabsf(hy)) + (fabsf(lz) + fabsf(hz)) +
+                    (fabsf(fp.t_inv[12]) + fabsf(fp.t_inv[13]) + fabsf(fp.t_inv[14]));
+    return 2.0e-6f * (((fp.fx + fp.fy) + fp.cols) + fp.rows) * S;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Per-tile skip flags of the frame (bit 0: outside the conflict view volume, conflict.vert:35; bit 1:
 // cannot reach the index map, index_map.vert:45-55 incl. the timeDelta gate), from the tile bounds as they
@@ -29,24 +46,24 @@ __device__ __forceinline__ uint32_t tile_flags_one(uint32_t t, const FrameParams
             const float lx = ord2f(~b[0]), ly = ord2f(~b[1]), lz = ord2f(~b[2]), hx = ord2f(b[4]), hy = ord2f(b[5]), hz = ord2f(b[6]);
             float zmin = 3.0e38f, zmax = -3.0e38f;
             bool right = true, left_c = true, left_s = true, below = true, above = true, finite = true;
+            const float gd = plane_guard(fp, lx, ly, lz, hx, hy, hz);
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
                 const float3 p = xform3(fp.t_inv, (c & 1) ? hx : lx, (c & 2) ? hy : ly, (c & 4) ? hz : lz);
                 finite = finite && (p.x - p.x == 0.0f) && (p.y - p.y == 0.0f) && (p.z - p.z == 0.0f);
                 zmin = fminf(zmin, p.z); zmax = fmaxf(zmax, p.z);
-                right = right && (fp.fx * p.x + (fp.cx - fp.cols - 2.0f) * p.z > 0.0f);
-                left_c = left_c && (fp.fx * p.x + (fp.cx - fp.stereo_border + 2.0f) * p.z < 0.0f);
-                left_s = left_s && (fp.fx * p.x + (fp.cx + 2.0f) * p.z < 0.0f);
-                below = below && (fp.fy * p.y + (fp.cy - fp.rows - 2.0f) * p.z > 0.0f);
-                above = above && (fp.fy * p.y + (fp.cy + 2.0f) * p.z < 0.0f);
+                right = right && (fp.fx * p.x + (fp.cx - fp.cols - 2.0f) * p.z > gd);
+                left_c = left_c && (fp.fx * p.x + (fp.cx - fp.stereo_border + 2.0f) * p.z < -gd);
+                left_s = left_s && (fp.fx * p.x + (fp.cx + 2.0f) * p.z < -gd);
+                below = below && (fp.fy * p.y + (fp.cy - fp.rows - 2.0f) * p.z > gd);
+                above = above && (fp.fy * p.y + (fp.cy + 2.0f) * p.z < -gd);
             }
             if (finite) {
-                const bool front = zmin > 1.0e-3f;
                 // bit 0: conflict.vert:35  (min < Z < max, border <= u <= cols, 0 <= v <= rows)
-                if (zmax < fp.min_depth - 0.01f || zmin > fp.max_depth + 0.01f || (front && (right || left_c || below || above)))
+                if (zmax < fp.min_depth - 0.01f || zmin > fp.max_depth + 0.01f || right || left_c || below || above)
                     f |= 1u;
                 // bit 1: index_map.vert:45-55  (0 < Z < far, inside the image, updated within timeDelta frames)
-                if (zmax < -0.01f || zmin > fp.depth_cutoff + 0.01f || (front && (right || left_s || below || above)) ||
+                if (zmax < -0.01f || zmin > fp.depth_cutoff + 0.01f || right || left_s || below || above ||
                     (float)fp.time - ord2f(b[7]) > (float)fp.time_delta)
                     f |= 2u;
             }
@@ -76,11 +93,12 @@ __device__ __forceinline__ void tile_flags_batch(uint32_t first, uint32_t stride
         const float3 p = xform3(fp.t_inv, (c & 1) ? ord2f(b4) : ord2f(~b0), (c & 2) ? ord2f(b5) : ord2f(~b1),
                                 (c & 4) ? ord2f(b6) : ord2f(~b2));
         const bool fin = (p.x - p.x == 0.0f) && (p.y - p.y == 0.0f) && (p.z - p.z == 0.0f);
-        const bool r_ = fp.fx * p.x + (fp.cx - fp.cols - 2.0f) * p.z > 0.0f;
-        const bool lc = fp.fx * p.x + (fp.cx - fp.stereo_border + 2.0f) * p.z < 0.0f;
-        const bool ls = fp.fx * p.x + (fp.cx + 2.0f) * p.z < 0.0f;
-        const bool be = fp.fy * p.y + (fp.cy - fp.rows - 2.0f) * p.z > 0.0f;
-        const bool ab = fp.fy * p.y + (fp.cy + 2.0f) * p.z < 0.0f;
+        const float gd = plane_guard(fp, ord2f(~b0), ord2f(~b1), ord2f(~b2), ord2f(b4), ord2f(b5), ord2f(b6));
+        const bool r_ = fp.fx * p.x + (fp.cx - fp.cols - 2.0f) * p.z > gd;
+        const bool lc = fp.fx * p.x + (fp.cx - fp.stereo_border + 2.0f) * p.z < -gd;
+        const bool ls = fp.fx * p.x + (fp.cx + 2.0f) * p.z < -gd;
+        const bool be = fp.fy * p.y + (fp.cy - fp.rows - 2.0f) * p.z > gd;
+        const bool ab = fp.fy * p.y + (fp.cy + 2.0f) * p.z < -gd;
         float zmin = p.z, zmax = p.z;
 #pragma unroll
         for (int o = 1; o < 8; o <<= 1) { zmin = fminf(zmin, __shfl_xor(zmin, o)); zmax = fmaxf(zmax, __shfl_xor(zmax, o)); }
@@ -94,9 +112,8 @@ __device__ __forceinline__ void tile_flags_batch(uint32_t first, uint32_t stride
             if (b0 == 0u && b4 == 0u) {
                 f = 3u;                                            // no surfel recorded at all
             } else if (finite) {
-                const bool front = zmin > 1.0e-3f;
-                if (zmax < fp.min_depth - 0.01f || zmin > fp.max_depth + 0.01f || (front && (right || left_c || below || above))) f |= 1u;
-                if (zmax < -0.01f || zmin > fp.depth_cutoff + 0.01f || (front && (right || left_s || below || above)) ||
+                if (zmax < fp.min_depth - 0.01f || zmin > fp.max_depth + 0.01f || right || left_c || below || above) f |= 1u;
+                if (zmax < -0.01f || zmin > fp.depth_cutoff + 0.01f || right || left_s || below || above ||
                     (float)fp.time - ord2f(b7) > (float)fp.time_delta)
                     f |= 2u;
             }
@@ -156,11 +173,12 @@ __device__ __forceinline__ void tile_prep_block(const FrameParams &fp, const Til
         const float3 p = xform3(fp.t_inv, (c & 1) ? ord2f(b4) : ord2f(~b0), (c & 2) ? ord2f(b5) : ord2f(~b1),
                                 (c & 4) ? ord2f(b6) : ord2f(~b2));
         const bool fin = (p.x - p.x == 0.0f) && (p.y - p.y == 0.0f) && (p.z - p.z == 0.0f);
-        const bool r_ = fp.fx * p.x + (fp.cx - fp.cols - 2.0f) * p.z > 0.0f;
-        const bool lc = fp.fx * p.x + (fp.cx - fp.stereo_border + 2.0f) * p.z < 0.0f;
-        const bool ls = fp.fx * p.x + (fp.cx + 2.0f) * p.z < 0.0f;
-        const bool be = fp.fy * p.y + (fp.cy - fp.rows - 2.0f) * p.z > 0.0f;
-        const bool ab = fp.fy * p.y + (fp.cy + 2.0f) * p.z < 0.0f;
+        const float gd = plane_guard(fp, ord2f(~b0), ord2f(~b1), ord2f(~b2), ord2f(b4), ord2f(b5), ord2f(b6));
+        const bool r_ = fp.fx * p.x + (fp.cx - fp.cols - 2.0f) * p.z > gd;
+        const bool lc = fp.fx * p.x + (fp.cx - fp.stereo_border + 2.0f) * p.z < -gd;
+        const bool ls = fp.fx * p.x + (fp.cx + 2.0f) * p.z < -gd;
+        const bool be = fp.fy * p.y + (fp.cy - fp.rows - 2.0f) * p.z > gd;
+        const bool ab = fp.fy * p.y + (fp.cy + 2.0f) * p.z < -gd;
         float zmin = p.z, zmax = p.z;
 #pragma unroll
         for (int o = 1; o < 8; o <<= 1) { zmin = fminf(zmin, __shfl_xor(zmin, o)); zmax = fmaxf(zmax, __shfl_xor(zmax, o)); }
@@ -174,9 +192,8 @@ __device__ __forceinline__ void tile_prep_block(const FrameParams &fp, const Til
             if (b0 == 0u && b4 == 0u) {
                 f = 3u;                                            // no surfel recorded at all
             } else if (finite) {
-                const bool front = zmin > 1.0e-3f;
-                if (zmax < fp.min_depth - 0.01f || zmin > fp.max_depth + 0.01f || (front && (right || left_c || below || above))) f |= 1u;
-                if (zmax < -0.01f || zmin > fp.depth_cutoff + 0.01f || (front && (right || left_s || below || above)) ||
+                if (zmax < fp.min_depth - 0.01f || zmin > fp.max_depth + 0.01f || right || left_c || below || above) f |= 1u;
+                if (zmax < -0.01f || zmin > fp.depth_cutoff + 0.01f || right || left_s || below || above ||
                     (float)fp.time - ord2f(b7) > (float)fp.time_delta)
                     f |= 2u;
             }
