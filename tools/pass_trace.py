@@ -4,7 +4,7 @@
 SM_PASS_TRACE=<prefix> makes the HIP core hand the kernel a buffer of 8 words per workgroup (wall_clock64 -- 100 MHz -- at
 entry, at its first visited tile, after that tile, at exit; the tile, its compacted entries, XCC | HW_ID, tiles) and dump
 the last launch's record at sm_destroy.  This script runs N KITTI-shaped frames (bench.py's generator), dumps, and
-prints the launch's time line.  usage: tools/pass_trace.py [frames] [compact 0|1]"""
+prints the launch's time line.  usage: tools/pass_trace.py [frames] [compact 0|1] | --analyze"""
 import os
 import sys
 
@@ -12,28 +12,31 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-n_frames = int(sys.argv[1]) if len(sys.argv) > 1 else 23
 prefix = os.path.join(ROOT, "gpurun_out", "pass_trace")
-os.environ["SM_PASS_TRACE"] = prefix
-if len(sys.argv) > 2:
-    os.environ["SM_PASS_COMPACT"] = sys.argv[2]
-from surfelmapping_amd import capi, synth   # noqa: E402
-import bench                                 # noqa: E402
+if len(sys.argv) > 1 and sys.argv[1] == "--analyze":      # only print the time line of the dumps already in gpurun_out/
+    pass
+else:
+    n_frames = int(sys.argv[1]) if len(sys.argv) > 1 else 23
+    os.environ["SM_PASS_TRACE"] = prefix
+    if len(sys.argv) > 2:
+        os.environ["SM_PASS_COMPACT"] = sys.argv[2]
+    from surfelmapping_amd import capi, synth   # noqa: E402
+    import bench                                 # noqa: E402
 
-cam = synth.KITTI
-frames = bench.make_frames(cam, n_frames, 1, 15.0, 8)
-P = cam["width"] * cam["height"]
-sm = capi.SurfelMap(capi.make_config(**cam, preprocess=0))
-bufs = []
-for rgb, d, s, p in frames:
-    dr, dd, ds = sm.device_alloc(P * 3), sm.device_alloc(P * 2), sm.device_alloc(P)
-    sm.device_upload(dr, rgb); sm.device_upload(dd, d); sm.device_upload(ds, s)
-    bufs.append((dr, dd, ds, p))
-for b in bufs:
-    sm.process_frame_device(*b)
-sm.sync()
-print("counts", sm.counts())
-sm.close()
+    cam = synth.KITTI
+    frames = bench.make_frames(cam, n_frames, 1, 15.0, 8)
+    P = cam["width"] * cam["height"]
+    sm = capi.SurfelMap(capi.make_config(**cam, preprocess=0))
+    bufs = []
+    for rgb, d, s, p in frames:
+        dr, dd, ds = sm.device_alloc(P * 3), sm.device_alloc(P * 2), sm.device_alloc(P)
+        sm.device_upload(dr, rgb); sm.device_upload(dd, d); sm.device_upload(ds, s)
+        bufs.append((dr, dd, ds, p))
+    for b in bufs:
+        sm.process_frame_device(*b)
+    sm.sync()
+    print("counts", sm.counts())
+    sm.close()
 t = np.fromfile(prefix + ".0.bin", dtype=np.uint64).reshape(-1, 8).astype(np.int64)
 t0 = t[:, 0].min()
 ent, first, after, ex = (t[:, 0] - t0) / 100.0, (t[:, 1] - t0) / 100.0, (t[:, 2] - t0) / 100.0, (t[:, 3] - t0) / 100.0     # us
