@@ -394,6 +394,56 @@ def test_tile_bounds_with_yaw_and_turning_back():
     assert log["n_conf_skipped"].max() > 10_000
 
 
+def test_tile_bounds_with_the_camera_inside_the_boxes():
+    """The side planes of the view volumes are applied to tile boxes that straddle the camera plane too (sm_kernels.h
+    plane_guard): a linear form that is positive at all 8 corners is positive on the whole box.  Uploaded model scattered
+    all around a camera that sits INSIDE every tile's box, with surfels within centimetres of the camera plane and close
+    to the image borders there (where the 2-pixel margin times z shrinks to the rounding error the guard has to cover);
+    small random pose changes; A/B against disable_tile_bounds=1 and against the oracle."""
+    rng = np.random.default_rng(77)
+    n_tiles, T = 48, 1024                                         # one compact cluster per 1024-surfel tile: a box of its own
+    n = n_tiles * T
+    m = np.zeros((n, 12), dtype=np.float32)
+    for t in range(n_tiles):
+        kind = t % 3
+        if kind == 0:      # beside the camera, straddling its plane: everything of it in front is outside the image
+            c = np.array([rng.choice([-1, 1]) * rng.uniform(1.5, 8.0), rng.uniform(-2, 2), rng.uniform(-1.0, 1.0)])
+            hs = rng.uniform(0.3, 1.2, 3)
+        elif kind == 1:    # tiny, on the ray of an image border, centimetres in front of / behind the camera plane
+            z0 = rng.uniform(0.01, 0.12)
+            u = rng.choice([0.0, float(SMALL["width"]), rng.uniform(0, SMALL["width"])])
+            v = 0.0 if u not in (0.0, float(SMALL["width"])) and rng.random() < 0.5 else rng.uniform(0, SMALL["height"])
+            c = np.array([(u - SMALL["cx"]) / SMALL["fx"] * z0, (v - SMALL["cy"]) / SMALL["fy"] * z0, z0])
+            hs = rng.uniform(0.005, 0.06, 3)
+        else:              # anywhere around, any size: some in view, some behind, some containing the camera
+            c = np.array([rng.uniform(-8, 8), rng.uniform(-3, 3), rng.uniform(-4, 12)])
+            hs = rng.uniform(0.1, 4.0, 3)
+        m[t * T:(t + 1) * T, 0:3] = (c + rng.uniform(-1, 1, (T, 3)) * hs).astype(np.float32)
+    m[:, 3] = rng.choice(np.array([0.9, 1.8, 2.7], dtype=np.float32), n)
+    m[:, 4] = ((rng.integers(0, 19, n, dtype=np.uint32) << 24) | rng.integers(0, 1 << 24, n, dtype=np.uint32)).view(np.float32)
+    m[:, 6] = 1.0; m[:, 7] = 1.0
+    nv = rng.normal(size=(n, 3)); nv /= np.linalg.norm(nv, axis=1, keepdims=True)
+    m[:, 8:11] = nv.astype(np.float32)
+    m[:, 11] = rng.uniform(0.02, 0.1, n).astype(np.float32)
+    poses = [synth.pose_matrix(0.002 * k, 0.001 * k, 0.003 * k, 0.4 * k) for k in range(6)]
+    seq = synth.make_sequence(SMALL, poses, seed=21, noise_mm=5.0)
+    o, h = pair(SMALL, stereo_border=20.0, max_sqrt_vertices=500)
+    args = (SMALL["width"], SMALL["height"], SMALL["fx"], SMALL["fy"], SMALL["cx"], SMALL["cy"])
+    h_off = make("hip", *args, preprocess=0, stereo_border=20.0, max_sqrt_vertices=500, disable_tile_bounds=1)
+    o.process_frame(*seq[0]); h.process_frame(*seq[0]); h_off.process_frame(*seq[0])
+    for b in (o, h, h_off):
+        b.upload_model(m)
+    for k, fr in enumerate(seq[1:]):
+        o.process_frame(*fr); h.process_frame(*fr); h_off.process_frame(*fr)
+        check(o, h, f"bounds on, frame {k}")
+        check(o, h_off, f"bounds off, frame {k}")
+    log_on, log_off = h.read_frame_log(), h_off.read_frame_log()
+    assert np.array_equal(log_on["visible_count"], log_off["visible_count"])
+    assert np.array_equal(log_on["conflict_count"], log_off["conflict_count"])
+    assert log_on["n_conf_skipped"].min() >= 8 * 1024 and log_on["n_splat_skipped"].min() >= 2 * 1024, log_on[-3:]     # (tiles really are skipped)
+    assert log_on["visible_count"].min() > 2000 and log_on["conflict_count"].max() > 500, log_on[-3:]
+
+
 def test_raw_feedback_cloud_matches_oracle():
     """FeedbackBuffer "RAW" (src/FeedbackBuffer.cpp:85-145, surfel_feedback.vert): the raw camera-frame cloud of the last
     frame through sm_download_raw_cloud -- empty before the second call (the reference computes it from the second
