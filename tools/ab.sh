@@ -1,3 +1,6 @@
+#!/bin/bash
+# Quick A/B step on the GPU box: the parity subset (fuzz, deferred compaction, KATs), then the three bench lines with their
+# dominant kernels.  usage (through gpurun): bash tools/ab.sh <tag>   -> gpurun_out/<tag>_{k20,k100,hd}.json
 set -e
 tag=$1; shift
 python -m pytest tests/test_fuzz_gpu.py tests/test_deferred_compaction.py tests/test_kat.py -m gpu -x -q > gpurun_out/${tag}_pytest.log 2>&1 || { tail -n 30 gpurun_out/${tag}_pytest.log; exit 1; }
