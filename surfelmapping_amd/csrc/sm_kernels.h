@@ -2602,13 +2602,31 @@ __device__ __forceinline__ void associate_pixel(int q, const SurfelSet &cur, con
                        global_to_local((uint32_t)gid, gseg_base, fp.n_gseg, seg_lstart, fp.rank, fp.world, &id);
             }
         }
+        // The key carries the winner's depth: d24 is index_map.vert's z / depth_cutoff in 24 bits, computed in THIS frame from
+        // the very transform data.vert:151 applies to the same position (an id sits in one pixel, so nothing has moved it
+        // since), i.e. camera-frame z to within depth_cutoff / 2^23 plus a few ulp.  A pixel whose measured depth is further
+        // from it than the threshold plus a millimetre-scale margin cannot pass that test, whatever the surfel's class: the
+        // 16-byte gather of its position -- a 64-byte line per keyed pixel, the largest single item of this kernel's HBM
+        // traffic -- is only issued for the others (depth noise of 15 mm: one keyed pixel in twenty).
+        if (mine) {
+            const float z_key = ((float)(uint32_t)(key >> 32) * (2.0f / 16777215.0f) - 1.0f) * fp.depth_cutoff;
+            const float slack = (1.0e-3f + 1.0e-5f * fp.depth_cutoff) * L.lambda;
+            if (fabsf(z_key - L.pos.z) * L.lambda > fp.fuse_thresh + slack) mine = false;            // (false for NaN: the exact test decides)
+        }
         if (mine) {
             const float4 pc = cur.pos_conf[id];
-            const uint32_t col = cur.color[id];
-            const uint32_t sem_o = col >> 24;
+            // The colour word (class + colour of the old surfel) is a second scattered line per keyed pixel -- ~150 k x 64 B of
+            // the launch's ~46 MB of HBM traffic.  With a threshold of exactly 0 (the frame path's default) data.vert:151's
+            // depth test passes for a pixel or two per frame, so there the word is fetched only behind that test; with a
+            // positive threshold most keyed pixels pass it and the two gathers stay together.
+            const bool lazy_col = fp.fuse_thresh == 0.0f;                                            // uniform
+            uint32_t col = lazy_col ? 0u : cur.color[id];
             // index_map.vert:40,61 camera-frame attributes, recomputed from the model
             const float3 vo = xform3(fp.t_inv, pc.x, pc.y, pc.z);
-            if (L.sem == sem_o && fabsf(vo.z * L.lambda - L.pos.z * L.lambda) <= fp.fuse_thresh) {   // data.vert:151
+            bool near = fabsf(vo.z * L.lambda - L.pos.z * L.lambda) <= fp.fuse_thresh;
+            if (lazy_col && near) col = cur.color[id];
+            const uint32_t sem_o = col >> 24;
+            if (near && L.sem == sem_o) {                                                            // data.vert:151
                 const float3 ray = make_float3(L.xl, L.yl, 1.0f);
                 const float3 cr = cross3(ray, vo);
                 const float dist = sqrtf(dot3(cr, cr)) / sqrtf(dot3(ray, ray));
