@@ -326,7 +326,7 @@ struct sm_ctx {
     unsigned long long *d_pass_trace = nullptr;   // SM_PASS_TRACE=<file prefix>: per-workgroup time stamps of the last k_surfel_pass launch, dumped by sm_destroy
     int pass_trace_grid = 0;
     unsigned long long *d_ap_trace = nullptr;     // the same for the last k_assoc_prep launch: (entry, exit) per workgroup
-    int ap_trace_n[3] = {0, 0, 0};                // its image / tile-flag / association workgroups
+    int ap_trace_n[3] = {0, 0, 0};                // its association / tile-flag / image workgroups (dispatch order)
     bool pass_compact = true;          // k_surfel_pass compacts the lanes that can be in view before the exact tests (SM_PASS_COMPACT=0: word by word)
     int pass_nw = 2;                   // 64-slot words a wave of k_surfel_pass settles at a time (SM_PASS_NW = 1, 2, 4)
     bool merged_finalize = true;       // SM_NO_MERGED_FINALIZE=1: keep k_cull_finalize + k_cull_lazy as separate launches
@@ -567,7 +567,7 @@ int launch_prep(sm_ctx *s, const uint8_t *rgb, const uint16_t *raw, const uint8_
         pa.keyT = clear_keys ? s->d_keyT : nullptr; pa.dcT = s->d_dcT;
         pa.conf_sub = clear_keys ? s->d_conf_sub + SUB_SET * s->conf_sub_set : nullptr;
         const uint32_t n_assoc = assoc_wgs(s);
-        if (s->d_ap_trace) { s->ap_trace_n[0] = (int)tiles; s->ap_trace_n[1] = (int)tp.nfb; s->ap_trace_n[2] = (int)n_assoc; }
+        if (s->d_ap_trace) { s->ap_trace_n[0] = (int)n_assoc; s->ap_trace_n[1] = (int)tp.nfb; s->ap_trace_n[2] = (int)tiles; }    // dispatch order
         if (s->assoc_pair)
             hipLaunchKernelGGL(k_assoc_prep<true>, dim3(tp.nfb + n_assoc + (uint32_t)tiles), dim3(PIX_BLOCK), 0, s->stream, s->assoc_args, pa, fp, tp,
                                n_assoc, (uint32_t)tiles, s->d_ap_trace);

@@ -2614,23 +2614,20 @@ __device__ __forceinline__ void associate_pixel(int q, const SurfelSet &cur, con
             if (fabsf(z_key - L.pos.z) * L.lambda > fp.fuse_thresh + slack) mine = false;            // (false for NaN: the exact test decides)
         }
         if (mine) {
+            // what is left after the filter is a pixel in twenty at 15 mm depth noise (most of them with a positive threshold and
+            // little noise): position, colour word and normal + radius go out TOGETHER -- the pixel or two per frame that
+            // really fuse sit in the workgroup that leaves the launch last, and every dependent gather there is ~1.5 us of it
             const float4 pc = cur.pos_conf[id];
-            // The colour word (class + colour of the old surfel) is a second scattered line per keyed pixel -- ~150 k x 64 B of
-            // the launch's ~46 MB of HBM traffic.  With a threshold of exactly 0 (the frame path's default) data.vert:151's
-            // depth test passes for a pixel or two per frame, so there the word is fetched only behind that test; with a
-            // positive threshold most keyed pixels pass it and the two gathers stay together.
-            const bool lazy_col = fp.fuse_thresh == 0.0f;                                            // uniform
-            uint32_t col = lazy_col ? 0u : cur.color[id];
+            const uint32_t col = cur.color[id];
+            const float4 nr = cur.norm_rad[id];
             // index_map.vert:40,61 camera-frame attributes, recomputed from the model
             const float3 vo = xform3(fp.t_inv, pc.x, pc.y, pc.z);
-            bool near = fabsf(vo.z * L.lambda - L.pos.z * L.lambda) <= fp.fuse_thresh;
-            if (lazy_col && near) col = cur.color[id];
+            const bool near = fabsf(vo.z * L.lambda - L.pos.z * L.lambda) <= fp.fuse_thresh;
             const uint32_t sem_o = col >> 24;
             if (near && L.sem == sem_o) {                                                            // data.vert:151
                 const float3 ray = make_float3(L.xl, L.yl, 1.0f);
                 const float3 cr = cross3(ray, vo);
                 const float dist = sqrtf(dot3(cr, cr)) / sqrtf(dot3(ray, ray));
-                const float4 nr = cur.norm_rad[id];
                 const float3 no = normalize3(rot3(fp.t_inv, nr.x, nr.y, nr.z));                       // index_map.vert:63
                 const float ang = acos_spec(dot3(no, L.nrm) / (sqrtf(dot3(no, no)) * sqrtf(dot3(L.nrm, L.nrm))));
                 if (dist < 1000.0f && fabsf(ang) < 0.5f) {                                           // data.vert:158
@@ -2938,12 +2935,18 @@ __global__ __launch_bounds__(PIX_BLOCK) void k_assoc_prep(AssocArgs a, PrepArgs 
     // three parts together are ~2 300 at KITTI size, so the launch takes 16.4 us where the association alone takes 12.2 and
     // k_prep alone 8.5: the parts overlap only partly.  Letting each image workgroup do four tiles in turn, so that
     // everything is resident at once, made those workgroups the long pole: 25 us.)
-    if (blockIdx.x < n_img) { prep_image_block<PIX_BLOCK>(p, fp_new, blockIdx.x); return; }       // workgroup-uniform
-    const uint32_t b = blockIdx.x - n_img;
-    if (b < tp.nfb) { tile_prep_block(fp_new, tp, n_img); return; }
+    // (round 2, second half: the association first.  All ~1 500 workgroups are in the chip within 0.3 us and their loads are one
+    //  burst served roughly in dispatch order; the association is the part with two or three DEPENDENT round trips, the image
+    //  tiles have one.)
+    if (blockIdx.x >= n_assoc) {                                                                  // workgroup-uniform
+        const uint32_t b = blockIdx.x - n_assoc;
+        if (b < tp.nfb) { tile_prep_block(fp_new, tp, n_assoc); return; }
+        prep_image_block<PIX_BLOCK>(p, fp_new, b - tp.nfb);
+        return;
+    }
     ShardArgs none;
     none.validmask = nullptr; none.ownmask = nullptr; none.gmask = nullptr; none.nwords = 0u; none.owner = 1;
-    associate_direct_block<false, PAIR>(a, none, b - tp.nfb);
+    associate_direct_block<false, PAIR>(a, none, blockIdx.x);
 }
 
 // stand-alone form (when something reads the frame's counters before the next frame's k_prep has run)

@@ -61,16 +61,16 @@ for x in range(8):
     m = xcc == x
     if m.any():
         print(f"xcc {x}: {m.sum()} workgroups, entries {nact[m].sum()}, last exit {ex[m].max():.2f}")
-# ---- the last k_assoc_prep launch: (entry, exit) per workgroup; block ranges: image tiles | tile flags | association
+# ---- the last k_assoc_prep launch: (entry, exit) per workgroup; block ranges: association | tile flags | image tiles
 ap = prefix + ".assoc_prep.bin"
 if os.path.exists(ap):
     a = np.fromfile(ap, dtype=np.uint64).astype(np.int64)
-    n_img, n_flag, n_assoc = a[:3]
+    n_assoc, n_flag, n_img = a[:3]          # block ranges in dispatch order: association | tile flags | image tiles
     a = a[3:].reshape(-1, 2)
     a0 = a[:, 0].min()
     en, exi = (a[:, 0] - a0) / 100.0, (a[:, 1] - a0) / 100.0
     print(f"k_assoc_prep: {n_img} image + {n_flag} flag + {n_assoc} association workgroups, launch span {exi.max():.2f} us")
-    for name, lo, hi in (("image", 0, n_img), ("flags", n_img, n_img + n_flag), ("assoc", n_img + n_flag, n_img + n_flag + n_assoc)):
+    for name, lo, hi in (("assoc", 0, n_assoc), ("flags", n_assoc, n_assoc + n_flag), ("image", n_assoc + n_flag, n_assoc + n_flag + n_img)):
         e, x = en[lo:hi], exi[lo:hi]
         print(f"  {name}: entry 0/50/100 {np.percentile(e, [0, 50, 100]).round(2)}  duration 50/90/100 {np.percentile(x - e, [50, 90, 100]).round(2)}  exit 50/90/100 {np.percentile(x, [50, 90, 100]).round(2)}")
     last = np.argsort(-exi)[:8]
