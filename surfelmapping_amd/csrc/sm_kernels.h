@@ -2929,7 +2929,7 @@ __global__ __launch_bounds__(PIX_BLOCK) void k_assoc_prep(AssocArgs a, PrepArgs 
     struct Stamp {              // entry / exit time of every workgroup (thread 0), for tools/pass_trace.py
         unsigned long long *t; unsigned long long t0;
         __device__ Stamp(unsigned long long *tr) : t(tr), t0(tr ? wall_clock64() : 0ull) {}
-        __device__ ~Stamp() { if (t && threadIdx.x == 0) { t[(size_t)blockIdx.x * 2] = t0; t[(size_t)blockIdx.x * 2 + 1] = wall_clock64(); } }
+        __device__ ~Stamp() { if (t && threadIdx.x == 0 && blockIdx.x < 65536u) { t[(size_t)blockIdx.x * 2] = t0; t[(size_t)blockIdx.x * 2 + 1] = wall_clock64(); } }   // (the buffer holds 65 536 records)
     } stamp(trace);
     // dispatch order: the short, streaming image tiles first.  (The chip holds ~2 048 workgroups of this size at once and the
     // three parts together are ~2 300 at KITTI size, so the launch takes 16.4 us where the association alone takes 12.2 and

@@ -297,7 +297,8 @@ def test_fused_associate_append_variant_matches_oracle():
 @pytest.mark.parametrize("env", [{"SM_COMPACT_TICKETS": "1"}, {"SM_ONE_PASS": "0"}, {"SM_ONE_PASS": "0", "SM_NO_MERGED_FINALIZE": "1"},
                                  {"SM_DIRECT_APPEND": "0"}, {"SM_DIRECT_APPEND": "0", "SM_TILE_FLAGS_IN_PREP": "0", "SM_PASS_NW": "4"},
                                  {"SM_DEFER_ASSOC": "0"}, {"SM_ASSOC_PAIR": "0"}, {"SM_ASSOC_PAIR": "0", "SM_DEFER_ASSOC": "0"},
-                                 {"SM_PASS_COMPACT": "0"}, {"SM_PASS_COMPACT": "0", "SM_TILE_FLAGS_IN_PREP": "0"}])
+                                 {"SM_PASS_COMPACT": "0"}, {"SM_PASS_COMPACT": "0", "SM_TILE_FLAGS_IN_PREP": "0"},
+                                 {"SM_PASS_TRACE": "@tmp"}])
 def test_kernel_variants_behind_switches_stay_bit_exact(env):
     """SM_COMPACT_TICKETS=1: the in-place compaction hands its moving tiles out from a ticket counter (the form used as
     soon as two contexts share a GPU: no co-residency assumption).  SM_ONE_PASS=0: separate conflict and cull passes over
@@ -311,11 +312,20 @@ def test_kernel_variants_behind_switches_stay_bit_exact(env):
     a 64-slot word as soon as one of them is in view) instead of first compacting the lanes that can be in view."""
     import subprocess
     import sys
+    import tempfile
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tmp = None
+    if env.get("SM_PASS_TRACE") == "@tmp":      # the per-workgroup time stamps (tools/pass_trace.py) must not change a result either
+        tmp = tempfile.TemporaryDirectory()
+        env = dict(env, SM_PASS_TRACE=os.path.join(tmp.name, "trace"))
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-m", "gpu", "-x", "tests/test_deferred_compaction.py",
                         "tests/test_fuzz_gpu.py"], cwd=root, env=dict(os.environ, SM_FUZZ_SEEDS="24", **env),
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2500:] + r.stderr[-1500:]
+    if tmp is not None:
+        dumps = os.listdir(tmp.name)
+        assert any(f.endswith(".bin") and os.path.getsize(os.path.join(tmp.name, f)) > 0 for f in dumps), dumps
+        tmp.cleanup()
 
 
 def assert_models_equal_nan_tolerant(a, b, what=""):
