@@ -159,6 +159,14 @@ int sm_clean_points(sm_ctx *s, const uint16_t *depth_mm, const uint8_t *semantic
  * but the "surfel id 0 never conflicts" rule (conflict.geom:15) applies only where exempt_first != 0 -- i.e. on the rank
  * whose slice holds the first surfel of the single GlobalModel; the other slices have no id 0. */
 int sm_clean_points_ex(sm_ctx *s, const uint16_t *depth_mm, const uint8_t *semantic, const float *pose16, int exempt_first);
+/* The same for rigs that stage the exchange outside the core (surfelmapping_amd/dist.py RigMapper.consolidate): between the
+ * conflict test -- which changes nothing -- and the cull, `fn` is called with this slice's conflict count and returns how many
+ * of them, in surfel order, may take effect: the slice's share of the union's W*H conflict records (src/GlobalModel.cpp:54-57),
+ * i.e. W*H minus the conflicts of the slices before it, clamped; a negative return abandons the cull (the model is untouched)
+ * and is passed on as the result. */
+typedef long long (*sm_cap_fn)(void *user, uint32_t local_conflicts);
+int sm_clean_points_cb(sm_ctx *s, const uint16_t *depth_mm, const uint8_t *semantic, const float *pose16, int exempt_first,
+                       sm_cap_fn fn, void *user);
 /* SurfelMapping::reset (src/SurfelMapping.cpp:436-441): empties the model and sets tick = 0; the next processFrame
  * builds the model anew from that frame's raw cloud (GlobalModel::initialize), discarding anything uploaded in between.
  * The index map is left as the last predictIndices drew it. */
@@ -235,7 +243,7 @@ int sm_export_model_device(sm_ctx *s, void **d_aos, uint32_t *n);
 int sm_append_model_aos_device(sm_ctx *s, const float *d_src12, uint32_t n);
 /* raw device pointer of the 64-bit depth|id key map (W*H, column-major) for the multi-GPU
  * min-reduction, and the entry points that bracket it */
-void *sm_key_map_device_ptr(sm_ctx *s);
+void *sm_key_map_device_ptr(sm_ctx *s);   /* (launches a held-back association first; valid until the next frame call on `s`) */
 /* per-pixel "fused by this rank" ballot words (ceil(W*H/64) x u64): sum-reduced over the ranks */
 void *sm_fused_mask_device_ptr(sm_ctx *s, uint32_t *nwords);
 int sm_device_download(sm_ctx *s, void *dst_host, const void *src_device, size_t bytes);
@@ -274,9 +282,11 @@ int sm_gpu_process_count(sm_ctx *s);
  * by sm_shard_rccl_init, or any callback with the same meaning (tests: several contexts on one GPU).  All ranks hold
  * the same counters (sm_get_counts) after every frame.  Replaces the per-stage calls above and the Python loop over
  * them (surfelmapping_amd/sharded.py) for production use; results are bit-identical to the single-GPU path. */
-enum { SM_COLL_SUM = 0, SM_COLL_MIN = 1 };
-/* all-reduce `count` unsigned 64-bit words from `send` to `recv` (may be equal; device memory of this context) over the
- * ranks, enqueued on `hip_stream`; returns 0 on success */
+enum { SM_COLL_SUM = 0, SM_COLL_MIN = 1, SM_COLL_GATHER = 2 };
+/* SUM / MIN: all-reduce `count` unsigned 64-bit words from `send` to `recv` (may be equal; device memory of this context) over
+ * the ranks.  GATHER: all-gather -- every rank contributes `count` words at `send`, `recv` receives world * count words, rank q's
+ * at recv + q * count (in place when send == recv + rank * count, as ncclAllGather).  Enqueued on `hip_stream`; returns 0 on
+ * success */
 typedef int (*sm_collective_fn)(void *user, const void *send, void *recv, size_t count, int op, void *hip_stream);
 /* on a new context (no frame yet); allocates the second surfel set the sharded compaction stages through */
 int sm_shard_stream_configure(sm_ctx *s, int rank, int world);
@@ -286,6 +296,8 @@ int sm_shard_set_collective(sm_ctx *s, sm_collective_fn fn, void *user);
 int sm_shard_rccl_unique_id(void *out128);
 int sm_shard_rccl_init(sm_ctx *s, const void *id128);
 int sm_shard_rccl_finalize(sm_ctx *s);
+/* ranks of the context's RCCL communicator as RCCL itself reports them (ncclCommCount), or a negative SM_E_* */
+int sm_shard_rccl_nranks(sm_ctx *s);
 /* SurfelMapping::processFrame (src/SurfelMapping.cpp:115-251) on every rank with the same arguments; the _device form
  * takes device pointers and only enqueues (sm_sync to wait) */
 int sm_shard_frame_device(sm_ctx *s, const uint8_t *d_rgb, const uint16_t *d_depth_mm, const uint8_t *d_semantic, const float *pose16);
@@ -302,8 +314,11 @@ int sm_shard_export_dense_device(sm_ctx *s, const float **d_out12, uint32_t *cou
  * SurfelMapping::cleanPoints (src/SurfelMapping.cpp:496-532), each rank cleaning its own slice, and the cleaned slices are
  * appended in rank order to `global` (another context on the same GPU) on every rank.  The collective is the one installed
  * with sm_shard_rccl_init / sm_shard_set_collective after sm_rig_configure (world 1: none needed).
- * view_conflicts[world] (may be null): conflicts per view over all slices; a view with more conflicts than pixels fails with
- * SM_E_UNSUPPORTED (the reference's conflict cap acts in global surfel order). */
+ * view_conflicts[world] (may be null): conflicts that took effect per view over all slices.  The reference's conflict cap -- at
+ * most W*H conflicts per view, in the surfel order of the union (src/GlobalModel.cpp:54-57) -- is applied exactly: between a
+ * view's conflict test and its cull the ranks exchange their conflict counts and every slice applies what the lower ranks
+ * left of the W*H.  Views, counts and slices cross the ranks as all-gathers; every exchange carries a status word, so a rank
+ * whose local step fails makes ALL ranks return an error together (nobody is left waiting inside a collective). */
 int sm_rig_configure(sm_ctx *s, int rank, int world);
 int sm_rig_consolidate(sm_ctx *s, const uint16_t *depth_mm, const uint8_t *semantic, const float *pose16, sm_ctx *global,
                        uint32_t *view_conflicts, uint32_t *total);

@@ -67,6 +67,7 @@ struct smo_ctx {
     int ref_set;
     float curr_pose[16], last_pose[16];
     int32_t exempt_id;        /* surfel that never fuses / conflicts: id 0 (A5); shard tests move it */
+    int64_t conflict_limit;   /* < 0: the config's rule (W*H records or none); >= 0: this many records (a rig slice's share, tests/test_rig.py) */
     int32_t *data_pix;        /* column-major pixel index of every dataVbo record */
 #ifdef _OPENMP
     uint8_t *omp_flag; uint32_t omp_flag_cap;   /* per-surfel flags of the parallel passes */
@@ -331,6 +332,7 @@ smo_ctx *smo_create(const smo_config *c)
     s->unstable = xcalloc(P * SURFEL_F, 4);
     s->conflict = xcalloc(P * 5, 4);
     s->conflict_cap = (uint32_t)P;
+    s->conflict_limit = -1;
     s->idx = xcalloc(P, 4); s->zbuf = xcalloc(P, 4);
     s->data_pix = xcalloc(P, 4);
     for (size_t q = 0; q < P; ++q) s->zbuf[q] = 16777215u;
@@ -575,6 +577,7 @@ int smo_stage_process_conflict(smo_ctx *s, const float *pose, float min_depth, f
     float t_inv[16];
     smo_invert4(pose, t_inv);
     uint32_t cap = c->conflict_cap ? (uint32_t)s->P : s->count;
+    if (s->conflict_limit >= 0) cap = (uint32_t)(s->conflict_limit > (int64_t)s->count ? (int64_t)s->count : s->conflict_limit);
     if (cap > s->conflict_cap) {
         s->conflict = realloc(s->conflict, (size_t)cap * 5 * 4);
         if (!s->conflict) abort();
@@ -1369,6 +1372,33 @@ int smo_set_exempt_id(smo_ctx *s, int32_t id)
 {
     if (!s) return SMO_E_ARG;
     s->exempt_id = id;
+    return SMO_OK;
+}
+
+/* A rig slice's share of the union's W*H conflict records (src/GlobalModel.cpp:54-57: the buffer is filled in the surfel
+ * order of the single GlobalModel, i.e. slice after slice): the next conflict passes record at most `limit` conflicts.
+ * limit < 0 restores the config's rule. */
+int smo_set_conflict_limit(smo_ctx *s, int64_t limit)
+{
+    if (!s) return SMO_E_ARG;
+    s->conflict_limit = limit;
+    return SMO_OK;
+}
+
+/* The conflict test of SurfelMapping::cleanPoints (src/SurfelMapping.cpp:496-532: p0a + processConflict with the clean-mode
+ * parameters) WITHOUT the record limit and without applying anything (no updateConflict / backMapping): how many surfels of
+ * this model the view contradicts. */
+int smo_count_clean_conflicts(smo_ctx *s, const uint16_t *depth_mm, const uint8_t *sem, const float *pose, uint32_t *n)
+{
+    if (!s || !depth_mm || !sem || !pose || !n) return SMO_E_ARG;
+    memcpy(s->depth_raw, depth_mm, (size_t)s->P * 2);
+    memcpy(s->sem, sem, (size_t)s->P);
+    smo_metricise(&s->c, s->depth_raw, s->depth_metric);
+    const int64_t keep = s->conflict_limit;
+    s->conflict_limit = (int64_t)s->count;
+    smo_stage_process_conflict(s, pose, s->c.near_clip, s->c.far_clip - 15.0f, 0.1f, 1);
+    s->conflict_limit = keep;
+    *n = s->conflict_count;
     return SMO_OK;
 }
 

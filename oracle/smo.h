@@ -113,6 +113,8 @@ int smo_render_image(const smo_ctx *s, const float *view, int w, int h, float fx
 
 /* ---- helpers for the multi-GPU shard tests: one oracle instance plays one rank ---- */
 int smo_set_exempt_id(smo_ctx *s, int32_t id);
+int smo_set_conflict_limit(smo_ctx *s, int64_t limit);   /* a rig slice's share of the W*H conflict records; < 0: the config's rule */
+int smo_count_clean_conflicts(smo_ctx *s, const uint16_t *depth_mm, const uint8_t *sem, const float *pose, uint32_t *n);
 int smo_download_zbuf(const smo_ctx *s, uint32_t *dst);
 int smo_upload_index_ids(smo_ctx *s, const int32_t *idx, const uint8_t *has);
 int smo_download_data_pixels(const smo_ctx *s, int32_t *dst, uint32_t cap, uint32_t *n);

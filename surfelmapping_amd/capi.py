@@ -19,7 +19,7 @@ TEX_DEPTH_METRIC, TEX_DEPTH_FILTERED, TEX_LAST = 0, 1, 2
 # every extern "C" symbol include/sm_c_api.h declares
 SYMBOLS = (
     "sm_api_version", "sm_last_error", "sm_default_config", "sm_create", "sm_destroy",
-    "sm_process_frame", "sm_process_frame_device", "sm_sync", "sm_clean_points", "sm_clean_points_ex", "sm_reset",
+    "sm_process_frame", "sm_process_frame_device", "sm_sync", "sm_clean_points", "sm_clean_points_ex", "sm_clean_points_cb", "sm_reset",
     "sm_get_counts", "sm_download_model_aos", "sm_upload_model_aos", "sm_save_map", "sm_load_map",
     "sm_download_index_map", "sm_download_raw_cloud", "sm_download_depth", "sm_render_image", "sm_set_frame", "sm_set_tick",
     "sm_stage_conflict", "sm_stage_cull", "sm_stage_splat", "sm_stage_associate_fuse",
@@ -28,13 +28,15 @@ SYMBOLS = (
     "sm_fused_mask_device_ptr", "sm_device_download", "sm_shard_configure", "sm_shard_begin_frame",
     "sm_shard_conflict", "sm_shard_cull_splat", "sm_shard_associate", "sm_shard_append",
     "sm_shard_stream_configure", "sm_shard_set_collective", "sm_shard_rccl_unique_id", "sm_shard_rccl_init",
-    "sm_shard_rccl_finalize", "sm_shard_frame_device", "sm_shard_frame", "sm_shard_compact", "sm_shard_export_dense_device",
+    "sm_shard_rccl_finalize", "sm_shard_rccl_nranks", "sm_shard_frame_device", "sm_shard_frame", "sm_shard_compact", "sm_shard_export_dense_device",
     "sm_gpu_process_count", "sm_rig_configure", "sm_rig_consolidate",
 )
 
-SM_COLL_SUM, SM_COLL_MIN = 0, 1
+SM_COLL_SUM, SM_COLL_MIN, SM_COLL_GATHER = 0, 1, 2
 # int fn(void *user, const void *send, void *recv, size_t count_u64, int op, void *hip_stream)
 COLLECTIVE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p)
+# long long fn(void *user, uint32_t local_conflicts)
+CAP_FN = C.CFUNCTYPE(C.c_longlong, C.c_void_p, C.c_uint32)
 
 
 class SmConfig(C.Structure):
@@ -167,6 +169,7 @@ def load():
     L.sm_sync.argtypes = [vp]
     L.sm_clean_points.argtypes = [vp, vp, vp, vp]
     L.sm_clean_points_ex.argtypes = [vp, vp, vp, vp, C.c_int]
+    L.sm_clean_points_cb.argtypes = [vp, vp, vp, vp, C.c_int, CAP_FN, vp]
     L.sm_reset.argtypes = [vp]
     L.sm_get_counts.argtypes = [vp, C.POINTER(SmCounts)]
     L.sm_download_model_aos.argtypes = [vp, vp, C.c_uint32, u32p]
@@ -205,6 +208,7 @@ def load():
     L.sm_shard_rccl_unique_id.argtypes = [vp]
     L.sm_shard_rccl_init.argtypes = [vp, vp]
     L.sm_shard_rccl_finalize.argtypes = [vp]
+    L.sm_shard_rccl_nranks.argtypes = [vp]
     L.sm_shard_frame_device.argtypes = [vp, vp, vp, vp, vp]
     L.sm_shard_frame.argtypes = [vp, vp, vp, vp, vp]
     L.sm_shard_compact.argtypes = [vp]
@@ -286,12 +290,29 @@ class SurfelMap:
         pose = np.ascontiguousarray(pose, np.float32)
         self._chk(self._L.sm_clean_points(self._h, _ptr(depth), _ptr(sem), _ptr(pose)), "sm_clean_points")
 
-    def clean_points_slice(self, depth, sem, pose, exempt_first: bool):
-        """cleanPoints on a rig slice (surfelmapping_amd/dist.py): the id-0 exemption only where the slice holds the global surfel 0"""
+    def clean_points_slice(self, depth, sem, pose, exempt_first: bool, cap_hook=None):
+        """cleanPoints on a rig slice (surfelmapping_amd/dist.py): the id-0 exemption only where the slice holds the global surfel
+        0; cap_hook(local_conflicts) -> how many of them may take effect (the slice's share of the union's W*H conflict
+        records), called between the conflict test and the cull"""
         depth = np.ascontiguousarray(depth, np.uint16)
         sem = np.ascontiguousarray(sem, np.uint8)
         pose = np.ascontiguousarray(pose, np.float32)
-        self._chk(self._L.sm_clean_points_ex(self._h, _ptr(depth), _ptr(sem), _ptr(pose), 1 if exempt_first else 0), "sm_clean_points_ex")
+        if cap_hook is None:
+            self._chk(self._L.sm_clean_points_ex(self._h, _ptr(depth), _ptr(sem), _ptr(pose), 1 if exempt_first else 0), "sm_clean_points_ex")
+            return
+        err = []
+
+        def tramp(user, local):
+            try:
+                return int(cap_hook(int(local)))
+            except Exception as e:                       # never let an exception cross the C frame
+                err.append(e)
+                return SM_E_HIP
+        cb = CAP_FN(tramp)
+        rc = self._L.sm_clean_points_cb(self._h, _ptr(depth), _ptr(sem), _ptr(pose), 1 if exempt_first else 0, cb, None)
+        if err:
+            raise err[0]
+        self._chk(rc, "sm_clean_points_cb")
 
     def reset(self):
         self._chk(self._L.sm_reset(self._h), "sm_reset")
@@ -481,6 +502,13 @@ class SurfelMap:
         _choose_rccl()
         buf = C.create_string_buffer(bytes(unique_id), 128)
         self._chk(self._L.sm_shard_rccl_init(self._h, buf), "sm_shard_rccl_init")
+
+    def shard_rccl_nranks(self) -> int:
+        """ranks of this context's RCCL communicator, as RCCL reports them"""
+        n = self._L.sm_shard_rccl_nranks(self._h)
+        if n < 0:
+            raise SurfelMapError("sm_shard_rccl_nranks", n, self._L.sm_last_error().decode())
+        return n
 
     def shard_rccl_finalize(self):
         self._chk(self._L.sm_shard_rccl_finalize(self._h), "sm_shard_rccl_finalize")

@@ -19,6 +19,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <atomic>
+#include <functional>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -594,7 +595,8 @@ int mark(sm_ctx *s, int which, bool timed)
     return SM_OK;
 }
 
-int launch_conflict(sm_ctx *s, const FrameParams &fp, bool timed = false, bool fold_finalize = false)
+// p2: the conflict test alone (masks, per-tile counts, per-workgroup partial sums); nothing of the model changes
+int launch_conflict_test(sm_ctx *s, const FrameParams &fp, bool timed = false)
 {
     if (finalize_if_pending(s)) return SM_E_HIP;
     s->n_conf_part = (uint32_t)grid_surfels(s);
@@ -603,10 +605,12 @@ int launch_conflict(sm_ctx *s, const FrameParams &fp, bool timed = false, bool f
                        s->d_conf_sub + SUB_SET * s->conf_sub_set);
     HIPCK(hipGetLastError());
     if (mark(s, 2, timed)) return SM_E_HIP;
-    if (fold_finalize) {            // k_cull_lazy_frame does the finalize step itself
-        if (mark(s, 3, timed)) return SM_E_HIP;
-        return SM_OK;
-    }
+    return SM_OK;
+}
+
+// the scan / finalize step of a cull that does not fold it into the cull kernel: applies the conflict cap of `fp`
+int launch_conflict_finalize(sm_ctx *s, const FrameParams &fp, bool timed = false)
+{
     if (fp.compact_now) {
         // this cull compacts: the survivor prefixes are needed, scan them with one workgroup per 1024 tiles.
         // A cull that only marks the dead gets its totals from k_conflict's partial sums in the finalize kernel.
@@ -621,6 +625,17 @@ int launch_conflict(sm_ctx *s, const FrameParams &fp, bool timed = false, bool f
     HIPCK(hipGetLastError());
     if (mark(s, 3, timed)) return SM_E_HIP;
     return SM_OK;
+}
+
+int launch_conflict(sm_ctx *s, const FrameParams &fp, bool timed = false, bool fold_finalize = false)
+{
+    int rc = launch_conflict_test(s, fp, timed);
+    if (rc) return rc;
+    if (fold_finalize) {            // k_cull_lazy_frame does the finalize step itself
+        if (mark(s, 3, timed)) return SM_E_HIP;
+        return SM_OK;
+    }
+    return launch_conflict_finalize(s, fp, timed);
 }
 
 // the cull of a frame that only marks the dead, with the finalize step folded in (frame path): `grid` workers + 1 publisher
@@ -686,7 +701,7 @@ int launch_surfel_pass(sm_ctx *s, const FrameParams &fp, bool timed, bool direct
     s->pend_finalize = false;            // the fixup's publisher completes the previous frame's statistics first
     hipLaunchKernelGGL(k_pass_fixup, dim3(fgrid + 1), dim3(256), 0, s->stream, s->M, s->d_state, fp, s->d_cm, s->d_dm /* km */, s->d_wave_cnt,
                        s->d_tile_flags, s->d_lazy_part, (uint32_t)grid, fix_cur, s->d_alive, s->d_tile_dead, sub, s->d_keyT, s->d_undo,
-                       s->d_stat, s->d_prep_part, ready ? s->n_prep_blocks : 0u, da);
+                       s->d_stat, s->d_prep_part, ready ? s->n_prep_blocks : 0u, da, s->d_tb);
     HIPCK(hipGetLastError());
     if (mark(s, 4, timed)) return SM_E_HIP;
     return SM_OK;
@@ -1412,6 +1427,7 @@ void sm_destroy(sm_ctx *s)
     (void)hipSetDevice(s->cfg.device);
     if (s->stream2) (void)hipStreamSynchronize(s->stream2);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
+    if (s->ss_comm) (void)sm_shard_rccl_finalize(s);         // a communicator the caller did not finalize
     if (s->d_pass_trace) {
         // SM_PASS_TRACE=<prefix>: the last k_surfel_pass launch's per-workgroup record (wall_clock64 at entry / first tile /
         // after it / exit, that tile, its compacted entries, XCC | HW_ID, tiles) -> <prefix>.<n>.bin (tools/pass_trace.py)
@@ -1505,8 +1521,12 @@ int sm_clean_points(sm_ctx *s, const uint16_t *depth_mm, const uint8_t *semantic
 
 namespace {
 // SurfelMapping::cleanPoints with the view already in device memory (sm_clean_points_ex uploads it; sm_rig_consolidate
-// takes it from the gathered views of the rig)
-int clean_points_device(sm_ctx *s, const uint16_t *d_depth_mm, const uint8_t *d_semantic, const float *pose16, int exempt_first)
+// takes it from the gathered views of the rig).  `cap_hook`, if given, runs between the conflict test (which changes nothing)
+// and the cull: it receives this model's conflict count and returns the number of them that may take effect, in surfel order
+// (src/GlobalModel.cpp:54-57: conflictVbo holds W*H records) -- a rig slice learns its share of the union's W*H there -- or a
+// negative error code, which abandons the cull with the model untouched.
+int clean_points_device(sm_ctx *s, const uint16_t *d_depth_mm, const uint8_t *d_semantic, const float *pose16, int exempt_first,
+                        const std::function<long long(uint32_t)> *cap_hook = nullptr)
 {
     if (s->pending_cull) { g_err = "sm_stage_conflict without sm_stage_cull"; return SM_E_ARG; }
     // cleanPoints culls without redrawing the index map (src/SurfelMapping.cpp:496-532): the map keeps ids of the model
@@ -1521,8 +1541,19 @@ int clean_points_device(sm_ctx *s, const uint16_t *d_depth_mm, const uint8_t *d_
     fp.is_clean = 1;                            // :517
     fp.no_exempt = exempt_first ? 0 : 1;
     fp.compact_now = decide_compact(s) ? 1u : 0u;
+    if ((rc = launch_conflict_test(s, fp))) return rc;
+    if (cap_hook) {
+        std::vector<uint32_t> part((size_t)s->n_conf_part * 4);
+        HIPCK(hipMemcpyAsync(part.data(), s->d_conf_part, part.size() * 4, hipMemcpyDeviceToHost, s->stream));
+        HIPCK(hipStreamSynchronize(s->stream));
+        uint64_t local = 0;
+        for (uint32_t b = 0; b < s->n_conf_part; ++b) local += part[(size_t)b * 4 + 1];
+        const long long allow = (*cap_hook)((uint32_t)local);
+        if (allow < 0) return (int)allow;
+        fp.conflict_cap = (uint32_t)std::min<long long>(allow, 0xFFFFFFFFll);
+    }
     note_cull(s, fp.compact_now != 0u);
-    if ((rc = launch_conflict(s, fp))) return rc;
+    if ((rc = launch_conflict_finalize(s, fp))) return rc;
     if ((rc = launch_compact(s, fp, false, false))) return rc;
     if ((rc = launch_post_fill(s))) return rc;
     return sm_sync(s);
@@ -1540,6 +1571,20 @@ int sm_clean_points_ex(sm_ctx *s, const uint16_t *depth_mm, const uint8_t *seman
     if (rc) return rc;
     if ((rc = upload_inputs(s, nullptr, depth_mm, semantic))) return rc;
     return clean_points_device(s, s->d_depth_raw, s->d_sem, pose16, exempt_first);
+}
+
+int sm_clean_points_cb(sm_ctx *s, const uint16_t *depth_mm, const uint8_t *semantic, const float *pose16, int exempt_first,
+                       sm_cap_fn fn, void *user)
+{
+    if (!s || !depth_mm || !semantic || !pose16) { g_err = "sm_clean_points: null argument"; return SM_E_ARG; }
+    HIPCK(hipSetDevice(s->cfg.device));
+    if (s->pending_cull) { g_err = "sm_stage_conflict without sm_stage_cull"; return SM_E_ARG; }
+    int rc = finalize_if_pending(s);
+    if (rc) return rc;
+    if ((rc = upload_inputs(s, nullptr, depth_mm, semantic))) return rc;
+    if (!fn) return clean_points_device(s, s->d_depth_raw, s->d_sem, pose16, exempt_first);
+    const std::function<long long(uint32_t)> hook = [&](uint32_t local) { return fn(user, local); };
+    return clean_points_device(s, s->d_depth_raw, s->d_sem, pose16, exempt_first, &hook);
 }
 
 int sm_reset(sm_ctx *s)
@@ -2030,11 +2075,20 @@ int sm_append_model_aos_device(sm_ctx *s, const float *d_src12, uint32_t n)
     return pull_state(s);
 }
 
-void *sm_key_map_device_ptr(sm_ctx *s) { return (s && !hip_runtime_conflict("sm_key_map_device_ptr")) ? (void *)s->d_keyT : nullptr; }
+// (a held-back association is launched first: the map the caller reads through the pointer is the one the last frame call
+//  drew and associated; the pointer is valid until the next frame call -- the two key maps alternate -- and the caller orders
+//  its reads after the context's stream, e.g. with sm_sync)
+void *sm_key_map_device_ptr(sm_ctx *s)
+{
+    if (!s || hip_runtime_conflict("sm_key_map_device_ptr")) return nullptr;
+    if (hipSetDevice(s->cfg.device) != hipSuccess || finalize_if_pending(s)) return nullptr;
+    return (void *)s->d_keyT;
+}
 
 void *sm_fused_mask_device_ptr(sm_ctx *s, uint32_t *nwords)
 {
     if (!s) return nullptr;
+    if (hipSetDevice(s->cfg.device) != hipSuccess || finalize_if_pending(s)) return nullptr;
     if (nwords) *nwords = (uint32_t)((s->P + 63) / 64);
     return (void *)s->d_fusedmask;
 }
@@ -2170,6 +2224,8 @@ struct RcclApi {
     ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
 };
@@ -2202,9 +2258,11 @@ int load_rccl()
     g_rccl.GetUniqueId = reinterpret_cast<decltype(g_rccl.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
     g_rccl.CommInitRank = reinterpret_cast<decltype(g_rccl.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
     g_rccl.AllReduce = reinterpret_cast<decltype(g_rccl.AllReduce)>(dlsym(h, "ncclAllReduce"));
+    g_rccl.AllGather = reinterpret_cast<decltype(g_rccl.AllGather)>(dlsym(h, "ncclAllGather"));
+    g_rccl.CommCount = reinterpret_cast<decltype(g_rccl.CommCount)>(dlsym(h, "ncclCommCount"));
     g_rccl.CommDestroy = reinterpret_cast<decltype(g_rccl.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
     g_rccl.GetErrorString = reinterpret_cast<decltype(g_rccl.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
-    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.CommDestroy) {
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.AllGather || !g_rccl.CommCount || !g_rccl.CommDestroy) {
         g_err = "RCCL: missing symbols in " + (loaded.empty() ? std::string("librccl.so") : loaded);
         return SM_E_UNSUPPORTED;
     }
@@ -2215,16 +2273,21 @@ int load_rccl()
 int rccl_collective(void *user, const void *send, void *recv, size_t count, int op, void *stream)
 {
     sm_ctx *s = static_cast<sm_ctx *>(user);
-    const ncclResult_t r = g_rccl.AllReduce(send, recv, count, ncclUint64, op == SM_COLL_MIN ? ncclMin : ncclSum,
-                                            static_cast<ncclComm_t>(s->ss_comm), static_cast<hipStream_t>(stream));
-    if (r != ncclSuccess) { g_err = std::string("ncclAllReduce: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "failed"); return SM_E_HIP; }
+    const ncclResult_t r = op == SM_COLL_GATHER
+        ? g_rccl.AllGather(send, recv, count, ncclUint64, static_cast<ncclComm_t>(s->ss_comm), static_cast<hipStream_t>(stream))
+        : g_rccl.AllReduce(send, recv, count, ncclUint64, op == SM_COLL_MIN ? ncclMin : ncclSum,
+                           static_cast<ncclComm_t>(s->ss_comm), static_cast<hipStream_t>(stream));
+    if (r != ncclSuccess) {
+        g_err = std::string(op == SM_COLL_GATHER ? "ncclAllGather: " : "ncclAllReduce: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "failed");
+        return SM_E_HIP;
+    }
     return SM_OK;
 }
 
 int ss_collective(sm_ctx *s, const void *send, void *recv, size_t count, int op)
 {
     if (!s->ss_coll) {
-        if (s->ss_world == 1) {          // one rank and no communicator: the reduction is the identity
+        if (s->ss_world == 1) {          // one rank and no communicator: reduction and gather are the identity
             if (send != recv) HIPCK(hipMemcpyAsync(recv, send, count * 8, hipMemcpyDeviceToDevice, s->stream));
             return SM_OK;
         }
@@ -2332,6 +2395,16 @@ int sm_shard_rccl_init(sm_ctx *s, const void *id128)
     s->ss_comm = comm;
     s->ss_coll = rccl_collective; s->ss_user = s;
     return SM_OK;
+}
+
+int sm_shard_rccl_nranks(sm_ctx *s)
+{
+    if (!s) return SM_E_ARG;
+    if (!s->ss_comm || !g_rccl.CommCount) { g_err = "sm_shard_rccl_nranks: no RCCL communicator on this context"; return SM_E_ARG; }
+    int n = 0;
+    const ncclResult_t r = g_rccl.CommCount(static_cast<ncclComm_t>(s->ss_comm), &n);
+    if (r != ncclSuccess) { g_err = "ncclCommCount failed"; return SM_E_HIP; }
+    return n;
 }
 
 int sm_shard_rccl_finalize(sm_ctx *s)
@@ -2468,6 +2541,35 @@ int sm_rig_configure(sm_ctx *s, int rank, int world)
     return SM_OK;
 }
 
+namespace {
+// The exchanges of a rig consolidation.  Every rank contributes a row of four words -- live surfels of its slice, conflicts of
+// the view at hand, a status word, a spare -- through an all-gather, so that (a) all ranks see all counts and (b) a rank whose
+// LOCAL step failed says so in the very exchange the others are waiting in: everybody then leaves together with an error
+// instead of one rank returning early and the rest blocking inside RCCL.
+struct RigXchg {
+    sm_ctx *s; int W, r;
+    unsigned long long *d_cnt = nullptr;            // [W][4]
+    std::vector<unsigned long long> h;
+    RigXchg(sm_ctx *s_, int W_, int r_) : s(s_), W(W_), r(r_), h((size_t)W_ * 4) {}
+    // returns 0, this rank's own failure code, or SM_E_HIP when another rank failed
+    int run(unsigned long long count, unsigned long long conflicts, int status)
+    {
+        unsigned long long row[4] = {count, conflicts, (unsigned long long)(long long)status, 0ull};
+        if (hipMemcpyAsync(d_cnt + (size_t)r * 4, row, 32, hipMemcpyHostToDevice, s->stream) != hipSuccess) return SM_E_HIP;
+        int rc = ss_collective(s, d_cnt + (size_t)r * 4, d_cnt, 4, SM_COLL_GATHER);
+        if (rc) return rc;
+        if (hipMemcpyAsync(h.data(), d_cnt, 32 * (size_t)W, hipMemcpyDeviceToHost, s->stream) != hipSuccess) return SM_E_HIP;
+        if (hipStreamSynchronize(s->stream) != hipSuccess) return SM_E_HIP;
+        if (status) return status;
+        for (int q = 0; q < W; ++q)
+            if (h[(size_t)q * 4 + 2]) { g_err = "sm_rig_consolidate: rank " + std::to_string(q) + " failed (code " + std::to_string((long long)h[(size_t)q * 4 + 2]) + "); all ranks abandon the consolidation"; return SM_E_HIP; }
+        return SM_OK;
+    }
+    unsigned long long count(int q) const { return h[(size_t)q * 4]; }
+    unsigned long long conflicts(int q) const { return h[(size_t)q * 4 + 1]; }
+};
+}  // namespace
+
 int sm_rig_consolidate(sm_ctx *s, const uint16_t *depth_mm, const uint8_t *semantic, const float *pose16, sm_ctx *global,
                        uint32_t *view_conflicts, uint32_t *total_out)
 {
@@ -2477,74 +2579,78 @@ int sm_rig_consolidate(sm_ctx *s, const uint16_t *depth_mm, const uint8_t *seman
     const int W = s->ss_world, r = s->ss_rank;
     const size_t P = (size_t)s->P;
     const size_t off_sem = 2 * P, off_pose = (3 * P + 7) / 8 * 8, row = off_pose + 64;        // bytes of one view (a multiple of 8)
-    int rc = finalize_if_pending(s);
-    if (rc) return rc;
     uint8_t *d_views = nullptr;
-    unsigned long long *d_cnt = nullptr;
-    HIPCK(hipMalloc((void **)&d_views, row * (size_t)W));
-    HIPCK(hipMalloc((void **)&d_cnt, 8 * (size_t)(W + 1)));
-    auto fail = [&](int code) { (void)hipFree(d_views); (void)hipFree(d_cnt); return code; };
-    // 1. every rank learns every camera's latest view
-    if (hipMemsetAsync(d_views, 0, row * (size_t)W, s->stream) != hipSuccess ||
-        hipMemcpyAsync(d_views + row * r, depth_mm, 2 * P, hipMemcpyHostToDevice, s->stream) != hipSuccess ||
-        hipMemcpyAsync(d_views + row * r + off_sem, semantic, P, hipMemcpyHostToDevice, s->stream) != hipSuccess ||
-        hipMemcpyAsync(d_views + row * r + off_pose, pose16, 64, hipMemcpyHostToDevice, s->stream) != hipSuccess) { g_err = "sm_rig_consolidate: staging the view failed"; return fail(SM_E_HIP); }
-    if ((rc = ss_collective(s, d_views, d_views, row * (size_t)W / 8, SM_COLL_SUM))) return fail(rc);
-    std::vector<float> poses((size_t)W * 16);
-    for (int v = 0; v < W; ++v)
-        if (hipMemcpyAsync(&poses[(size_t)v * 16], d_views + row * v + off_pose, 64, hipMemcpyDeviceToHost, s->stream) != hipSuccess) return fail(SM_E_HIP);
-    if (hipStreamSynchronize(s->stream) != hipSuccess) return fail(SM_E_HIP);
-    // slice sizes of all ranks (own count at index rank, summed)
-    std::vector<unsigned long long> h_cnt((size_t)W + 1);
-    auto exchange_counts = [&](unsigned long long extra) -> int {
-        int rcx = pull_state(s);
-        if (rcx) return rcx;
-        std::fill(h_cnt.begin(), h_cnt.end(), 0ull);
-        h_cnt[(size_t)r] = s->counts.count;
-        h_cnt[(size_t)W] = extra;
-        if (hipMemcpyAsync(d_cnt, h_cnt.data(), 8 * (size_t)(W + 1), hipMemcpyHostToDevice, s->stream) != hipSuccess) return SM_E_HIP;
-        if ((rcx = ss_collective(s, d_cnt, d_cnt, (size_t)W + 1, SM_COLL_SUM))) return rcx;
-        if (hipMemcpyAsync(h_cnt.data(), d_cnt, 8 * (size_t)(W + 1), hipMemcpyDeviceToHost, s->stream) != hipSuccess) return SM_E_HIP;
-        return hipStreamSynchronize(s->stream) == hipSuccess ? SM_OK : SM_E_HIP;
-    };
-    // 2. the union cleaned against every view, in rank order: each rank cleans ITS slice (the test is per surfel and view)
-    for (int v = 0; v < W; ++v) {
-        if ((rc = exchange_counts(0ull))) return fail(rc);
-        int first = -1;
-        for (int q = 0; q < W && first < 0; ++q) if (h_cnt[(size_t)q] > 0) first = q;
-        // surfel id 0 never conflicts (conflict.geom:15): the exemption belongs to the rank that holds the union's first surfel
-        if ((rc = clean_points_device(s, reinterpret_cast<const uint16_t *>(d_views + row * v), d_views + row * v + off_sem,
-                                      &poses[(size_t)v * 16], first == r ? 1 : 0))) return fail(rc);
-        if ((rc = exchange_counts(s->counts.conflict_count))) return fail(rc);
-        const unsigned long long conf = h_cnt[(size_t)W];
-        if (view_conflicts) view_conflicts[v] = (uint32_t)conf;
-        // at most W*H conflicts take effect per view, in global surfel order (src/GlobalModel.cpp:54-57): not reproducible per slice
-        if (s->cfg.conflict_cap && conf > (unsigned long long)s->P) {
-            g_err = "sm_rig_consolidate: a view has more conflicts than pixels over all slices: the reference's conflict cap would truncate them in "
-                    "global surfel order";
-            return fail(SM_E_UNSUPPORTED);
-        }
+    float *d_union = nullptr;
+    RigXchg x(s, W, r);
+    auto done = [&](int code) { (void)hipFree(d_views); (void)hipFree(d_union); (void)hipFree(x.d_cnt); return code; };
+    // the exchange buffer first: without it this rank cannot even tell the others that it failed
+    HIPCK(hipMalloc((void **)&x.d_cnt, 32 * (size_t)W));
+    // ---- local, fallible: settle the stream's pending work, stage this camera's latest view
+    int st = finalize_if_pending(s);
+    if (!st) st = pull_state(s);
+    if (!st && hipMalloc((void **)&d_views, row * (size_t)W) != hipSuccess) { g_err = "sm_rig_consolidate: out of device memory for the views"; st = SM_E_HIP; }
+    if (!st && (hipMemsetAsync(d_views + row * r, 0, row, s->stream) != hipSuccess ||
+                hipMemcpyAsync(d_views + row * r, depth_mm, 2 * P, hipMemcpyHostToDevice, s->stream) != hipSuccess ||
+                hipMemcpyAsync(d_views + row * r + off_sem, semantic, P, hipMemcpyHostToDevice, s->stream) != hipSuccess ||
+                hipMemcpyAsync(d_views + row * r + off_pose, pose16, 64, hipMemcpyHostToDevice, s->stream) != hipSuccess)) {
+        g_err = "sm_rig_consolidate: staging the view failed"; st = SM_E_HIP;
     }
-    // 3. the cleaned slices, concatenated in rank order, appended to `global` on every rank
-    unsigned long long T = 0, base = 0;
-    for (int q = 0; q < W; ++q) { if (q < r) base += h_cnt[(size_t)q]; T += h_cnt[(size_t)q]; }
+    int rc = x.run(st ? 0ull : s->counts.count, 0ull, st);
+    if (rc) return done(rc);
+    // ---- 1. every rank learns every camera's latest view: all-gather, in place (3 bytes per pixel and camera)
+    if ((rc = ss_collective(s, d_views + row * r, d_views, row / 8, SM_COLL_GATHER))) return done(rc);
+    std::vector<float> poses((size_t)W * 16);
+    st = SM_OK;
+    for (int v = 0; v < W && !st; ++v)
+        if (hipMemcpyAsync(&poses[(size_t)v * 16], d_views + row * v + off_pose, 64, hipMemcpyDeviceToHost, s->stream) != hipSuccess) st = SM_E_HIP;
+    if (!st && hipStreamSynchronize(s->stream) != hipSuccess) st = SM_E_HIP;
+    // ---- 2. the union cleaned against every view, in rank order: each rank cleans ITS slice (the test is per surfel and view)
+    for (int v = 0; v < W; ++v) {
+        int first = -1;
+        for (int q = 0; q < W && first < 0; ++q) if (x.count(q) > 0) first = q;
+        unsigned long long view_total = 0;
+        bool hook_ran = false;
+        // Between the conflict test and the cull the ranks exchange their conflict counts: at most W*H conflicts take effect per
+        // view, in the surfel order of the UNION (src/GlobalModel.cpp:54-57) -- slices are concatenated in rank order, so this
+        // rank's share is what the lower ranks left of the W*H, and "the first `share` conflicts of my slice" is exactly the rule
+        // the single-model cull applies with that cap.
+        const std::function<long long(uint32_t)> hook = [&](uint32_t local) -> long long {
+            hook_ran = true;
+            const int e = x.run(s->counts.count, local, SM_OK);
+            if (e) return e;
+            unsigned long long before = 0;
+            for (int q = 0; q < W; ++q) { if (q < r) before += x.conflicts(q); view_total += x.conflicts(q); }
+            if (!s->cfg.conflict_cap) return 0xFFFFFFFFll;
+            return before >= (unsigned long long)s->P ? 0ll : (long long)std::min<unsigned long long>(local, (unsigned long long)s->P - before);
+        };
+        // surfel id 0 never conflicts (conflict.geom:15): the exemption belongs to the rank that holds the union's first surfel
+        const int cl = st ? st : clean_points_device(s, reinterpret_cast<const uint16_t *>(d_views + row * v), d_views + row * v + off_sem,
+                                                     &poses[(size_t)v * 16], first == r ? 1 : 0, &hook);
+        // every rank makes both exchanges of a view whatever happened to it locally: a failure travels in the status word
+        if (!hook_ran) (void)x.run(0ull, 0ull, cl ? cl : SM_E_HIP);
+        if ((rc = x.run(s->counts.count, 0ull, cl))) return done(rc);              // the slices' sizes after this view
+        if (view_conflicts) view_conflicts[v] = (uint32_t)(s->cfg.conflict_cap ? std::min<unsigned long long>(view_total, (unsigned long long)s->P) : view_total);
+    }
+    // ---- 3. the cleaned slices, all-gathered (padded to the largest) and appended in rank order to `global` on every rank
+    unsigned long long T = 0, maxcnt = 0;
+    std::vector<unsigned long long> cnt((size_t)W);
+    for (int q = 0; q < W; ++q) { cnt[(size_t)q] = x.count(q); T += cnt[(size_t)q]; maxcnt = std::max(maxcnt, cnt[(size_t)q]); }
     if (total_out) *total_out = (uint32_t)T;
     (void)hipFree(d_views); d_views = nullptr;
-    if (T == 0) { (void)hipFree(d_cnt); return SM_OK; }
-    float *d_union = nullptr;
-    if (hipMalloc((void **)&d_union, (size_t)T * 48) != hipSuccess) { g_err = "sm_rig_consolidate: out of device memory for the union"; return fail(SM_E_HIP); }
-    auto fail2 = [&](int code) { (void)hipFree(d_union); (void)hipFree(d_cnt); return code; };
-    if ((rc = ensure_compact(s))) return fail2(rc);
-    if ((rc = pull_state(s))) return fail2(rc);
-    const uint32_t cnt = s->h_state->count;
-    if (hipMemsetAsync(d_union, 0, (size_t)T * 48, s->stream) != hipSuccess) return fail2(SM_E_HIP);
-    if (cnt) hipLaunchKernelGGL(k_export_aos, dim3((cnt + 255) / 256), dim3(256), 0, s->stream, s->M, s->d_state, d_union + (size_t)base * 12, 0u, cnt);
-    if (hipGetLastError() != hipSuccess) return fail2(SM_E_HIP);
-    if ((rc = ss_collective(s, d_union, d_union, (size_t)T * 6, SM_COLL_SUM))) return fail2(rc);
-    if (hipStreamSynchronize(s->stream) != hipSuccess) return fail2(SM_E_HIP);
-    rc = sm_append_model_aos_device(global, d_union, (uint32_t)T);
-    (void)hipFree(d_union); (void)hipFree(d_cnt);
-    return rc;
+    st = SM_OK;
+    if (T && hipMalloc((void **)&d_union, (size_t)maxcnt * 48 * (size_t)W) != hipSuccess) { g_err = "sm_rig_consolidate: out of device memory for the union"; st = SM_E_HIP; }
+    if (!st) st = ensure_compact(s);
+    if (!st) st = pull_state(s);
+    if ((rc = x.run(cnt[(size_t)r], 0ull, st))) return done(rc);
+    if (T == 0) return done(SM_OK);
+    const uint32_t own = s->h_state->count;
+    if (own) hipLaunchKernelGGL(k_export_aos, dim3((own + 255) / 256), dim3(256), 0, s->stream, s->M, s->d_state, d_union + (size_t)r * maxcnt * 12, 0u, own);
+    if (hipGetLastError() != hipSuccess) { g_err = "sm_rig_consolidate: export kernel launch failed"; return done(SM_E_HIP); }   // (the others' all-gather then fails or stalls: a launch failure is not recoverable)
+    if ((rc = ss_collective(s, d_union + (size_t)r * maxcnt * 12, d_union, (size_t)maxcnt * 6, SM_COLL_GATHER))) return done(rc);
+    if (hipStreamSynchronize(s->stream) != hipSuccess) return done(SM_E_HIP);
+    for (int q = 0; q < W; ++q)
+        if (cnt[(size_t)q] && (rc = sm_append_model_aos_device(global, d_union + (size_t)q * maxcnt * 12, (uint32_t)cnt[(size_t)q]))) return done(rc);
+    return done(SM_OK);
 }
 
 }  // extern "C"

@@ -2199,7 +2199,7 @@ __global__ __launch_bounds__(256) void k_pass_fixup(Model M, DevState *__restric
                                                     const uint32_t *__restrict__ conf_sub, uint64_t *__restrict__ keyT,
                                                     const float *__restrict__ undo, unsigned long long *__restrict__ host_stat,
                                                     const uint2 *__restrict__ prep_part, uint32_t n_prep /* k_prep's skip statistics (it evaluated the tile flags), or 0 */,
-                                                    DirectArgs da)
+                                                    DirectArgs da, uint32_t *__restrict__ tb /* tile bounds: a tile drawn only through a resurrected surfel gets the frame's time stamp too */)
 {
     __shared__ uint32_t s_a[4], s_b[4], s_c[4];
     __shared__ uint32_t s_fl;
@@ -2360,7 +2360,7 @@ __global__ __launch_bounds__(256) void k_pass_fixup(Model M, DevState *__restric
         if (nconf == 0u || tile_pre + nconf <= cap) continue;              // every conflict of the tile is effective
         const bool nosplat = (tile_flags[tile] & 2u) != 0u;
         uint32_t wpre = tile_pre + (wave > 0 ? c4.x : 0u) + (wave > 1 ? c4.y : 0u) + (wave > 2 ? c4.z : 0u);
-        uint32_t res_wave = 0;
+        uint32_t res_wave = 0, vis_tile = vis;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const uint32_t word = tile * TILE_WORDS + (uint32_t)wave * 4u + (uint32_t)r;
@@ -2387,6 +2387,10 @@ __global__ __launch_bounds__(256) void k_pass_fixup(Model M, DevState *__restric
             }
         }
         if (res_wave && lane == 0) atomicSub(&tile_dead[tile], res_wave);
+        // A resurrected surfel that went into the index map can be fused by this frame's association: the tile carries the
+        // frame's time stamp like a tile k_surfel_pass drew itself (pass_quarter / pass_tile_compact: "drawn at t" bounds the
+        // last update of every surfel of the tile, and tells the next frame's tile flags which boxes may still grow)
+        if (vis != vis_tile && lane == 0) atomicMax(&tb[(size_t)tile * 8 + 7], f2ord((float)fp.time));
         resurrected += res_wave;
     }
     __syncthreads();

@@ -103,11 +103,12 @@ class RigMapper:
     of the G latest depth / semantic images and poses: 3 bytes per pixel per camera) and the cleaned slices are gathered.
     Two rules of the reference couple the slices and are carried explicitly: surfel id 0 never conflicts
     (conflict.geom:15) -- only the rank holding the first surfel of the union applies the exemption -- and at most W*H
-    conflicts take effect per view (src/GlobalModel.cpp:54-57) -- the per-view total is all-reduced and a view with more
-    conflicts than pixels raises instead of returning a model that could differ from the definition.
+    conflicts take effect per view, in the surfel order of the union (src/GlobalModel.cpp:54-57) -- between a view's
+    conflict test and its cull the ranks exchange their conflict counts, and every slice lets its first
+    (W*H - conflicts of the slices before it) conflicts take effect: exactly the single-model rule.
 
     `backend` is the rank's mapper (capi.SurfelMap, or an oracle-backed stand-in in CPU tests) with process_frame, counts,
-    clean_points_slice(depth, sem, pose, exempt_first), download_model; `comm` has rank, world, allgather(obj),
+    clean_points_slice(depth, sem, pose, exempt_first, cap_hook), download_model; `comm` has rank, world, allgather(obj),
     allreduce_sum(array) (sharded.ThreadComm / sharded.TorchComm)."""
 
     def __init__(self, backend, comm, n_pixels: int, conflict_cap: bool = True):
@@ -133,12 +134,18 @@ class RigMapper:
                 continue
             counts = [int(c) for c in self.comm.allgather(int(self.be.counts()["count"]))]
             first = next((r for r, c in enumerate(counts) if c > 0), None)
-            self.be.clean_points_slice(*view, exempt_first=(first == self.comm.rank))
-            total = int(self.comm.allreduce_sum(np.array([self.be.counts()["conflict_count"]], np.int64))[0])
-            if self.conflict_cap and total > self.P:
-                raise RuntimeError(f"view {v}: {total} conflicts > W*H = {self.P}: the reference's conflict cap would truncate them in "
-                                   "global surfel order, which a per-slice pass does not reproduce")
-            per_view.append(total)
+            seen = []
+
+            def share(local):
+                # between the conflict test and the cull: this slice's share of the union's W*H conflict records -- the buffer
+                # fills in the surfel order of the union, i.e. slice after slice (src/GlobalModel.cpp:54-57)
+                allc = [int(c) for c in self.comm.allgather(int(local))]
+                seen.append(sum(allc))
+                if not self.conflict_cap:
+                    return 0xFFFFFFFF
+                return max(0, min(int(local), self.P - sum(allc[:self.comm.rank])))
+            self.be.clean_points_slice(*view, exempt_first=(first == self.comm.rank), cap_hook=share)
+            per_view.append(min(seen[0], self.P) if self.conflict_cap else seen[0])
         if device_index is not None and sm_global is not None:
             gathered, counts = gather_model_device(self.be, device_index)
             return build_global_model(sm_global, gathered, counts), counts, per_view

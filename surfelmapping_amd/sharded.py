@@ -272,10 +272,12 @@ class ThreadCollective:
         self.sm = sm
 
     def __call__(self, send, recv, count, op):
-        from .capi import SM_COLL_MIN
+        from .capi import SM_COLL_GATHER, SM_COLL_MIN
         a = self.sm.device_download(send, count * 8, np.uint64)          # waits for the context's stream
         vals = self.comm._exchange(a)
-        if op == SM_COLL_MIN:
+        if op == SM_COLL_GATHER:
+            r = np.concatenate(vals)                                      # rank q's words at recv + q * count
+        elif op == SM_COLL_MIN:
             r = np.minimum.reduce(np.stack(vals))
         else:
             r = np.sum(np.stack(vals), axis=0, dtype=np.uint64)

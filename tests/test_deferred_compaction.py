@@ -237,3 +237,73 @@ def test_async_frames_hand_their_association_to_the_next_frame(period, thresh):
     assert_models_equal(o.download_model(), h.download_model(), "end")
     if thresh > 0:
         assert sum(r["fused_count"] for r in ref) > 1000
+
+
+def fixup_only_tile_scenario():
+    """A model and frames where a tile is drawn ONLY through k_pass_fixup: 16 x 8 pixels (cap = 128 conflicts),
+    every pixel class 10 (sky: conflict.vert:51-54 measures max + 1 for it, so every surfel in view conflicts) at 4 m.
+    Tile 0 (slots 0..1023): 1024 class-0 surfels in view at 5 m -- the first 128 conflicts in slot order use the cap up.
+    Tile 1: three class-10 surfels exactly on the rays of checkerboard pixels at 4 m, conf 0.9, last updated at time 1: the
+    pass kills them (conflict, 0.9 - 1 <= 0), the cap takes that back (resurrected, drawn by the fixup), and the association
+    of the same frame fuses them (same depth, same class, data.vert:151) -- which sets their time to 3.  time_delta = 2: from
+    frame 4 on, the tile's stale time word (1) would gate it out of the index map while its surfels (3) still belong there."""
+    W, H = 16, 8
+    fx, cxx, cyy = 100.0, W / 2 - 0.5, H / 2 - 0.5
+
+    def on_ray(i, j, z, **kw):
+        s = np.zeros(12, np.float32)
+        s[0] = np.float32(np.float32(np.float32(i + 0.5) - np.float32(cxx)) * np.float32(z)) * np.float32(1.0 / fx)
+        s[1] = np.float32(np.float32(np.float32(j + 0.5) - np.float32(cyy)) * np.float32(z)) * np.float32(1.0 / fx)
+        s[2] = z
+        s[3] = kw.get("conf", 0.9)
+        s[4] = np.array([np.uint32(kw.get("sem", 0) << 24 | 0x102030)], np.uint32).view(np.float32)[0]
+        s[6], s[7] = 1.0, 1.0
+        s[10] = 1.0
+        s[11] = 0.05
+        return s
+
+    tile0 = [on_ray(k % W, (k // W) % H, 5.0) for k in range(1024)]
+    tile1 = [on_ray(i, j, 4.0, sem=10) for i, j in ((3, 2), (8, 5), (11, 4))]          # (i + j) odd: data.vert:88
+    model = np.stack(tile0 + tile1)
+    rgb = np.zeros((H, W, 3), np.uint8)
+    rgb[..., 0], rgb[..., 1], rgb[..., 2] = 0x10, 0x20, 0x30
+    sky4 = (rgb, np.full((H, W), 4000, np.uint16), np.full((H, W), 10, np.uint8))
+    road4 = (rgb, np.full((H, W), 4000, np.uint16), np.zeros((H, W), np.uint8))        # class 0 at the same depth: nothing conflicts
+    return dict(width=W, height=H, fx=fx, fy=fx, cx=cxx, cy=cyy), model, [sky4, road4, road4, road4]
+
+
+@pytest.mark.parametrize("asynchronous", [False, True])
+def test_tile_drawn_only_through_the_cap_fixup_keeps_its_time_stamp(asynchronous):
+    cam, model, frames = fixup_only_tile_scenario()
+    o, h = pair(cam, stereo_border=0.0, conflict_cap=1, max_sqrt_vertices=64, compact_period=1000, time_delta=2)
+    P = cam["width"] * cam["height"]
+    for b in (o, h):
+        b.upload_model(model)
+        b.set_tick(3)
+    ref = []
+    for fr in frames:
+        o.process_frame(*fr, IDENT)
+        ref.append((o.counts(), o.download_index_map()[0].copy()))
+    assert ref[0][0]["conflict_count"] == P and ref[0][0]["fused_count"] == 3, ref[0][0]       # the scenario does what it says
+    ids1 = set(range(1024 - 128, 1024 - 128 + 3))          # tile 1's surfels after frame 3's cull (128 of tile 0 died)
+    assert ids1 <= set(ref[1][1].ravel().tolist()), "frame 4 must still draw tile 1's surfels (updated at 3, delta 2)"
+    if asynchronous:
+        bufs = []
+        for rgb, d, s in frames:
+            dr, dd, ds = h.device_alloc(P * 3), h.device_alloc(P * 2), h.device_alloc(P)
+            h.device_upload(dr, rgb); h.device_upload(dd, d); h.device_upload(ds, s)
+            bufs.append((dr, dd, ds))
+        for b in bufs:
+            h.process_frame_device(*b, IDENT)
+        h.sync()
+        log = h.read_frame_log(8)
+        assert [int(x) for x in log["visible_count"]] == [r[0]["visible_count"] for r in ref], log["visible_count"]
+        assert [int(x) for x in log["fused_count"]] == [r[0]["fused_count"] for r in ref]
+    else:
+        for k, fr in enumerate(frames):
+            h.process_frame(*fr, IDENT)
+            ch = h.counts()
+            assert {x: ch[x] for x in COUNT_KEYS} == {x: ref[k][0][x] for x in COUNT_KEYS}, f"frame {k}"
+            np.testing.assert_array_equal(h.download_index_map()[0], ref[k][1], err_msg=f"index map, frame {k}")
+    same_counts(o, h, "end")
+    assert_models_equal(o.download_model(), h.download_model(), "fixup-only tile")

@@ -43,6 +43,8 @@ class OracleRigBackend:
         self.o = ol.Oracle(ol.make_config(**CAM, **OVER))
         self.L = ol.lib()
         self.L.smo_set_exempt_id.argtypes = [C.c_void_p, C.c_int32]
+        self.L.smo_set_conflict_limit.argtypes = [C.c_void_p, C.c_int64]
+        self.L.smo_count_clean_conflicts.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32)]
 
     def process_frame(self, *fr):
         return self.o.process_frame(*fr)
@@ -53,9 +55,15 @@ class OracleRigBackend:
     def download_model(self):
         return self.o.download_model()
 
-    def clean_points_slice(self, depth, sem, pose, exempt_first):
+    def clean_points_slice(self, depth, sem, pose, exempt_first, cap_hook=None):
         self.L.smo_set_exempt_id(self.o._h, 0 if exempt_first else -1)
+        if cap_hook is not None:
+            d = np.ascontiguousarray(depth, np.uint16); s_ = np.ascontiguousarray(sem, np.uint8); p = np.ascontiguousarray(pose, np.float32)
+            n = C.c_uint32()
+            assert self.L.smo_count_clean_conflicts(self.o._h, d.ctypes.data, s_.ctypes.data, p.ctypes.data, C.byref(n)) == 0
+            self.L.smo_set_conflict_limit(self.o._h, int(cap_hook(n.value)))
         self.o.clean_points(depth, sem, pose)
+        self.L.smo_set_conflict_limit(self.o._h, -1)
         self.L.smo_set_exempt_id(self.o._h, 0)
 
 
@@ -240,3 +248,102 @@ def test_rig_consolidation_two_gloo_processes():
     for rank, counts, per_view, blob in res:
         assert per_view == conflicts and sum(counts) == model.shape[0]
         assert np.array_equal(np.frombuffer(blob, np.uint32).reshape(-1, 12), model.view(np.uint32))
+
+
+# ---------------------------------------------------------------- the W*H conflict cap across slices (src/GlobalModel.cpp:54-57)
+CAP_CAM = dict(width=48, height=32, fx=40.0, fy=40.0, cx=23.5, cy=15.5)
+CAP_OVER = dict(preprocess=0, stereo_border=0.0, max_sqrt_vertices=120, conflict_cap=1)
+CAP_SIZES = (1000, 2500, 3000)              # slice 0 leaves 536 of the 1 536 records to slice 1, slice 2 gets none (first view)
+
+
+def cap_slice(rank):
+    rng = np.random.default_rng(100 + rank)
+    n = CAP_SIZES[rank]
+    m = synth.seeded_model(n, tick=1, seed=50 + rank)
+    m[:, 0] = rng.uniform(-1.5, 1.5, n)
+    m[:, 1] = rng.uniform(-1.0, 1.0, n)
+    m[:, 2] = rng.uniform(3.0, 6.0, n)
+    m[:, 3] = rng.uniform(0.5, 3.5, n).astype(np.float32)
+    return m
+
+
+def cap_view(rank):
+    """every camera sees a wall at 12 + rank metres from the origin: all surfels in view are contradicted (clean mode: far - 15 = 15 m)"""
+    return (np.full((32, 48), 12000 + 1000 * rank, np.uint16), np.zeros((32, 48), np.uint8),
+            np.eye(4, dtype=np.float32).T.reshape(16).copy())
+
+
+def cap_definition(world):
+    g = ol.Oracle(ol.make_config(**CAP_CAM, **CAP_OVER))
+    g.upload_model(np.concatenate([cap_slice(r) for r in range(world)], axis=0))
+    conflicts = []
+    for r in range(world):
+        g.clean_points(*cap_view(r))
+        conflicts.append(g.counts()["conflict_count"])
+    return g.download_model(), conflicts
+
+
+def run_cap_threads(world, make_backend, native=False):
+    group = sharded.ThreadGroup(world)
+    out, err = [None] * world, []
+
+    def work(r):
+        try:
+            be = make_backend(r)
+            be.upload_model(cap_slice(r))
+            mp = smd.RigMapper(be, sharded.ThreadComm(group, r), CAP_CAM["width"] * CAP_CAM["height"])
+            mp.last = cap_view(r)
+            if native:
+                from surfelmapping_amd import capi
+                glob = capi.SurfelMap(capi.make_config(**CAP_CAM, **CAP_OVER))
+                mp.enable_native(sharded.ThreadCollective(group, r, be))
+                total, per_view = mp.consolidate_native(glob)
+                out[r] = (glob.download_model(), total, per_view)
+            else:
+                model, counts, per_view = mp.consolidate()
+                out[r] = (model, sum(counts), per_view)
+        except BaseException as e:
+            err.append(e)
+            group.barrier.abort()
+
+    ts = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    [t.start() for t in ts]
+    [t.join(600) for t in ts]
+    if err:
+        raise err[0]
+    return out
+
+
+def check_cap(out, world):
+    model, conflicts = cap_definition(world)
+    P = CAP_CAM["width"] * CAP_CAM["height"]
+    assert conflicts[0] == P and max(conflicts) == P, conflicts         # the cap binds
+    for r in range(world):
+        got, total, per_view = out[r]
+        assert per_view == conflicts and total == model.shape[0], (per_view, conflicts, total, model.shape)
+        assert np.array_equal(got.view(np.uint32), model.view(np.uint32)), f"rank {r}"
+
+
+class _OracleUploadBackend(OracleRigBackend):
+    def __init__(self):
+        self.o = ol.Oracle(ol.make_config(**CAP_CAM, **CAP_OVER))
+        self.L = ol.lib()
+        self.L.smo_set_exempt_id.argtypes = [C.c_void_p, C.c_int32]
+        self.L.smo_set_conflict_limit.argtypes = [C.c_void_p, C.c_int64]
+        self.L.smo_count_clean_conflicts.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32)]
+
+    def upload_model(self, m):
+        self.o.upload_model(m)
+
+
+def test_rig_conflict_cap_is_shared_exactly_oracle_ranks():
+    """more conflicts than pixels in every view: the first W*H in the surfel order of the union take effect, i.e. slice 0's
+    all, slice 1's first 536, none of slice 2's (first view) -- each rank applies its share, nobody refuses"""
+    check_cap(run_cap_threads(3, lambda r: _OracleUploadBackend()), 3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("native", [False, True])
+def test_rig_conflict_cap_is_shared_exactly_hip_contexts(native):
+    from surfelmapping_amd import capi
+    check_cap(run_cap_threads(3, lambda r: capi.SurfelMap(capi.make_config(**CAP_CAM, **CAP_OVER)), native), 3)
