@@ -9,18 +9,32 @@ RGB-D+semantic frame (BASELINE.json configs[1]); frames are resident in HBM befo
 region starts and are enqueued back-to-back (no host read-back inside a frame or between
 frames -- the counters of every frame are audited afterwards from the device-side frame log).
 
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself: N fresh
+child processes of this file (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set, one
+GPU each) -- the parent never touches a GPU -- and relays rank 0's one line.  Under torchrun
+(WORLD_SIZE set) the process is one of the ranks.  WORLD_SIZE != --gpus is an error, never a
+silent one-GPU run.
+
 Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel against the 8 TB/s HBM
 peak with algorithmic bytes from the per-frame counters (DESIGN.md "Measurement");
 `cpu_baseline` is the CPU oracle (oracle/, a scalar restatement of the reference's passes)
-timed on this host over the same frames, 1 thread.
+timed on this host over the same frames, 1 thread.  One rank also reports, in the same line:
+`steady_leg` (100 frames after 10), `fuse_leg` (frames that actually fuse), `reference_path_leg`
+(preprocess = 1, host buffers: what the drop-in's SurfelMapping::processFrame executes) and
+`hd_leg` (BASELINE configs[2]: 1920x1080, 20 M seeded surfels).  N ranks report the rig
+aggregate as `value` (configs[4]: one camera per GPU), the consolidation into a single
+GlobalModel, and `sharded_leg` (configs[3]: ONE stream over the N GPUs).
 """
 from __future__ import annotations
 
 import argparse
 import gc
 import json
+import math
 import multiprocessing as mp
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -34,12 +48,15 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 from surfelmapping_amd import synth  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+METRIC = "frames/sec per GPU, 1242x375 KITTI-shaped RGB-D+semantic, full associate+fuse+merge"
 
 
+# ------------------------------------------------------------------------------------------------
+# synthetic frames (CPU only; forked workers never touch a GPU)
+# ------------------------------------------------------------------------------------------------
 def rig_trajectory(n, rank, world, step=0.8):
     """Camera `rank` of a `world`-camera rig: same forward motion, yaw offset rank*360/world deg
     (BASELINE configs[4] / SURVEY 8d config 5); world == 1 is the plain KITTI trajectory."""
-    import math
     yaw0 = 360.0 / world * rank if world > 1 else 0.0
     return [synth.pose_matrix(0.0, 0.0, step * k, yaw0 + 0.5 * math.sin(k / 20.0)) for k in range(n)]
 
@@ -60,6 +77,79 @@ def make_frames(cam_kw, n, seed, noise, workers, rank=0, world=1):
     return [_render(j) for j in jobs]
 
 
+# ------------------------------------------------------------------------------------------------
+# N ranks from one command line
+# ------------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(args, argv):
+    """`--gpus N` outside torchrun: N fresh child processes, one per GPU.  The parent has not imported torch or the HIP core
+    and never will; it relays rank 0's stdout (the one JSON line), lets every rank's stderr through, and fails if any rank does."""
+    n = args.gpus
+    env0 = dict(os.environ)
+    env0.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env0["MASTER_ADDR"] = env0.get("MASTER_ADDR", "127.0.0.1")
+    env0["MASTER_PORT"] = str(_free_port())
+    env0["WORLD_SIZE"] = str(n)
+    env0["LOCAL_WORLD_SIZE"] = str(n)
+    procs = []
+    for r in range(n):
+        env = dict(env0, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=subprocess.PIPE))
+    # wait for all of them; the first rank that fails (or the time limit) ends the others -- the exact PIDs started above --
+    # so that nobody is left waiting inside a collective
+    deadline = time.time() + args.launch_timeout
+    failed = False
+    while any(pr.poll() is None for pr in procs):
+        if any(pr.poll() not in (None, 0) for pr in procs) or time.time() > deadline:
+            failed = True
+            for q in procs:
+                if q.poll() is None:
+                    q.kill()
+            break
+        time.sleep(0.05)
+    outs = [pr.communicate()[0].decode(errors="replace") for pr in procs]       # (one short line per rank: far below the pipe buffer)
+    rcs = [pr.returncode for pr in procs]
+    if failed or any(rcs):
+        sys.stderr.write(f"bench.py: rank exit codes {rcs}" + (" (time limit)" if time.time() > deadline else "") + "\n")
+        raise SystemExit(1)
+    if args.launch_dry_run:
+        kids = sorted((json.loads(o.strip().splitlines()[-1]) for o in outs), key=lambda d: d["rank"])
+        print(json.dumps({"launch_dry_run": True, "n_gpus": n, "ranks": [k["rank"] for k in kids], "children": kids}))
+        return
+    lines = [ln for ln in outs[0].splitlines() if ln.strip()]
+    if len(lines) != 1:
+        sys.stderr.write(f"bench.py: rank 0 printed {len(lines)} lines, expected one\n")
+        raise SystemExit(1)
+    stray = [r for r in range(1, n) if outs[r].strip()]
+    if stray:
+        sys.stderr.write(f"bench.py: ranks {stray} wrote to stdout\n")
+        raise SystemExit(1)
+    print(lines[0])
+
+
+def dry_run_rank(rank, world, local_rank):
+    """--launch-dry-run: what a child would bind to, plus a gloo all-reduce over the ranks (proves the rendezvous the launcher
+    set up); no GPU is touched, so this runs in the CPU test suite."""
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    t = torch.tensor([rank + 1], dtype=torch.int64)
+    dist.all_reduce(t)
+    dist.destroy_process_group()
+    print(json.dumps({"rank": rank, "world": world, "local_rank": local_rank, "master": f"{os.environ['MASTER_ADDR']}:{os.environ['MASTER_PORT']}",
+                      "sum_of_ranks_plus_1": int(t[0]), "pid": os.getpid()}))
+
+
+# ------------------------------------------------------------------------------------------------
+# roofline bookkeeping
+# ------------------------------------------------------------------------------------------------
 def kernel_bytes(log):
     """Algorithmic HBM bytes per launch of each kernel from the per-frame counters
     (DESIGN.md "Measurement"; SoA surfel = 44 B, key = 8 B).  Every entry is an array over the timed frames; a kernel
@@ -74,14 +164,12 @@ def kernel_bytes(log):
     # frame the rest is read in full (44) and its survivors rewritten (44); every drawn surfel costs one 8-byte key atomic
     compact = 20.0 * np.maximum(Ns - Ss, 0.0) + 44.0 * np.maximum(Sl - Ns, 0.0) + 44.0 * np.maximum(Np - Ns, 0.0) + 8.0 * V
     # one-pass frames: pos_conf (16) of every slot whose tile is not skipped by BOTH tests (>= Sl - min(Cs, Ss): the
-    # exact count is not logged, this is the lower bound), the time (4) of the slots whose tile reaches the index map,
-    # one key atomic per drawn surfel
-    # (lane-compacting form, the default: the time plane is read only for the slots that reach the exact tests -- not
-    #  logged; lower bound: the drawn ones.  SM_PASS_COMPACT=0, word by word: every slot of a tile that reaches the index map)
-    t_read = V if os.environ.get("SM_PASS_COMPACT", "1") != "0" else np.maximum(Sl - Ss, 0.0)
-    one_pass = 16.0 * np.maximum(Sl - np.minimum(Cs, Ss), 0.0) + 4.0 * t_read + 8.0 * V
+    # exact count is not logged, this is the lower bound), the time (4) of the slots that reach the exact tests (not
+    # logged; lower bound: the drawn ones), one key atomic per drawn surfel
+    one_pass = 16.0 * np.maximum(Sl - np.minimum(Cs, Ss), 0.0) + 4.0 * V + 8.0 * V
+    pre = 6.0 * P + 24.0 * P                                     # u8x3+u16+u8 in, f32+u32+u64+(f32,u32) out
     return {
-        "k_prep": np.full_like(N, 6.0 * P + 24.0 * P),          # u8x3+u16+u8 in, f32+u32+u64+(f32,u32) out
+        "k_prep": np.full_like(N, pre),
         "k_conflict": 16.0 * np.maximum(Sl - Cs, 0.0),            # tiles skipped by their bounds are not read
         "k_compact": compact,
         "k_surfel_pass": one_pass,
@@ -92,7 +180,7 @@ def kernel_bytes(log):
     }
 
 
-def kernel_table(log, tim, P, K, args, workload=None):
+def kernel_table(log, tim, P, K, warmup, compact_period, workload):
     """Per-kernel launches, average duration (HIP events), algorithmic bytes and GB/s of the timed frames, and the
     roofline entry of the kernel the run spends most time in.  The frame forms: a frame whose cull only
     marks the dead runs k_surfel_pass + k_pass_fixup (+ k_associate_direct when it appends directly), the others
@@ -105,7 +193,7 @@ def kernel_table(log, tim, P, K, args, workload=None):
     # (one-pass <=> not compacted on the default path; direct <=> one-pass and k_prep evaluated the tile flags)
     sel_op = ~moved if n_op else np.zeros(len(log), bool)
     sel_dir = sel_op if n_dir == n_op else np.zeros(len(log), bool)
-    # asynchronous plain streams: a frame's association is held back and runs in the NEXT frame's preparation launch (k_assoc_prep)
+    # asynchronous streams: a frame's association is held back and runs in the NEXT frame's preparation launch (k_assoc_prep)
     n_mrg, n_alone = int(tim.get("frames_merged", 0)), int(tim.get("frames_assoc_alone", n_dir))
     sel_mrg = np.zeros(len(log), bool)
     if n_mrg and len(log):
@@ -121,7 +209,7 @@ def kernel_table(log, tim, P, K, args, workload=None):
             ("k_compact", tim.get("k_compact_own", 0.0), moved, n_comp),
             ("k_associate", tim.get("k_associate_own", 0.0), ~sel_dir, K - n_dir),
             ("k_append", tim.get("k_append_own", 0.0), ~sel_dir, K - n_dir)]
-    if K - n_op - n_comp > 0:      # lazy culls outside the one-pass form (SM_ONE_PASS=0, or the depth filter chain on the second stream)
+    if K - n_op - n_comp > 0:      # lazy culls outside the one-pass form
         rows.append(("k_cull_lazy", tim.get("k_cull_lazy", 0.0), ~moved & ~sel_op, K - n_op - n_comp))
     kern, launches = {}, {}
     for name, ms, sel, n in rows:
@@ -133,152 +221,451 @@ def kernel_table(log, tim, P, K, args, workload=None):
         launches[name] = n
     if K - n_op > 0:
         kern["k_scan_cull+k_cull_finalize"] = {"ms": tim["k_scan_cull"] * K / max(K - n_op, 1), "MB": None, "GBs": None, "launches": K - n_op}
+    # HBM bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this very command
+    # (profiles/README.md), gfx950-corrected per kernel by tools/prof_summary.py
+    tj = None
+    for tpath in (os.path.join(ROOT, "profiles", f"traffic_{workload}_s{K}_w{warmup}.json"), os.path.join(ROOT, "profiles", f"traffic_{workload}.json")):
+        if os.path.exists(tpath):
+            cand = json.load(open(tpath))
+            if cand.get("steps") == K and cand.get("warmup") == warmup and cand.get("compact_period", 16) == compact_period:
+                tj = cand
+                break
+    for name in kern:
+        t = (tj or {}).get("kernels", {}).get(name, {})
+        kern[name]["hbm_traffic_MB"] = t.get("hbm_bytes_per_launch") / 1e6 if t.get("hbm_bytes_per_launch") else None
+        kern[name]["frac_of_hbm_peak"] = (kern[name]["GBs"] / HBM_PEAK_GBS) if kern[name].get("GBs") else None
     # dominant kernel = the one the run spends most time in (average duration x launches)
     dom = max(launches.keys(), key=lambda n: kern[n]["ms"] * launches[n])
     achieved = kern[dom]["GBs"] or 0.0
-    traffic, valu = None, None
-    wl = workload or args.workload
-    for tpath in (os.path.join(ROOT, "profiles", f"traffic_{wl}_s{K}_w{max(args.warmup, 2)}.json"), os.path.join(ROOT, "profiles", f"traffic_{wl}.json")):
-        if not os.path.exists(tpath):
-            continue
-        # HBM bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this very
-        # command (profiles/README.md), gfx950-corrected per kernel by tools/prof_summary.py
-        tj = json.load(open(tpath))
-        if tj.get("steps") == K and tj.get("warmup") == max(args.warmup, 2) and tj.get("compact_period", 16) == args.compact_period:
-            traffic = tj.get("kernels", {}).get(dom, {}).get("hbm_bytes_per_launch")
-            valu = tj.get("kernels", {}).get(dom, {}).get("valu_issue_util")
-            break
+    t = (tj or {}).get("kernels", {}).get(dom, {})
     roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": t.get("hbm_bytes_per_launch"),
                 "ms_per_launch": kern[dom]["ms"], "alg_bytes_per_launch": kern[dom]["MB"] * 1e6,
-                "launches": launches[dom],
-                "valu_issue_util": valu,
-                "note": "not byte-bound: a frame touches ~60 MB.  tools/pass_trace.py (per-workgroup time stamps of one launch, DESIGN.md 4): "
-                        "the 2 048 workgroups of k_surfel_pass take 5-8 us to enter the chip, every visited tile's 16 KB arrives in one "
-                        "~4 us burst at the start, and the ~240 tiles that hold most of the surfels in view then run ~350 IEEE-exact "
-                        "VALU instructions per surfel for ~6 us; k_assoc_prep is one such burst (28 MB) plus two dependent gathers"}
+                "launches": launches[dom], "valu_issue_util": t.get("valu_issue_util"),
+                "traffic_source": (os.path.relpath(tpath, ROOT) if tj else None)}
     return kern, launches, roofline
 
 
-def bench_sharded(args, dist, torch, capi, cam, frames, rank, world, local_rank, K, Wm, t_gen, emit):
-    """ONE camera stream split over the GPUs (BASELINE configs[3]); every rank holds the replicated frame sequence (same
-    seed, no rank offset).  Default: the in-stream form (sm_shard_frame_device: slot-addressed shards, RCCL called from the
-    HIP core on the context's stream, frames resident in HBM); --shard-form staged is round 1's per-stage form driven from
-    Python (surfelmapping_amd/sharded.py ShardedMapper), kept for comparison."""
-    from surfelmapping_amd import sharded
-    P = cam["width"] * cam["height"]
-    stream = args.shard_form == "stream"
-    kw = dict(preprocess=args.preprocess, device=local_rank, conflict_cap=1)
-    if args.compact_period is not None:
-        kw["compact_period"] = args.compact_period
-    sm = capi.SurfelMap(capi.make_config(**cam, **kw))
-    if stream:
-        ids = [capi.rccl_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(ids, src=0)
-        mp = sharded.StreamShard(sm, rank, world, *((None,) if (args.no_rccl and world == 1) else ("rccl", ids[0])))
-        dptr = []
-        for rgb, depth, sem, pose in frames:
-            dr, dd, ds = sm.device_alloc(P * 3), sm.device_alloc(P * 2), sm.device_alloc(P)
-            sm.device_upload(dr, rgb); sm.device_upload(dd, depth); sm.device_upload(ds, sem)
-            dptr.append((dr, dd, ds, pose))
-        step = lambda k: sm.shard_frame_device(*dptr[k])
-    else:
-        mp = sharded.ShardedMapper(sharded.HipShardBackend(sm, rank, world), sharded.TorchComm(device_index=local_rank), P,
-                                   collect_stats=False)
-        step = lambda k: mp.process_frame(*frames[k])
-    # no collector pause inside the timed region: with torch imported a full collection takes ~45 ms (measured: one frame call
-    # of 110 stalled that long).  Collect BEFORE the warm-up: a 45 ms pause between warm-up and t0 lets the GPU clock down.
-    gc.collect(); gc.disable()
-    for k in range(Wm):
-        step(k)
-    sm.sync()
-    c0 = sm.counts() if stream else mp.counts()
-    dist.barrier(); torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    enq = []
-    for k in range(Wm, Wm + K):
-        te = time.perf_counter()
-        step(k)
-        enq.append(time.perf_counter() - te)
-    t_enq = time.perf_counter() - t0
-    sm.sync(); torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0      # this rank's K frames are complete; the MAX over the ranks below is when the last rank was
-    dist.barrier(); torch.cuda.synchronize()  # (the closing barrier itself -- ~0.4 ms with torch's NCCL -- is not part of the K frames)
-    gc.enable()
-    t = torch.tensor([elapsed], dtype=torch.float64, device=torch.device("cuda", local_rank))
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t[0])
-    c1 = sm.counts() if stream else mp.counts()
-    log = sm.read_frame_log(K) if stream else None
-    fused = int(log["fused_count"].sum() + log["unstable_count"].sum()) if log is not None and len(log) else 0
-    plain = None
-    if rank == 0 and stream and not args.no_plain_leg:
-        # the same frames on the plain single-GPU path of this GPU: what sharding has to beat
-        fps1, ms1, _, cp, _ = run_simple_leg(capi, cam, frames, K, Wm, dict(preprocess=args.preprocess, conflict_cap=1, **(
-            {"compact_period": args.compact_period} if args.compact_period is not None else {})), argparse.Namespace(no_events=True))
-        plain = {"frames_per_sec": fps1, "ms_per_step": ms1, "surfels_end": int(cp["count"]),
-                 "sharded_over_plain": (elapsed / K * 1e3) / ms1}
-    if stream and not (args.no_rccl and world == 1):
-        sm.shard_rccl_finalize()
-    dist.destroy_process_group()
-    if rank != 0:
-        return
-    form = ("in-stream form: slot-addressed shards, per frame all-reduce(min) of the 3.7 MB key map and all-reduce(sum) of the fused-pixel "
-            "mask + 3 counters, RCCL called from the HIP core on the frame's stream, frames resident in HBM, deferred compaction "
-            "between frames (all-reduce(sum) of the alive bits)") if stream else (
-            "staged form driven from Python: all-reduce(sum) segment counts, all-reduce(min) key map, all-reduce(sum) fused mask; "
-            "host-buffer frames (PCIe-inclusive)")
-    emit(({
-        "metric": "frames/sec, 1242x375 KITTI-shaped RGB-D+semantic, full associate+fuse+merge",
-        "value": K / elapsed, "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm,
-        "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"BASELINE configs[3]: ONE KITTI 1242x375 stream sharded over {world} GPUs, {form}; result bit-identical to 1 GPU",
-                   "frames": f"{Wm}..{Wm + K - 1}", "surfels_start": int(c0["count"]), "surfels_end": int(c1["count"])},
-        "surfels_fused_per_sec": fused / elapsed, "plain_single_gpu": plain,
-        "host_enqueue_ms_per_step": t_enq / K * 1e3, "host_enqueue_max_ms": max(enq) * 1e3, "host_enqueue_argmax": int(np.argmax(enq)), "host_enqueue_median_ms": float(np.median(enq)) * 1e3, "roofline": None, "cpu_baseline": None, "gen_seconds": t_gen}))
+# ------------------------------------------------------------------------------------------------
+# one single-GPU leg
+# ------------------------------------------------------------------------------------------------
+def stage_frames(sm, frames, P):
+    out = []
+    for rgb, depth, sem, pose in frames:
+        dr, dd, ds = sm.device_alloc(P * 3), sm.device_alloc(P * 2), sm.device_alloc(P)
+        sm.device_upload(dr, rgb); sm.device_upload(dd, depth); sm.device_upload(ds, sem)
+        out.append((dr, dd, ds, pose))
+    return out
 
 
-def run_simple_leg(capi, cam, frames, K, Wm, cfg_kw, args):
-    """One single-GPU leg: stage the frames in HBM, time K frames after Wm on an un-instrumented context, replay them on
-    a context with HIP events for the per-kernel durations.  Returns (frames/s, ms/step, frame log, counts, timings)."""
+def run_leg(capi, cam, frames, K, Wm, cfg_kw, *, events=True, mode="device", seed_model=None, seed_tick=None, keep=False):
+    """K frames after Wm on an un-instrumented context (this is the leg's frames/s), then -- events=True -- the same frames
+    again on a context that records a HIP event after every kernel (per-kernel durations for the roofline).
+    mode: "device"     frames staged in HBM, sm_process_frame_device, no host wait inside the K frames (the metric's form);
+          "host_sync"  sm_process_frame on host buffers: 2.8 MB H2D + a host wait per frame = the reference's processFrame;
+          "host_async" sm_process_frame_async on host buffers: pinned staging, the copy of frame f+1 overlaps frame f;
+          "device_sync" device-resident frames, host waits for the counters after every frame.
+    Returns a dict; with keep=True the timed context stays open under "sm"."""
     P = cam["width"] * cam["height"]
 
-    def stage(sm):
-        out = []
-        for rgb, depth, sem, pose in frames:
-            dr, dd, ds = sm.device_alloc(P * 3), sm.device_alloc(P * 2), sm.device_alloc(P)
-            sm.device_upload(dr, rgb); sm.device_upload(dd, depth); sm.device_upload(ds, sem)
-            out.append((dr, dd, ds, pose))
-        return out
+    def prime(sm):
+        if seed_model is not None:
+            sm.upload_model(seed_model)
+            sm.set_tick(seed_tick)
+
+    def step_fn(sm, dptr):
+        if mode == "device":
+            return lambda k: sm.process_frame_device(*dptr[k])
+        if mode == "device_sync":
+            def f(k):
+                sm.process_frame_device(*dptr[k]); sm.sync()
+            return f
+        if mode == "host_sync":
+            return lambda k: sm.process_frame(*frames[k])
+        if mode == "host_async":
+            return lambda k: sm.process_frame_async(*frames[k])
+        raise ValueError(mode)
 
     sm = capi.SurfelMap(capi.make_config(**cam, **cfg_kw, enable_timing=0))
-    dptr = stage(sm)
+    prime(sm)
+    dptr = stage_frames(sm, frames, P) if mode.startswith("device") else None
+    step = step_fn(sm, dptr)
+    # no collector pause inside the timed region: with torch imported a full collection takes ~45 ms.  Collect BEFORE the
+    # warm-up: a pause between warm-up and t0 lets the GPU clock down (+130 us on the first frames)
     gc.collect(); gc.disable()
     for k in range(Wm):
-        sm.process_frame_device(*dptr[k])
+        step(k)
     sm.sync()
     t0 = time.perf_counter()
     for k in range(Wm, Wm + K):
-        sm.process_frame_device(*dptr[k])
+        step(k)
+    t_enq = time.perf_counter() - t0
     sm.sync()
     el = time.perf_counter() - t0
     gc.enable()
-    log, counts = sm.read_frame_log(K), sm.counts()
-    sm.close()
-    tim = None
-    if not args.no_events:
-        sm = capi.SurfelMap(capi.make_config(**cam, **cfg_kw, enable_timing=1))
-        dptr = stage(sm)
-        for k in range(Wm):
-            sm.process_frame_device(*dptr[k])
-        sm.sync(); sm.timings()
-        for k in range(Wm, Wm + K):
-            sm.process_frame_device(*dptr[k])
-        sm.sync()
-        tim = sm.timings()
+    res = {"fps": K / el, "ms": el / K * 1e3, "log": sm.read_frame_log(K), "counts": sm.counts(), "tim": None,
+           "host_enqueue_ms": t_enq / K * 1e3}
+    if keep:
+        res["sm"], res["dptr"] = sm, dptr
+    else:
         sm.close()
-    return K / el, el / K * 1e3, log, counts, tim
+    if events:
+        ev = capi.SurfelMap(capi.make_config(**cam, **cfg_kw, enable_timing=1))
+        prime(ev)
+        dp = stage_frames(ev, frames, P)
+        for k in range(Wm):
+            ev.process_frame_device(*dp[k])
+        ev.sync(); ev.timings()                       # drop the warm-up samples
+        for k in range(Wm, Wm + K):
+            ev.process_frame_device(*dp[k])
+        ev.sync()
+        res["tim"] = ev.timings()
+        assert ev.counts()["count"] == res["counts"]["count"], "instrumented pass diverged from the timed pass"
+        ev.close()
+    return res
+
+
+def leg_summary(res, K):
+    log = res["log"]
+    return {"value": res["fps"], "unit": "frames/s", "ms_per_step": res["ms"],
+            "fused_F_per_frame": float(log["fused_count"].mean()) if len(log) else 0.0,
+            "new_U_per_frame": float(log["unstable_count"].mean()) if len(log) else 0.0,
+            "conflicts_per_frame": float(log["conflict_count"].mean()) if len(log) else 0.0,
+            "frames_that_compacted": int((log["n_static"] < log["n_slots"]).sum()) if len(log) else 0,
+            "surfels_start": int(log["n_before"][0]) if len(log) else 0, "surfels_end": int(res["counts"]["count"])}
+
+
+def oracle_run(ol, cam, frames, Wm, Kc, cfg_kw, libpath=None, seed_model=None, seed_tick=None, per_frame=False):
+    """the CPU oracle over frames [0, Wm + Kc); returns (frames/s over the last Kc, final counts, per-frame counts)"""
+    o = ol.Oracle(ol.make_config(**cam, **cfg_kw), **({"libpath": libpath} if libpath else {}))
+    if seed_model is not None:
+        o.upload_model(seed_model); o.set_tick(seed_tick)
+    for k in range(Wm):
+        o.process_frame(*frames[k])
+    seq = []
+    c0 = time.perf_counter()
+    for k in range(Wm, Wm + Kc):
+        o.process_frame(*frames[k])
+        if per_frame:
+            seq.append(o.counts())
+    el = time.perf_counter() - c0
+    oc = o.counts()
+    o.close()
+    return Kc / el, oc, seq
+
+
+# ------------------------------------------------------------------------------------------------
+# N ranks: the rig (configs[4], `value`), its consolidation, and ONE stream sharded over the ranks (configs[3])
+# ------------------------------------------------------------------------------------------------
+def bench_ranks(args, cam, rank, world, local_rank, K, Wm, workers, emit):
+    P = cam["width"] * cam["height"]
+    t0 = time.time()
+    frames = make_frames(cam, Wm + K, args.seed, args.noise_mm, workers, rank, world)           # this rank's camera
+    shared = frames if rank == 0 else make_frames(cam, Wm + K, args.seed, args.noise_mm, workers, 0, 1)   # rank 0's stream, on every rank
+    t_gen = time.time() - t0
+    # torch first: its HIP runtime must be the one the core binds to (one runtime per process)
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if world == 1:                         # --force-dist outside a launcher: a one-rank rendezvous of its own
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(_free_port()))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    from surfelmapping_amd import capi
+    from surfelmapping_amd import dist as smd
+    from surfelmapping_amd import sharded as smsh
+    os.environ.setdefault("SM_COMPACT_TICKETS", "0")     # this process's contexts never run at the same time
+
+    def barrier():
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    def max_over_ranks(x):
+        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t[0])
+
+    def bcast_id():
+        ids = [capi.rccl_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        return ids[0]
+
+    cfg = dict(preprocess=args.preprocess, device=local_rank, conflict_cap=1, compact_period=args.compact_period)
+    # ---- rig leg: one camera stream per GPU, no collective inside a frame
+    sm = capi.SurfelMap(capi.make_config(**cam, **cfg))
+    dptr = stage_frames(sm, frames, P)
+    gc.collect(); gc.disable()
+    for k in range(Wm):
+        sm.process_frame_device(*dptr[k])
+    sm.sync()
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(Wm, Wm + K):
+        sm.process_frame_device(*dptr[k])
+    sm.sync()
+    torch.cuda.synchronize()
+    own = time.perf_counter() - t0                # this rank's K frames are complete; MAX over the ranks below
+    barrier()                                     # (the closing barrier's own latency, ~0.4 ms, is not K frames' work)
+    gc.enable()
+    elapsed = max_over_ranks(own)
+    log = sm.read_frame_log(K)
+    fu = torch.tensor([float(log["fused_count"].sum()), float(log["unstable_count"].sum())], dtype=torch.float64, device=dev)
+    dist.all_reduce(fu, op=dist.ReduceOp.SUM)
+    F_total, U_total = float(fu[0]), float(fu[1])
+    own_t = torch.tensor([own], dtype=torch.float64, device=dev)
+    dist.broadcast(own_t, src=0)
+    plain_ms = float(own_t[0]) / K * 1e3           # rank 0's camera IS the shared stream: the plain single-GPU time of those frames
+    # ---- consolidation into a single GlobalModel (sm_rig_consolidate: all-gathers + per-slice cleanPoints, inside the core)
+    sm_global = capi.SurfelMap(capi.make_config(**cam, preprocess=0, device=local_rank,
+                                                max_sqrt_vertices=int(math.ceil(math.sqrt(world) * 5000))))
+    rig = smd.RigMapper(sm, smsh.TorchComm(device_index=local_rank), P)
+    rig.last = (frames[Wm + K - 1][1], frames[Wm + K - 1][2], frames[Wm + K - 1][3])     # the camera's latest view
+    rig.enable_native("rccl", bcast_id())
+    nranks_rig = sm.shard_rccl_nranks()
+    barrier()
+    g0 = time.perf_counter()
+    global_count, view_conflicts = rig.consolidate_native(sm_global)
+    torch.cuda.synchronize()
+    gather_ms = max_over_ranks((time.perf_counter() - g0) * 1e3)
+    sm.shard_rccl_finalize()
+    counts = sm.counts()
+    sm_global.close()
+    sm.close()
+    # ---- sharded leg: ONE stream (rank 0's camera) split over the ranks, bit-identical to one GPU (sm_shard_frame_device)
+    sharded_leg = None
+    if not args.no_sharded_leg:
+        ss = capi.SurfelMap(capi.make_config(**cam, **cfg))
+        shard = smsh.StreamShard(ss, rank, world, "rccl", bcast_id())
+        nranks_sh = ss.shard_rccl_nranks()
+        dsh = stage_frames(ss, shared, P)
+        gc.collect(); gc.disable()
+        for k in range(Wm):
+            ss.shard_frame_device(*dsh[k])
+        ss.sync()
+        barrier()
+        t0 = time.perf_counter()
+        for k in range(Wm, Wm + K):
+            ss.shard_frame_device(*dsh[k])
+        ss.sync()
+        torch.cuda.synchronize()
+        s_own = time.perf_counter() - t0
+        barrier()
+        gc.enable()
+        s_el = max_over_ranks(s_own)
+        sc = ss.counts()
+        chk = torch.tensor([sc["count"], sc["conflict_count"], sc["unstable_count"]], dtype=torch.int64, device=dev)
+        lo, hi = chk.clone(), chk.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        ss.shard_rccl_finalize()
+        ss.close()
+        del shard
+        sharded_leg = {"config": f"BASELINE configs[3]: ONE KITTI 1242x375 stream sharded over {world} GPUs (slot-addressed shards; per frame an "
+                                 "all-reduce(min) of the 3.7 MB key map and an all-reduce(sum) of the fused-pixel mask + 3 counters, RCCL called from the "
+                                 "HIP core on the frame's stream; deferred compaction between frames), bit-identical to one GPU",
+                       "value": K / s_el, "unit": "frames/s", "ms_per_step": s_el / K * 1e3, "scaling": "strong",
+                       "plain_single_gpu_ms_per_step": plain_ms, "sharded_over_plain": (s_el / K * 1e3) / plain_ms,
+                       "counters_identical_on_all_ranks": bool(torch.equal(lo, hi)), "surfels_end": int(sc["count"]),
+                       "plain_surfels_end_rank0": None, "rccl_nranks": nranks_sh}
+        c0 = torch.tensor([counts["count"]], dtype=torch.int64, device=dev)
+        dist.broadcast(c0, src=0)
+        sharded_leg["plain_surfels_end_rank0"] = int(c0[0])
+        sharded_leg["same_surfel_count_as_plain"] = int(c0[0]) == int(sc["count"])
+    dist.destroy_process_group()
+    if rank != 0:
+        return
+    emit({
+        "metric": METRIC, "value": world * K / elapsed, "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm,
+        "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"BASELINE configs[4] at the metric's image size: {world}-camera rig (yaw k*{360.0 / world:.0f} deg), one KITTI 1242x375 "
+                               f"stream per GPU, depth noise {args.noise_mm} mm, metricise+conflict+cull+splat+associate+fuse+append per frame; "
+                               "no collective inside a frame",
+                   "frames": f"{Wm}..{Wm + K - 1}",
+                   "multi_gpu": {"consolidation": "after the timed frames: every slice cleaned against all latest views (cleanPoints per view, the W*H "
+                                                  "conflict cap shared exactly across the slices), slices all-gathered in rank order into a single "
+                                                  "GlobalModel on every rank, inside the HIP core over RCCL (sm_rig_consolidate); not in `value`",
+                                 "consolidation_ms": gather_ms, "consolidation_ms_per_frame_if_every_K": gather_ms / K,
+                                 "global_model_surfels": int(global_count), "conflicts_per_view": [int(c) for c in view_conflicts]},
+                   "host_sync": "none inside the timed region", "surfels_end_rank0": int(counts["count"])},
+        "rccl": {"nranks": nranks_rig, "world_size": world, "backend": "RCCL bound by the HIP core (ncclCommInitRank / ncclCommCount); torch.distributed "
+                                                                         "only hands the communicator id round"},
+        "surfels_fused_per_sec": (F_total + U_total) / elapsed,
+        "fused_F": {"total": F_total, "per_sec": F_total / elapsed, "per_frame": F_total / (K * world)},
+        "new_U": {"total": U_total, "per_sec": U_total / elapsed, "per_frame": U_total / (K * world)},
+        "sharded_leg": sharded_leg,
+        "roofline": None, "cpu_baseline": None,       # N = 1 reports them (cpu_baseline: rank 0 at N = 1 only)
+        "gen_seconds": t_gen})
+
+
+# ------------------------------------------------------------------------------------------------
+# one rank: the metric's line with its legs
+# ------------------------------------------------------------------------------------------------
+def bench_single(args, cam, K, Wm, workers, emit):
+    hd = args.workload == "hd20m"
+    P = cam["width"] * cam["height"]
+    t0 = time.time()
+    n_steady = 0 if (hd or args.no_steady_leg) else args.steady_warmup + args.steady_steps
+    frames = make_frames(cam, max(Wm + K, n_steady), args.seed, args.noise_mm, workers)
+    t_gen = time.time() - t0
+    from surfelmapping_amd import capi
+    # this process creates several contexts one after the other; they never run at the same time: keep the default
+    # round-robin form of the compaction kernel (the library would switch to ticket order for contexts that share a GPU)
+    os.environ.setdefault("SM_COMPACT_TICKETS", "0")
+    base = dict(preprocess=args.preprocess, conflict_cap=0 if hd else 1, max_sqrt_vertices=10000 if hd else 5000,
+                compact_period=args.compact_period)
+    seed_model = synth.seeded_model(args.seed_surfels, tick=300, seed=args.seed) if hd else None
+    head = run_leg(capi, cam, frames, K, Wm, base, events=not args.no_events, seed_model=seed_model, seed_tick=300,
+                   mode="device_sync" if args.sync_every_frame else "device")
+    log, counts, tim = head["log"], head["counts"], head["tim"]
+    kern, roofline = None, None
+    if tim is not None:
+        kern, _, roofline = kernel_table(log, tim, P, K, Wm, args.compact_period, args.workload)
+        roofline["note"] = ("not byte-bound at this size: a frame touches ~60 MB; tools/pass_trace.py (DESIGN.md 4) accounts for the launch. "
+                            "hd_leg carries the same figures where the surfel pass IS the frame (20 M surfels)")
+    F_total, U_total = float(log["fused_count"].sum()), float(log["unstable_count"].sum())
+    elapsed = K / head["fps"]
+
+    legs = {}
+    if not hd and not args.no_steady_leg:
+        # the fair steady-state figure: the driver's 20-frame window holds one compaction, 100 frames hold six
+        r = run_leg(capi, cam, frames, args.steady_steps, args.steady_warmup, base, events=False)
+        legs["steady_leg"] = dict(leg_summary(r, args.steady_steps), config=f"the same stream, {args.steady_steps} frames after {args.steady_warmup}",
+                                  steps=args.steady_steps, warmup=args.steady_warmup)
+    if not hd and not args.no_fuse_leg:
+        # frames that actually fuse: 4 mm depth noise and fuse_thresh 0.05 (data.vert:177-208 carries the frame)
+        ff = make_frames(cam, Wm + K, args.seed, 4.0, workers)
+        r = run_leg(capi, cam, ff, K, Wm, dict(base, fuse_thresh=0.05), events=not args.no_events)
+        fl = dict(leg_summary(r, K), config="same KITTI trajectory and scene, depth noise 4 mm, fuse_thresh 0.05 (Config::surfelFuseDistanceThreshFactor)",
+                  fused_F_per_sec=float(r["log"]["fused_count"].sum()) / (r["ms"] * 1e-3 * K))
+        if r["tim"] is not None:
+            fk, _, froof = kernel_table(r["log"], r["tim"], P, K, Wm, args.compact_period, "kitti_fuse")
+            fl["kernels"] = fk
+            fl["roofline"] = {k: froof[k] for k in ("kernel", "achieved", "frac", "ms_per_launch", "alg_bytes_per_launch")}
+        legs["fuse_leg"] = fl
+    if not hd and not args.no_reference_path_leg:
+        # what the drop-in's default SurfelMapping::processFrame executes (facade/SurfelMapping.h -> sm_process_frame;
+        # /root/reference/src/SurfelMapping.cpp:122-156): three host images uploaded, p0a..p0e, the caller waits for the frame
+        pre = dict(base, preprocess=1)
+        rp = {"config": "preprocess = 1 (p0a..p0e), KITTI 1242x375, the same stream"}
+        r = run_leg(capi, cam, frames, K, Wm, pre, events=False, mode="host_sync")
+        rp["host_buffers_sync"] = dict(leg_summary(r, K), what="sm_process_frame: 2.8 MB H2D + one host wait per frame (the reference's semantics)")
+        if hasattr(capi.SurfelMap, "process_frame_async"):
+            r = run_leg(capi, cam, frames, K, Wm, pre, events=False, mode="host_async")
+            rp["host_buffers_async"] = dict(leg_summary(r, K), what="sm_process_frame_async: pinned staging, the H2D copy of frame f+1 overlaps frame f, no host wait")
+        r = run_leg(capi, cam, frames, K, Wm, pre, events=False, mode="device")
+        rp["device_resident_async"] = dict(leg_summary(r, K), what="sm_process_frame_device, frames staged in HBM, no host wait")
+        if "host_buffers_async" in rp:
+            rp["host_over_device"] = rp["host_buffers_async"]["ms_per_step"] / rp["device_resident_async"]["ms_per_step"]
+        legs["reference_path_leg"] = rp
+    if not hd and not args.no_hd_leg:
+        legs["hd_leg"] = hd_leg(args, capi, workers)
+
+    # ---- CPU baseline: the oracle over the very same frames (rank 0, N = 1 only), a bounded sample
+    cpu, cpu_all = None, None
+    if not args.no_cpu_baseline:
+        import oracle_lib as ol                  # checker / baseline only
+        ocfg = dict(preprocess=args.preprocess, conflict_cap=0 if hd else 1, max_sqrt_vertices=10000 if hd else 5000)
+        Kc = min(K, 3) if hd else min(K, args.cpu_frames)
+        v1, oc, _ = oracle_run(ol, cam, frames, Wm, Kc, ocfg, seed_model=seed_model, seed_tick=300)
+        same = None
+        if Kc == K:
+            same = all(oc[k] == counts[k] for k in ("count", "offset", "unstable_count", "fused_count", "conflict_count"))
+        cpu = {"value": v1, "unit": "frames/s", "cores": 1, "kind": "port",
+               "sample": f"the first {Kc} of the same {K} frames (after the same {Wm} warm-up frames), oracle/libsmo.so, 1 thread, "
+                         f"host {os.cpu_count()} logical CPUs", "final_counts_match_gpu": same}
+        try:
+            # all cores: the OpenMP build of the same oracle source (bit-identical results: tests/test_oracle_omp.py) on the CPU
+            # share of one GPU of this box (256 logical CPUs / 8 GPUs = 32)
+            nthr = max(1, min(os.cpu_count() or 1, int(os.environ.get("SM_BENCH_CPU_THREADS", "32"))))
+            os.environ["OMP_NUM_THREADS"] = str(nthr)
+            va, oac, _ = oracle_run(ol, cam, frames, Wm, Kc, ocfg, libpath=ol.OMP_LIB_PATH, seed_model=seed_model, seed_tick=300)
+            cpu_all = {"value": va, "unit": "frames/s", "cores": nthr, "kind": "port",
+                       "sample": f"the same {Kc} frames, oracle/libsmo_omp.so (OpenMP build of the same source), {nthr} threads",
+                       "final_counts_match_1_thread": all(oac[k] == oc[k] for k in oc)}
+            st = ol.stage_seconds(ol.OMP_LIB_PATH) if hasattr(ol, "stage_seconds") else None
+            if st:
+                cpu_all["seconds_per_stage"] = st
+        except Exception as e:               # the baseline is a report, never a reason to lose the GPU line
+            cpu_all = {"error": repr(e)}
+
+    out = {
+        "metric": ("frames/sec per GPU, 1920x1080 dense depth, >=20 M live surfels" if hd else METRIC),
+        "value": head["fps"], "unit": "frames/s", "n_gpus": 1, "steps": K, "warmup": Wm,
+        "ms_per_step": head["ms"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": (f"BASELINE configs[2]: 1920x1080 dense depth, model pre-seeded with {args.seed_surfels} surfels, conflict cap off, "
+                                if hd else "BASELINE configs[1]: KITTI 1242x375 synthetic street sequence, 0.8 m/frame, ")
+                               + f"depth noise {args.noise_mm} mm, metricise+conflict+cull+splat+associate+fuse+append per frame"
+                               + (" + depth pre-processing p0b..p0e" if args.preprocess else ""),
+                   "frames": f"{Wm}..{Wm + K - 1}", "multi_gpu": "single stream",
+                   "host_sync": "per frame" if args.sync_every_frame else "none inside the timed region",
+                   "compaction": (f"deferred: culled surfels keep their slots, every {args.compact_period}th cull compacts "
+                                  f"({int((log['n_static'] < log['n_slots']).sum()) if len(log) else 0} of {K} timed frames moved surfels)")
+                                 if args.compact_period > 1 else "every frame",
+                   "surfels_start": int(log["n_before"][0]) if len(log) else 0, "surfels_end": int(counts["count"])},
+        "surfels_fused_per_sec": (F_total + U_total) / elapsed,
+        # SURVEY 8d: F (measurements integrated into an existing surfel) and U (new surfels) separately.  With the reference's
+        # default fuse threshold 0.0 only bit-equal ray depths associate, so on a moving camera F ~ 0 and the figure above is
+        # append throughput; `fuse_leg` times the integration path with F > 0.
+        "fused_F": {"total": F_total, "per_sec": F_total / elapsed, "per_frame": F_total / K},
+        "new_U": {"total": U_total, "per_sec": U_total / elapsed, "per_frame": U_total / K},
+        "conflicts_per_frame": float(log["conflict_count"].mean()) if len(log) else 0.0,
+        "roofline": roofline,
+        "cpu_baseline": cpu,
+        "cpu_baseline_all_cores": cpu_all,
+        "kernels": kern,
+        "frame_ms_gpu_events": tim["run"] if tim else None,
+        "host_enqueue_ms_per_step": head["host_enqueue_ms"],
+        "event_overhead_ms": tim.get("event_overhead", 0.0) if tim else None,
+        "gen_seconds": t_gen,
+    }
+    out.update(legs)
+    emit(out)
+
+
+def hd_leg(args, capi, workers):
+    """BASELINE configs[2] inside the default line: 1920x1080, model pre-seeded with 20 M surfels, conflict cap off, 40 frames
+    after 5; its own roofline entries for k_surfel_pass and k_assoc_prep (the >= 40 % target lives here), PMC traffic from
+    profiles/traffic_hd20m_s40_w5.json; the first frames' counters checked against the all-core oracle."""
+    cam = synth.HD
+    P = cam["width"] * cam["height"]
+    K, Wm = args.hd_steps, args.hd_warmup
+    t0 = time.time()
+    frames = make_frames(cam, Wm + K, args.seed, args.noise_mm, workers)
+    seed_model = synth.seeded_model(args.seed_surfels, tick=300, seed=args.seed)
+    t_gen = time.time() - t0
+    cfg = dict(preprocess=0, conflict_cap=0, max_sqrt_vertices=10000, compact_period=args.compact_period)
+    r = run_leg(capi, cam, frames, K, Wm, cfg, events=not args.no_events, seed_model=seed_model, seed_tick=300)
+    out = dict(leg_summary(r, K), config=f"BASELINE configs[2]: 1920x1080 dense depth, {args.seed_surfels} seeded surfels (uniformly scattered), "
+                                         f"conflict cap off, depth noise {args.noise_mm} mm", steps=K, warmup=Wm, gen_seconds=t_gen)
+    if r["tim"] is not None:
+        kern, _, roof = kernel_table(r["log"], r["tim"], P, K, Wm, args.compact_period, "hd20m")
+        out["kernels"] = kern
+        out["roofline"] = roof
+        out["roofline_by_kernel"] = {n: {"achieved_GBs": kern[n]["GBs"], "frac": kern[n]["frac_of_hbm_peak"], "ms_per_launch": kern[n]["ms"],
+                                         "alg_MB_per_launch": kern[n]["MB"], "hbm_traffic_MB_per_launch": kern[n]["hbm_traffic_MB"]}
+                                     for n in ("k_surfel_pass", "k_assoc_prep", "k_compact") if n in kern}
+    if not args.no_cpu_baseline:
+        try:
+            import oracle_lib as ol
+            Kc = min(K, args.hd_cpu_frames)
+            nthr = max(1, min(os.cpu_count() or 1, int(os.environ.get("SM_BENCH_CPU_THREADS", "32"))))
+            os.environ["OMP_NUM_THREADS"] = str(nthr)
+            va, oc, seq = oracle_run(ol, cam, frames, Wm, Kc, dict(preprocess=0, conflict_cap=0, max_sqrt_vertices=10000),
+                                     libpath=ol.OMP_LIB_PATH, seed_model=seed_model, seed_tick=300, per_frame=True)
+            lg = r["log"][:Kc]
+            same = all(int(lg["n_after_cull"][k]) == seq[k]["offset"] and int(lg["unstable_count"][k]) == seq[k]["unstable_count"] and
+                       int(lg["fused_count"][k]) == seq[k]["fused_count"] and int(lg["conflict_count"][k]) == seq[k]["conflict_count"] and
+                       int(lg["visible_count"][k]) == seq[k]["visible_count"] for k in range(Kc))
+            out["cpu_baseline_all_cores"] = {"value": va, "unit": "frames/s", "cores": nthr, "kind": "port",
+                                             "sample": f"frames {Wm}..{Wm + Kc - 1} of the same stream on the same seeded model, oracle/libsmo_omp.so, {nthr} threads",
+                                             "final_counts_match_gpu": bool(same),
+                                             "checked": "offset, new, fused, conflict and index-map counts of every sampled frame against the GPU's frame log"}
+        except Exception as e:
+            out["cpu_baseline_all_cores"] = {"error": repr(e)}
+    return out
 
 
 def main():
@@ -289,28 +676,48 @@ def main():
     ap.add_argument("--noise-mm", type=float, default=15.0)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=40, help="frames of the CPU-oracle sample (bounded: ~1-2 s of one core each)")
     ap.add_argument("--workers", type=int, default=0, help="frame-generation processes (0 = auto; use 1 under rocprofv3)")
     ap.add_argument("--no-events", action="store_true", help="no HIP events inside frames (no per-kernel timings / roofline)")
     ap.add_argument("--preprocess", type=int, default=0, help="1: run the full depth pre-processing chain p0a..p0e per frame")
     ap.add_argument("--workload", choices=["kitti", "hd20m"], default="kitti",
-                    help="kitti = BASELINE configs[1] (default, the metric's config); hd20m = configs[2]: 1920x1080 "
+                    help="kitti = BASELINE configs[1] (default, the metric's config); hd20m = configs[2] as the whole run: 1920x1080 "
                          "dense depth, model pre-seeded with 20 M surfels (HBM-bandwidth stress)")
     ap.add_argument("--seed-surfels", type=int, default=20_000_000)
-    ap.add_argument("--mode", choices=["rig", "sharded"], default="rig",
-                    help="N>1: 'rig' = one camera stream per GPU + all-gather into one GlobalModel (weak scaling); "
-                         "'sharded' = ONE stream split over the GPUs, bit-identical to 1 GPU (strong scaling)")
-    ap.add_argument("--force-dist", action="store_true", help="rehearse the multi-GPU code path with WORLD_SIZE=1")
-    ap.add_argument("--shard-form", choices=["stream", "staged"], default="stream",
-                    help="--mode sharded: in-stream form (RCCL from the HIP core; default) or round 1's per-stage form driven from Python")
-    ap.add_argument("--no-rccl", action="store_true", help="--mode sharded with one rank: no communicator (the core's identity path) instead of RCCL")
-    ap.add_argument("--no-plain-leg", action="store_true", help="--mode sharded: skip the plain single-GPU run of the same frames on rank 0")
+    ap.add_argument("--force-dist", action="store_true", help="rehearse the multi-GPU code path with one rank (torch.distributed + RCCL up)")
+    ap.add_argument("--no-sharded-leg", action="store_true", help="N ranks: skip the ONE-stream-over-N-GPUs leg (configs[3])")
     ap.add_argument("--compact-period", type=int, default=16,
                     help="deferred compaction: culled surfels keep their slots, every Nth cull squeezes them out (1: every frame)")
-    ap.add_argument("--no-fuse-leg", action="store_true",
-                    help="skip the second, labelled leg (same trajectory, depth noise 4 mm, fuse_thresh 0.05: frames that actually fuse)")
+    ap.add_argument("--no-fuse-leg", action="store_true")
+    ap.add_argument("--no-steady-leg", action="store_true")
+    ap.add_argument("--no-reference-path-leg", action="store_true")
+    ap.add_argument("--no-hd-leg", action="store_true")
+    ap.add_argument("--only-headline", action="store_true", help="no extra legs (profiling runs)")
+    ap.add_argument("--steady-steps", type=int, default=100)
+    ap.add_argument("--steady-warmup", type=int, default=10)
+    ap.add_argument("--hd-steps", type=int, default=40)
+    ap.add_argument("--hd-warmup", type=int, default=5)
+    ap.add_argument("--hd-cpu-frames", type=int, default=2)
     ap.add_argument("--sync-every-frame", action="store_true",
                     help="reference semantics: host waits for the counters after every frame")
+    ap.add_argument("--launch-dry-run", action="store_true", help="start the ranks, rendezvous over gloo, print who is who; no GPU work")
+    ap.add_argument("--launch-timeout", type=float, default=1500.0)
     args = ap.parse_args()
+    if args.only_headline:
+        args.no_fuse_leg = args.no_steady_leg = args.no_reference_path_leg = args.no_hd_leg = True
+
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return launch_ranks(args, sys.argv[1:])           # before anything touches a GPU (nothing above imports torch or the core)
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: WORLD_SIZE={world} but --gpus {args.gpus}: refusing to measure another configuration than the one asked for")
+    if args.launch_dry_run:
+        return dry_run_rank(rank, world, local_rank)
 
     # ONE JSON line on stdout: native libraries (RCCL prints a version banner to stdout when a communicator is created)
     # write to file descriptor 1 directly, so fd 1 is pointed at stderr for the whole run and the line goes to the real stdout
@@ -321,264 +728,12 @@ def main():
     def emit(obj):
         os.write(real_stdout, (json.dumps(obj) + "\n").encode())
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"WORLD_SIZE={world} but --gpus {args.gpus}")
     K, Wm = args.steps, max(args.warmup, 2)     # call 1 only sets the reference frame
-    hd = args.workload == "hd20m"
-    cam = synth.HD if hd else synth.KITTI
-    P = cam["width"] * cam["height"]
-    n_frames = Wm + K
-
-    # ---- synthetic frames (before anything touches the GPU; forked workers never do)
-    t0 = time.time()
-    workers = args.workers or max(1, min(8, (os.cpu_count() or 2) // max(world, 1)))
-    shard = args.mode == "sharded" and (world > 1 or args.force_dist)
-    frames = make_frames(cam, n_frames, args.seed, args.noise_mm, workers, 0 if shard else rank, 1 if shard else world)
-    t_gen = time.time() - t0
-
-    dist = None
+    cam = synth.HD if args.workload == "hd20m" else synth.KITTI
+    workers = args.workers or max(1, min(16, (os.cpu_count() or 2) // max(world, 1)))
     if world > 1 or args.force_dist:
-        # torch first: its HIP runtime must be the one the core binds to (one runtime per process)
-        import torch
-        import torch.distributed as dist_mod
-        dist = dist_mod
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if world == 1:                     # --force-dist outside torchrun: a one-rank rendezvous of its own
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", "29533")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-
-    from surfelmapping_amd import capi
-    if dist and args.mode == "sharded":
-        return bench_sharded(args, dist, torch, capi, cam, frames, rank, world, local_rank, K, Wm, t_gen, emit)
-    # hd20m: the conflict cap is off for the stress benchmark (SURVEY.md A13 says to state which)
-    mk = lambda timing: capi.SurfelMap(capi.make_config(**cam, preprocess=args.preprocess, device=local_rank,
-                                                        enable_timing=timing, conflict_cap=0 if hd else 1,
-                                                        max_sqrt_vertices=10000 if hd else 5000,
-                                                        compact_period=args.compact_period))
-    # this process creates a second (instrumented) context later, but the two never run at the same time: keep the
-    # default round-robin form of the compaction kernel for both (the library would switch to ticket order otherwise)
-    os.environ.setdefault("SM_COMPACT_TICKETS", "0")
-    sm = mk(0)                                    # raises without a GPU: no CPU fallback
-    # A second context replays the same frames with HIP events between the kernels (the events cost ~25 us per frame,
-    # so they stay out of the run that produces `value`).  It is created AFTER the timed run: the timed context is then
-    # the only one on its GPU, as in deployment (contexts that share a GPU chain their compaction kernels).
-    sm_ev = None
-
-    # ---- stage every frame in HBM
-    dptr = []
-    for rgb, depth, sem, pose in frames:
-        dr, dd, ds = sm.device_alloc(P * 3), sm.device_alloc(P * 2), sm.device_alloc(P)
-        sm.device_upload(dr, rgb); sm.device_upload(dd, depth); sm.device_upload(ds, sem)
-        dptr.append((dr, dd, ds, pose))
-
-    seed_model = None
-    if hd:
-        seed_model = synth.seeded_model(args.seed_surfels, tick=300, seed=args.seed)
-        sm.upload_model(seed_model)
-        sm.set_tick(300)
-
-    def run(ctx, lo, hi):
-        for k in range(lo, hi):
-            ctx.process_frame_device(*dptr[k])
-            if args.sync_every_frame:
-                ctx.sync()
-
-    sm_global = None
-    if dist:
-        from surfelmapping_amd import dist as smd
-        # warm the collective path (RCCL communicator setup is not part of a frame)
-        g0, c0 = smd.gather_model_device(sm, local_rank)
-        del g0
-
-    def barrier():
-        if dist:
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    gc.collect(); gc.disable()                    # no collector pause inside the timed region (~45 ms with torch imported), and none
-    run(sm, 0, Wm)                                # between the warm-up and t0 either (the GPU would clock down: +130 us on the first frames)
-    sm.sync()
-    barrier()
-    t0 = time.perf_counter()
-    run(sm, Wm, Wm + K)
-    t_enq = time.perf_counter() - t0              # host time to enqueue the K frames (no waiting inside)
-    sm.sync()
-    if dist:
-        torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0            # this rank's K frames are complete (MAX over the ranks is taken below)
-    barrier()                                     # the closing barrier + synchronize; its own latency (~0.4 ms) is not K frames' work
-    gc.enable()
-    # Consolidation into a single GlobalModel (BASELINE configs[4]): an end-of-run exchange, not part of a frame --
-    # the per-frame hot path of a camera touches only its own slice -- so it is timed separately.
-    global_count, gather_ms = None, None
-    if dist:
-        from surfelmapping_amd import sharded as smsh
-        sm_global = capi.SurfelMap(capi.make_config(**cam, preprocess=0, device=local_rank, max_sqrt_vertices=10000 if (hd or world > 2) else 5000))
-        rig = smd.RigMapper(sm, smsh.TorchComm(device_index=local_rank), P)
-        rig.last = (frames[Wm + K - 1][1], frames[Wm + K - 1][2], frames[Wm + K - 1][3])     # the camera's latest view
-        # the consolidation runs inside the HIP core (sm_rig_consolidate), its exchanges on RCCL bound by the core itself;
-        # torch.distributed only hands the communicator id round
-        ids = [capi.rccl_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(ids, src=0)
-        rig.enable_native("rccl", ids[0])
-        barrier()
-        g0 = time.perf_counter()
-        # every slice cleaned against every camera's latest view (cleanPoints per view), then the slices gathered in rank order
-        global_count, view_conflicts = rig.consolidate_native(sm_global)
-        barrier()
-        gather_ms = (time.perf_counter() - g0) * 1e3
-        sm.shard_rccl_finalize()
-    log = sm.read_frame_log(K)
-    counts = sm.counts()
-
-    # ---- the same K frames on the instrumented context: per-kernel durations for the roofline
-    tim = {k: 0.0 for k in ("k_prep", "k_conflict", "k_scan_cull", "k_compact", "k_associate", "k_scan_new", "k_append", "run")}
-    if not args.no_events:
-        sm_ev = mk(1)
-        if hd:
-            sm_ev.upload_model(seed_model)
-            sm_ev.set_tick(300)
-        run(sm_ev, 0, Wm)
-        sm_ev.sync()
-        sm_ev.timings()                           # drop warm-up samples
-        run(sm_ev, Wm, Wm + K)
-        sm_ev.sync()
-        tim = sm_ev.timings()
-        assert sm_ev.counts()["count"] == counts["count"], "instrumented pass diverged from the timed pass"
-
-    if dist:
-        dev = torch.device("cuda", local_rank)
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t[0])
-        fu = torch.tensor([float(log["fused_count"].sum()), float(log["unstable_count"].sum())], dtype=torch.float64, device=dev)
-        dist.all_reduce(fu, op=dist.ReduceOp.SUM)
-        F_total, U_total = float(fu[0]), float(fu[1])
-        dist.destroy_process_group()
-    else:
-        F_total, U_total = float(log["fused_count"].sum()), float(log["unstable_count"].sum())
-    fused_total = F_total + U_total
-
-    if rank != 0:
-        return
-
-    # ---- roofline of the dominant kernel (live HIP-event durations, algorithmic bytes)
-    kern, launches, roofline = kernel_table(log, tim, P, K, args)
-
-    # ---- second, labelled leg: the same trajectory with 4 mm depth noise and fuse_thresh = 0.05, so that the in-place
-    # integration (depth/colour/normal/radius update, data.vert:177-208) is timed with F > 0; `value` stays the default config
-    fuse_leg = None
-    if not hd and dist is None and not args.no_fuse_leg:
-        ff = make_frames(cam, n_frames, args.seed, 4.0, workers)
-        fv, fms, flog, fcounts, ftim = run_simple_leg(capi, cam, ff, K, Wm, dict(preprocess=args.preprocess, device=local_rank, conflict_cap=1,
-                                                                                 fuse_thresh=0.05, compact_period=args.compact_period), args)
-        fuse_leg = {"config": "same KITTI trajectory and scene, depth noise 4 mm, fuse_thresh 0.05 (Config::surfelFuseDistanceThreshFactor)",
-                    "value": fv, "unit": "frames/s", "ms_per_step": fms,
-                    "fused_F_per_frame": float(flog["fused_count"].mean()), "new_U_per_frame": float(flog["unstable_count"].mean()),
-                    "fused_F_per_sec": float(flog["fused_count"].sum()) / (fms * 1e-3 * K),
-                    "conflicts_per_frame": float(flog["conflict_count"].mean()), "surfels_end": int(fcounts["count"])}
-        if ftim is not None:
-            fk, _, froof = kernel_table(flog, ftim, P, K, args, workload="kitti_fuse")
-            fuse_leg["kernels"] = fk
-            fuse_leg["roofline"] = {k: froof[k] for k in ("kernel", "achieved", "frac", "ms_per_launch", "alg_bytes_per_launch")}
-
-    # ---- CPU baseline: the oracle over the very same frames (rank 0, N=1 only)
-    cpu, cpu_all = None, None
-    if not args.no_cpu_baseline and dist is None:
-        import oracle_lib as ol                  # checker / baseline only
-        o = ol.Oracle(ol.make_config(**cam, preprocess=args.preprocess, conflict_cap=0 if hd else 1,
-                                     max_sqrt_vertices=10000 if hd else 5000))
-        Kc = K
-        if hd:                                   # bounded sample: a 20 M-surfel frame takes seconds on one core
-            o.upload_model(seed_model); o.set_tick(300)
-            Kc = min(K, 3)
-        for k in range(Wm):
-            o.process_frame(*frames[k])
-        c0 = time.perf_counter()
-        for k in range(Wm, Wm + Kc):
-            o.process_frame(*frames[k])
-        c_el = time.perf_counter() - c0
-        oc = o.counts()
-        same = (Kc == K) and all(oc[k] == counts[k] for k in ("count", "offset", "unstable_count", "fused_count", "conflict_count"))
-        # all cores: the OpenMP build of the same oracle source (bit-identical results: tests/test_oracle_omp.py), on the
-        # CPU share of one GPU of this box (16 hardware threads of 256), same frames
-        cpu_all = None
-        try:
-            nthr = max(1, min(os.cpu_count() or 1, int(os.environ.get("SM_BENCH_CPU_THREADS", "16"))))
-            os.environ["OMP_NUM_THREADS"] = str(nthr)
-            oa = ol.Oracle(ol.make_config(**cam, preprocess=args.preprocess, conflict_cap=0 if hd else 1,
-                                          max_sqrt_vertices=10000 if hd else 5000), libpath=ol.OMP_LIB_PATH)
-            if hd:
-                oa.upload_model(seed_model); oa.set_tick(300)
-            for k in range(Wm):
-                oa.process_frame(*frames[k])
-            a0 = time.perf_counter()
-            for k in range(Wm, Wm + Kc):
-                oa.process_frame(*frames[k])
-            a_el = time.perf_counter() - a0
-            oac = oa.counts()
-            cpu_all = {"value": Kc / a_el, "unit": "frames/s", "cores": nthr, "kind": "port",
-                       "sample": f"the same {Kc} frames, oracle/libsmo_omp.so (OpenMP build of the same source), {nthr} threads",
-                       "final_counts_match_1_thread": all(oac[k] == oc[k] for k in oc)}
-            oa.close()
-        except Exception as e:               # the baseline is a report, never a reason to lose the GPU line
-            cpu_all = {"error": repr(e)}
-        cpu = {"value": Kc / c_el, "unit": "frames/s", "cores": 1, "kind": "port",
-               "sample": f"the first {Kc} of the same {K} frames (after the same {Wm} warm-up frames), oracle/libsmo.so, 1 thread, "
-                         f"host {os.cpu_count()} logical CPUs", "final_counts_match_gpu": bool(same) if Kc == K else None}
-
-    out = {
-        "metric": ("frames/sec per GPU, 1920x1080 dense depth, >=20 M live surfels" if hd else
-                   "frames/sec per GPU, 1242x375 KITTI-shaped RGB-D+semantic, full associate+fuse+merge"),
-        "value": world * K / elapsed,
-        "unit": "frames/s",
-        "n_gpus": world,
-        "steps": K,
-        "warmup": Wm,
-        "ms_per_step": elapsed / K * 1e3,
-        "higher_is_better": True,
-        "scaling": "weak",
-        "vs_baseline": None,
-        "dtype": "f32",
-        "data": "synthetic",
-        "config": {"workload": (f"BASELINE configs[2]: 1920x1080 dense depth, model pre-seeded with {args.seed_surfels} surfels, conflict cap off, "
-                                if hd else "BASELINE configs[1]: KITTI 1242x375 synthetic street sequence, 0.8 m/frame, ")
-                               + f"depth noise {args.noise_mm} mm, metricise+conflict+cull+splat+associate+fuse+append per frame"
-                               + (" + depth pre-processing p0b..p0e" if args.preprocess else ""),
-                   "frames": f"{Wm}..{Wm + K - 1}", "multi_gpu": (f"{world}-camera rig, one stream per GPU; consolidation after the timed frames: every slice cleaned "
-                                 f"against all {world} latest views (cleanPoints per view, {sum(view_conflicts)} conflicts), slices gathered in rank order into a single "
-                                 f"GlobalModel of {global_count} surfels, all inside the HIP core over RCCL (sm_rig_consolidate: {gather_ms:.1f} ms, not in `value`)") if dist else "single stream",
-                   "host_sync": "per frame" if args.sync_every_frame else "none inside the timed region",
-                   "frame_form": ("four launches per frame" if (args.preprocess or args.sync_every_frame or os.environ.get("SM_DEFER_ASSOC", "1") == "0") else
-                                  "three launches per frame (k_assoc_prep = the previous frame's association + this frame's image "
-                                  "preparation, then k_surfel_pass, k_pass_fixup; DESIGN.md 4)"),
-                   "compaction": (f"deferred: culled surfels keep their slots, every {args.compact_period}th cull compacts "
-                                  f"({int((log['n_static'] < log['n_slots']).sum()) if len(log) else 0} of {K} timed frames moved surfels)")
-                                 if args.compact_period > 1 else "every frame",
-                   "surfels_start": int(log["n_before"][0]) if len(log) else 0, "surfels_end": int(counts["count"])},
-        "surfels_fused_per_sec": fused_total / elapsed,
-        # F (measurements integrated into an existing surfel) and U (new surfels) separately.  With the reference's
-        # default fuse threshold 0.0 only bit-equal ray depths associate, so on a moving camera F ~ 0 and the figure above is
-        # append throughput; `fuse_leg` below times the integration path with F > 0.
-        "fused_F": {"total": F_total, "per_sec": F_total / elapsed, "per_frame": F_total / (K * world)},
-        "new_U": {"total": U_total, "per_sec": U_total / elapsed, "per_frame": U_total / (K * world)},
-        "conflicts_per_frame": float(log["conflict_count"].mean()) if len(log) else 0.0,
-        "fuse_leg": fuse_leg,
-        "roofline": roofline,
-        "cpu_baseline": cpu,
-        "cpu_baseline_all_cores": cpu_all if cpu is not None else None,
-        "kernels": kern,
-        "frame_ms_gpu_events": tim["run"],
-        "host_enqueue_ms_per_step": t_enq / K * 1e3,
-        "event_overhead_ms": tim.get("event_overhead", 0.0),
-        "gen_seconds": t_gen,
-    }
-    emit(out)
+        return bench_ranks(args, cam, rank, world, local_rank, K, Wm, workers, emit)
+    return bench_single(args, cam, K, Wm, workers, emit)
 
 
 if __name__ == "__main__":

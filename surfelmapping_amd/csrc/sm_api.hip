@@ -360,6 +360,7 @@ struct sm_ctx {
     void *ss_user = nullptr;
     void *ss_comm = nullptr;           // ncclComm_t when the built-in RCCL binding is used
     uint64_t *d_galive = nullptr, *d_new_alive = nullptr, *d_gmask = nullptr;
+    uint64_t *d_capx = nullptr;        // the conflict-cap exchange of a sharded frame: total | quarter-tile counts | conflict masks (k_shard_cap_pack)
     uint32_t *d_ss_info = nullptr;
     // deferred association (k_assoc_prep): the association of an asynchronous frame is held back until the next frame's images
     // arrive and then shares that frame's k_prep launch (three launches per frame instead of four)
@@ -521,8 +522,7 @@ int take_error(sm_ctx *s)
         HIPCK(hipMemcpyAsync(&s->d_state->error, &s->h_state->error, sizeof(int32_t), hipMemcpyHostToDevice, s->stream));
         HIPCK(hipStreamSynchronize(s->stream));
         g_err = e == SM_E_CAPACITY ? "model capacity (MAX_VERTICES) exceeded; frame's new surfels dropped"
-              : e == SM_E_UNSUPPORTED ? "sharded frame with more than W*H conflicts over all ranks: the reference's conflict cap would truncate them in "
-                                        "global surfel order, which a sharded cull does not reproduce"
+              : e == SM_E_UNSUPPORTED ? "unsupported operation flagged on the device"
               : "device-side error";
         return e;
     }
@@ -1468,7 +1468,7 @@ void sm_destroy(sm_ctx *s)
     (void)hipFree(s->d_tile_cnt); (void)hipFree(s->d_tile_allow); (void)hipFree(s->d_tile_keep); (void)hipFree(s->d_tile_flag); (void)hipFree(s->d_group_tot); (void)hipFree(s->d_group_base); (void)hipFree(s->d_tb); (void)hipFree(s->d_tile_flags); (void)hipFree(s->d_conf_part); (void)hipFree(s->d_compact_part); (void)hipFree(s->d_lazy_part); (void)hipFree(s->d_conf_sub); (void)hipFree(s->d_fix_part); (void)hipFree(s->d_blk_cand); (void)hipFree(s->d_grp_cand); (void)hipFree(s->d_frame_sub); (void)hipFree(s->d_wave_cnt); (void)hipFree(s->d_undo); (void)hipFree(s->d_prep_part);
     (void)hipFree(s->d_validmask); (void)hipFree(s->d_fusedmask); (void)hipFree(s->d_blk_prefix); (void)hipFree(s->d_desc); (void)hipFree(s->d_blk_cnt);
     (void)hipFree(s->d_seg_lstart); (void)hipFree(s->d_seg_gbase); (void)hipFree(s->d_gseg_base); (void)hipFree(s->d_seg_keep);
-    (void)hipFree(s->d_galive); (void)hipFree(s->d_new_alive); (void)hipFree(s->d_gmask); (void)hipFree(s->d_ss_info);
+    (void)hipFree(s->d_galive); (void)hipFree(s->d_new_alive); (void)hipFree(s->d_gmask); (void)hipFree(s->d_ss_info); (void)hipFree(s->d_capx);
     if (s->d_export) (void)hipFree(s->d_export);
     for (void *p : s->user_allocs) (void)hipFree(p);
     if (s->ev_ok)
@@ -2352,7 +2352,8 @@ int sm_shard_stream_configure(sm_ctx *s, int rank, int world)
     }
     if ((rc = alloc_set(s->M.s[1], s->cap))) return rc;                        // staging set of the sharded compaction
     if ((rc = dalloc(&s->d_galive, s->alive_words)) || (rc = dalloc(&s->d_new_alive, s->alive_words)) ||
-        (rc = dalloc(&s->d_gmask, (size_t)(s->P + 63) / 64 + 4)) || (rc = dalloc(&s->d_ss_info, 4)))
+        (rc = dalloc(&s->d_gmask, (size_t)(s->P + 63) / 64 + 4)) || (rc = dalloc(&s->d_ss_info, 4)) ||
+        (rc = dalloc(&s->d_capx, (size_t)1 + (size_t)(2 + TILE_WORDS) * s->dead_tiles)))
         return rc;
     HIPCK(hipMemset(s->d_ss_info, 0, 16));
     s->ss_on = true; s->ss_rank = rank; s->ss_world = world; s->ss_frames = 0;
@@ -2465,6 +2466,21 @@ int sm_shard_frame_device(sm_ctx *s, const uint8_t *d_rgb, const uint16_t *d_dep
     if (s->ev_ok) { s->ev_compacted[s->ev_frames % EV_RING] = false; s->ev_one_pass[s->ev_frames % EV_RING] = true; s->ev_direct[s->ev_frames % EV_RING] = true; }
     if (s->n_prep_blocks == 0) { g_err = "internal: sharded frame without tile flags from k_prep"; return SM_E_ARG; }
     if ((rc = launch_surfel_pass(s, fp, true, true))) return rc;
+    // The W*H conflict cap acts in surfel order over ALL ranks: exchange the conflict masks and take this rank's surplus back
+    // before anything reads the key map (k_shard_cap_pack / k_shard_cap_repair).  Conflicts <= surfels, so a model with no
+    // more slots than pixels cannot reach the cap; the bound is the host's, the same on every rank.
+    if (s->cfg.conflict_cap && (uint64_t)s->count_bound > (uint64_t)s->P) {
+        const uint32_t tbnd = (uint32_t)std::min<uint64_t>(((uint64_t)s->count_bound + TILE - 1) / TILE, s->dead_tiles);
+        const int gp = (int)std::min<uint32_t>(std::max<uint32_t>((tbnd * (uint32_t)TILE_WORDS + 255u) / 256u, 1u), 1024u);
+        hipLaunchKernelGGL(k_shard_cap_pack, dim3(gp), dim3(256), 0, s->stream, s->d_state, s->d_wave_cnt, s->d_cm,
+                           s->d_conf_sub + SUB_SET * s->conf_sub_set, s->d_capx, tbnd);
+        HIPCK(hipGetLastError());
+        if ((rc = ss_collective(s, s->d_capx, s->d_capx, (size_t)1 + (size_t)(2 + TILE_WORDS) * tbnd, SM_COLL_SUM))) return rc;
+        hipLaunchKernelGGL(k_shard_cap_repair, dim3(std::min<uint32_t>(std::max<uint32_t>(tbnd, 1u), (uint32_t)MAX_GRID)), dim3(256), 0, s->stream, s->M,
+                           s->d_state, fp, s->d_capx, tbnd, (uint32_t)s->P, s->d_wave_cnt, s->d_dm /* km */, s->d_tile_flags, s->d_alive,
+                           s->d_tile_dead, s->d_keyT, s->d_undo, s->d_tb);
+        HIPCK(hipGetLastError());
+    }
     if ((rc = ss_collective(s, s->d_keyT, s->d_keyT, (size_t)s->P, SM_COLL_MIN))) return rc;
     ShardArgs sh;
     sh.validmask = s->d_validmask; sh.ownmask = s->d_fusedmask; sh.gmask = s->d_gmask; sh.nwords = (uint32_t)((s->P + 63) / 64);

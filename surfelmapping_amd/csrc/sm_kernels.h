@@ -275,10 +275,11 @@ __device__ __forceinline__ void shard_settle_body(const ShardSettle &a, uint32_t
     }
     if (blk == 0u && tid == 0u) {
         const uint64_t conf = a.gmask[a.nwords], vis = a.gmask[a.nwords + 1], kill = a.gmask[a.nwords + 2];
-        a.st->conflict_count = (uint32_t)conf;
+        // (the cap itself was applied before the association -- k_shard_cap_repair, with conflict ordinals over ALL ranks -- so
+        //  the counters that arrive here are the effective ones; conflictCount saturates like the reference's query)
+        a.st->conflict_count = (uint32_t)(conf > (uint64_t)a.cap_pixels ? (uint64_t)a.cap_pixels : conf);
         a.st->visible_count = (uint32_t)vis;
         a.st->n_kill = (uint32_t)kill;
-        if (conf > (uint64_t)a.cap_pixels) a.st->error = -3;      // SM_E_UNSUPPORTED: the conflict cap would bind
     }
     if (lane == 0 && in) {
         const uint32_t nf = (uint32_t)__popcll(gw & vw), nn = (uint32_t)__popcll(vw & ~gw);
@@ -2951,6 +2952,133 @@ __global__ __launch_bounds__(PIX_BLOCK) void k_assoc_prep(AssocArgs a, PrepArgs 
     ShardArgs none;
     none.validmask = nullptr; none.ownmask = nullptr; none.gmask = nullptr; none.nwords = 0u; none.owner = 1;
     associate_direct_block<false, PAIR>(a, none, blockIdx.x);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Slot-addressed sharding: the W*H conflict cap (src/GlobalModel.cpp:54-57), exactly.  Only the first W*H
+// conflicts in surfel order take effect, and with the surfels spread over the ranks that order runs across ranks: a slot's
+// conflict ordinal needs the conflicts of every rank in the slots below it.  k_surfel_pass has (speculatively) applied every
+// conflict of this rank and left cm / km / undo / the quarter-tile counts, as on one GPU; the ranks then sum-reduce
+//   x[0]                     conflicts of the frame
+//   x[1 + 2 t .. 1 + 2 t + 1]   tile t's four quarter counts (two per word)
+//   x[1 + 2 T + w]           conflict mask of word w            (T, 16 T words: the host's slot bound, equal on all ranks)
+// -- slots have one owner, so the sum of the masks is their union -- and k_shard_cap_repair takes this rank's surplus
+// back like k_pass_fixup's repair does, with ordinals from the reduced buffer: confidences restored from the undo plane,
+// victims resurrected and drawn into the (still local) key map, counters corrected, BEFORE the key-map exchange and the
+// association.  One all-reduce of 144 bytes per 1024 slots; the host skips it while the model has no more slots than pixels.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_shard_cap_pack(const DevState *__restrict__ st, const uint4 *__restrict__ wave_cnt,
+                                                        const uint64_t *__restrict__ cm, const uint32_t *__restrict__ conf_sub,
+                                                        uint64_t *__restrict__ x, uint32_t tiles_bound)
+{
+    const uint32_t N = st->count;
+    const uint32_t ntiles = (N + TILE - 1) / TILE;
+    const uint32_t gid = blockIdx.x * 256u + threadIdx.x, gsz = gridDim.x * 256u;
+    if (blockIdx.x == 0 && threadIdx.x < 64) {
+        const uint32_t tot = wave_sum_u32(conf_sub[threadIdx.x * SUB_STRIDE]);
+        if (threadIdx.x == 0) x[0] = tot;
+    }
+    for (uint32_t w = gid; w < tiles_bound * (uint32_t)TILE_WORDS; w += gsz) {
+        const uint32_t t = w / TILE_WORDS, qtr = (w % TILE_WORDS) / 4u;
+        uint64_t m = 0ull;
+        uint4 c = make_uint4(0u, 0u, 0u, 0u);
+        if (t < ntiles) {
+            c = wave_cnt[t];                      // (zero for the tiles the pass skipped: their cm words are stale)
+            const uint32_t cq = qtr == 0 ? c.x : qtr == 1 ? c.y : qtr == 2 ? c.z : c.w;
+            if (cq) m = cm[w];
+        }
+        x[1 + 2 * (size_t)tiles_bound + w] = m;
+        if ((w % TILE_WORDS) == 0u) {
+            x[1 + 2 * (size_t)t] = (uint64_t)c.x | ((uint64_t)c.y << 32);
+            x[2 + 2 * (size_t)t] = (uint64_t)c.z | ((uint64_t)c.w << 32);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_shard_cap_repair(Model M, DevState *__restrict__ st, FrameParams fp, const uint64_t *__restrict__ x,
+                                                          uint32_t tiles_bound, uint32_t cap, const uint4 *__restrict__ wave_cnt,
+                                                          const uint64_t *__restrict__ km, const uint8_t *__restrict__ tile_flags,
+                                                          uint64_t *__restrict__ alive, uint32_t *__restrict__ tile_dead,
+                                                          uint64_t *__restrict__ keyT, const float *__restrict__ undo, uint32_t *__restrict__ tb)
+{
+    if (x[0] <= (uint64_t)cap) return;                   // the cap does not bind (nearly every frame): nothing to take back
+    __shared__ uint32_t s_c[4], s_a[4], s_b[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t N = st->count;
+    const uint32_t ntiles = (N + TILE - 1) / TILE;
+    const uint32_t nwg = gridDim.x, wi = blockIdx.x;
+    const SurfelSet set = M.s[st->cur];
+    const uint64_t *__restrict__ xq = x + 1, *__restrict__ xm = x + 1 + 2 * (size_t)tiles_bound;
+    auto tile_conf = [&](uint32_t t) { const uint64_t a = xq[2 * (size_t)t], b = xq[2 * (size_t)t + 1]; return (uint32_t)a + (uint32_t)(a >> 32) + (uint32_t)b + (uint32_t)(b >> 32); };
+    uint32_t cpre = 0;                                   // conflicts (all ranks) in the tiles below this workgroup's current one
+    {
+        uint32_t p = 0;
+        for (uint32_t t = threadIdx.x; t < min(wi, ntiles); t += 256u) p += tile_conf(t);
+        p = wave_sum_u32(p);
+        if (lane == 0) s_c[wave] = p;
+        __syncthreads();
+        cpre = s_c[0] + s_c[1] + s_c[2] + s_c[3];
+        __syncthreads();
+    }
+    uint32_t vis = 0, resurrected = 0;
+    for (uint32_t tile = wi; tile < ntiles; tile += nwg) {
+        const uint64_t qa = xq[2 * (size_t)tile], qb = xq[2 * (size_t)tile + 1];
+        const uint32_t g0 = (uint32_t)qa, g1 = (uint32_t)(qa >> 32), g2 = (uint32_t)qb, g3 = (uint32_t)(qb >> 32);
+        const uint32_t nconf = g0 + g1 + g2 + g3, tile_pre = cpre;
+        {   // advance the prefix to this workgroup's next tile
+            uint32_t p = 0;
+            for (uint32_t t = tile + threadIdx.x; t < min(tile + nwg, ntiles); t += 256u) p += tile_conf(t);
+            p = wave_sum_u32(p);
+            __syncthreads();
+            if (lane == 0) s_c[wave] = p;
+            __syncthreads();
+            cpre += s_c[0] + s_c[1] + s_c[2] + s_c[3];
+        }
+        if (nconf == 0u || tile_pre + nconf <= cap) continue;              // every conflict of the tile is effective
+        const uint4 own4 = wave_cnt[tile];
+        const uint32_t own_q = wave == 0 ? own4.x : wave == 1 ? own4.y : wave == 2 ? own4.z : own4.w;     // this rank's conflicts in the wave's quarter
+        const bool nosplat = (tile_flags[tile] & 2u) != 0u;
+        uint32_t wpre = tile_pre + (wave > 0 ? g0 : 0u) + (wave > 1 ? g1 : 0u) + (wave > 2 ? g2 : 0u);
+        uint32_t res_wave = 0;
+        const uint32_t vis_tile = vis;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const uint32_t word = tile * TILE_WORDS + (uint32_t)wave * 4u + (uint32_t)r;
+            if ((uint64_t)word * 64u >= N) break;                             // wave-uniform
+            const uint64_t cg = xm[word];                                     // conflicts of this word over all ranks
+            const uint64_t ineff = ineffective_conflicts(cg, wpre, cap);
+            wpre += (uint32_t)__popcll(cg);
+            if (ineff == 0ull || own_q == 0u) continue;                       // (own_q == 0: this rank's km word is stale, and it has nothing here)
+            const uint64_t res = ineff & km[word];                            // killed HERE by a conflict that does not count
+            const uint64_t restore = ineff & ~res & alive[word];              // survived here, decremented (alive bits are this rank's slots only)
+            const uint32_t k = word * 64u + lane;
+            if ((restore >> lane) & 1ull) set.pos_conf[k].w = undo[k];
+            if (res) {
+                if (lane == 0) alive[word] |= res;
+                res_wave += (uint32_t)__popcll(res);
+                if (!nosplat) {
+                    bool drew = false;
+                    if ((res >> lane) & 1ull) {
+                        const float4 pv = set.pos_conf[k];
+                        drew = splat_one(fp, pv.x, pv.y, pv.z, set.time[k], k, keyT);
+                    }
+                    vis += (uint32_t)__popcll(__ballot(drew));
+                }
+            }
+        }
+        if (res_wave && lane == 0) atomicSub(&tile_dead[tile], res_wave);
+        if (vis != vis_tile && lane == 0) atomicMax(&tb[(size_t)tile * 8 + 7], f2ord((float)fp.time));      // as k_pass_fixup
+        resurrected += res_wave;
+    }
+    __syncthreads();
+    if (lane == 0) { s_a[wave] = vis; s_b[wave] = resurrected; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        // this rank's share of the frame's counters (k_pass_fixup published them; the association's first block sends them round)
+        const uint32_t v = s_a[0] + s_a[1] + s_a[2] + s_a[3], rs = s_b[0] + s_b[1] + s_b[2] + s_b[3];
+        if (v) atomicAdd(&st->visible_count, v);
+        if (rs) atomicSub(&st->n_kill, rs);
+    }
 }
 
 // stand-alone form (when something reads the frame's counters before the next frame's k_prep has run)

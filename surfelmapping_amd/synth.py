@@ -149,6 +149,34 @@ def make_sequence(cam_kw: dict, poses, seed: int = 0, noise_mm: float = 0.0, sce
     return out
 
 
+def _render_job(job):
+    cam_kw, pose, seed, k, noise_mm, scene_kw = job
+    scene = Scene(**scene_kw) if scene_kw else Scene(seed)
+    rgb, depth, sem = scene.render(Camera(**cam_kw), pose, noise_mm=noise_mm, noise_seed=seed * 100003 + k)
+    return rgb, depth, sem, pose_to_colmajor(pose)
+
+
+def make_sequences_parallel(specs, workers: int = 8):
+    """Several sequences at once on `workers` fresh processes (spawned, not forked: safe in a process that holds a GPU context).
+    specs: [(cam_kw, poses, seed, noise_mm, scene_kw or None), ...] with scene_kw the arguments of Scene (None: Scene(seed));
+    returns the sequences in the same order, each as make_sequence would."""
+    import multiprocessing as mp
+    jobs, owner = [], []
+    for si, (cam_kw, poses, seed, noise_mm, scene_kw) in enumerate(specs):
+        for k, p in enumerate(poses):
+            jobs.append((cam_kw, p, seed, k, noise_mm, scene_kw))
+            owner.append(si)
+    if workers <= 1 or len(jobs) <= 1:
+        res = [_render_job(j) for j in jobs]
+    else:
+        with mp.get_context("spawn").Pool(min(workers, len(jobs))) as pool:
+            res = pool.map(_render_job, jobs, chunksize=1)
+    out = [[] for _ in specs]
+    for si, r in zip(owner, res):
+        out[si].append(r)
+    return out
+
+
 def seeded_model(n: int, tick: int, seed: int = 0) -> np.ndarray:
     """Config-3 style pre-seeded model: n surfels, AoS float32[n][12]."""
     rng = np.random.default_rng(0xABCD0000 + seed)

@@ -29,13 +29,13 @@ def _oracle(seq, over):
 KEYS = ("count", "offset", "conflict_count", "unstable_count", "fused_count", "data_count", "visible_count")
 
 
-def _run_threads(G, seq, over, period):
+def _run_threads(G, seq, over, period, cam=None):
     grp = sharded.ThreadGroup(G)
     out, errs = [None] * G, []
 
     def work(r):
         try:
-            sm = capi.SurfelMap(capi.make_config(**CAM, **over, compact_period=period))
+            sm = capi.SurfelMap(capi.make_config(**(cam or CAM), **over, compact_period=period))
             coll = sharded.ThreadCollective(grp, r, sm) if G > 1 else None
             mp = sharded.StreamShard(sm, r, G, coll)
             cs = [mp.process_frame(*fr) for fr in seq]
@@ -103,33 +103,45 @@ def test_stream_shard_rccl_world1():
     assert got.shape == ref.shape and np.array_equal(got.view(np.uint32), ref.view(np.uint32))
 
 
-@pytest.mark.gpu
-def test_stream_shard_conflict_cap_is_flagged():
-    """more conflicts than W*H over all ranks: the frame is flagged, not silently different"""
+def _cap_frames():
+    """frames whose model holds more surfels in view than pixels, then frames far behind all of them: every surfel in view
+    conflicts, the W*H cap (src/GlobalModel.cpp:54-57) binds -- in slot order over ALL ranks"""
     cam = dict(width=64, height=48, fx=50.0, fy=50.0, cx=31.5, cy=23.5)
-    over = dict(preprocess=0, stereo_border=0.0, max_sqrt_vertices=300)
-    sm = capi.SurfelMap(capi.make_config(**cam, **over))
-    mp = sharded.StreamShard(sm, 0, 1)
     rng = np.random.default_rng(5)
     W, H = cam["width"], cam["height"]
     rgb = rng.integers(0, 255, (H, W, 3), dtype=np.uint8)
     sem = np.full((H, W), 3, np.uint8)
-    pose = np.eye(4, dtype=np.float32).T.copy()
+    pose = np.eye(4, dtype=np.float32).T.reshape(16).copy()
     near = np.full((H, W), 4000, np.uint16)
-    plain = capi.SurfelMap(capi.make_config(**cam, **over))
-    # a model with more surfels in view than pixels: every frame a little closer than the last, so nothing conflicts or fuses
-    for k in range(6):
-        d = near - np.uint16(40 * k)
-        mp.sm.shard_frame(rgb, d, sem, pose)
-        plain.process_frame(rgb, d, sem, pose)
-    assert sm.counts()["count"] == plain.counts()["count"] > 2 * W * H
-    # then a frame far behind all of them: every surfel in view conflicts
+    # every frame a little closer than the last, so nothing conflicts or fuses: six layers of W*H/2 surfels
+    frames = [(rgb, near - np.uint16(40 * k), sem, pose) for k in range(7)]
     far = np.full((H, W), 20000, np.uint16)
-    plain.process_frame(rgb, far, sem, pose)
-    assert plain.counts()["conflict_count"] == W * H, "the scenario must make the cap bind on the plain path"
-    with pytest.raises(capi.SurfelMapError) as ei:
-        mp.sm.shard_frame(rgb, far, sem, pose)
-    assert ei.value.rc == capi.SM_E_UNSUPPORTED
+    mid = np.full((H, W), 3900, np.uint16)
+    frames += [(rgb, far, sem, pose), (rgb, mid, sem, pose), (rgb, far, sem, pose), (rgb, far, sem, pose)]
+    return cam, frames
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("G,period", [(1, 1000), (2, 1000), (3, 2), (4, 1000)])
+def test_stream_shard_conflict_cap_is_applied_in_global_slot_order(G, period):
+    """more conflicts than W*H over all ranks: the first W*H in the slot order of the single-GPU model take effect, whichever
+    rank owns them (k_shard_cap_pack / k_shard_cap_repair) -- counters every frame and the union equal the oracle's"""
+    cam, frames = _cap_frames()
+    over = dict(preprocess=0, stereo_border=0.0, max_sqrt_vertices=300, conflict_cap=1)
+    o = ol.Oracle(ol.make_config(**cam, **over))
+    ref_counts = []
+    for fr in frames:
+        o.process_frame(*fr)
+        ref_counts.append(o.counts())
+    ref = o.download_model()
+    P = cam["width"] * cam["height"]
+    assert sum(c["conflict_count"] == P for c in ref_counts) >= 2, [c["conflict_count"] for c in ref_counts]     # the cap binds
+    out = _run_threads(G, frames, over, period, cam)
+    for r in range(G):
+        for f, (a, b) in enumerate(zip(out[r][1], ref_counts)):
+            assert all(a[k] == b[k] for k in KEYS), (r, f, {k: (a[k], b[k]) for k in KEYS})
+    union = sharded.StreamShard.union([x[0] for x in out])
+    assert union.shape == ref.shape and np.array_equal(union.view(np.uint32), ref.view(np.uint32))
 
 
 def _run_threads_script(G, seq, over, period, script):

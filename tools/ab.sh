@@ -5,8 +5,8 @@ set -e
 tag=$1; shift
 python -m pytest tests/test_fuzz_gpu.py tests/test_deferred_compaction.py tests/test_kat.py -m gpu -x -q > gpurun_out/${tag}_pytest.log 2>&1 || { tail -n 30 gpurun_out/${tag}_pytest.log; exit 1; }
 tail -n 1 gpurun_out/${tag}_pytest.log
-python bench.py --steps 20 --warmup 5 --no-cpu > gpurun_out/${tag}_k20.json 2> gpurun_out/${tag}.err
-python bench.py --steps 100 --warmup 10 --no-cpu --no-fuse-leg > gpurun_out/${tag}_k100.json 2>> gpurun_out/${tag}.err
+python bench.py --steps 20 --warmup 5 --no-cpu --no-steady-leg --no-reference-path-leg --no-hd-leg > gpurun_out/${tag}_k20.json 2> gpurun_out/${tag}.err
+python bench.py --steps 100 --warmup 10 --no-cpu --only-headline > gpurun_out/${tag}_k100.json 2>> gpurun_out/${tag}.err
 python bench.py --workload hd20m --steps 40 --warmup 5 --no-cpu > gpurun_out/${tag}_hd.json 2>> gpurun_out/${tag}.err
 for f in k20 k100 hd; do python - $tag $f <<PY
 import json,sys

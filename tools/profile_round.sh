@@ -4,7 +4,7 @@
 set -e
 export TMPDIR=/tmp
 out=gpurun_out/$1; steps=$2; warm=$3; shift 3
-args="--steps $steps --warmup $warm --workers 1 --no-cpu-baseline --no-fuse-leg $*"
+args="--steps $steps --warmup $warm --workers 1 --no-cpu-baseline --only-headline $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 bench.py $args > $out.bench_under_profiler.json 2> $out.trace.err
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python3 bench.py $args > /dev/null 2> $out.fetch.err
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- python3 bench.py $args > /dev/null 2> $out.write.err
