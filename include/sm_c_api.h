@@ -149,6 +149,20 @@ int sm_process_frame(sm_ctx *s, const uint8_t *rgb, const uint16_t *depth_mm,
  * (default 2000) microseconds for the device's slot count before deciding whether this frame's cull must compact.) */
 int sm_process_frame_device(sm_ctx *s, const uint8_t *d_rgb, const uint16_t *d_depth_mm,
                             const uint8_t *d_semantic, const float *pose16);
+/* The same for callers whose images live in HOST memory and who do not want to wait (SurfelMapping::processFrame uploads its
+ * three images itself, src/SurfelMapping.cpp:122-128): the images are copied on a second stream into one of three device input
+ * sets, so the 2.8 MB host-to-device copy of frame f+1 runs while frame f computes; the call returns once copy and frame are
+ * enqueued.  Buffers registered with sm_pin_host_buffer (a reader that reuses its buffers registers them once) are copied from
+ * in place and must stay unchanged until sm_inputs_consumed() or sm_sync() returns; any other buffer is first copied into
+ * pinned staging inside the call and may be reused at once. */
+int sm_process_frame_async(sm_ctx *s, const uint8_t *rgb, const uint16_t *depth_mm, const uint8_t *semantic, const float *pose16);
+int sm_pin_host_buffer(sm_ctx *s, const void *host, size_t bytes);     /* hipHostRegister, remembered by the context */
+int sm_unpin_host_buffer(sm_ctx *s, const void *host);
+/* pinned host memory owned by the context (hipHostMalloc) for readers that decode straight into it: the fastest source for
+ * sm_process_frame_async (registered pageable memory is mapped to the device page by page on first use) */
+void *sm_host_alloc(sm_ctx *s, size_t bytes);
+int sm_host_free(sm_ctx *s, void *p);
+int sm_inputs_consumed(sm_ctx *s);                                     /* waits for the copies only, not for the frames */
 /* Wait for all enqueued work; refresh counters; returns a sticky device-side error. */
 int sm_sync(sm_ctx *s);
 

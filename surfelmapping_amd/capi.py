@@ -19,7 +19,8 @@ TEX_DEPTH_METRIC, TEX_DEPTH_FILTERED, TEX_LAST = 0, 1, 2
 # every extern "C" symbol include/sm_c_api.h declares
 SYMBOLS = (
     "sm_api_version", "sm_last_error", "sm_default_config", "sm_create", "sm_destroy",
-    "sm_process_frame", "sm_process_frame_device", "sm_sync", "sm_clean_points", "sm_clean_points_ex", "sm_clean_points_cb", "sm_reset",
+    "sm_process_frame", "sm_process_frame_device", "sm_process_frame_async", "sm_pin_host_buffer", "sm_unpin_host_buffer",
+    "sm_inputs_consumed", "sm_host_alloc", "sm_host_free", "sm_sync", "sm_clean_points", "sm_clean_points_ex", "sm_clean_points_cb", "sm_reset",
     "sm_get_counts", "sm_download_model_aos", "sm_upload_model_aos", "sm_save_map", "sm_load_map",
     "sm_download_index_map", "sm_download_raw_cloud", "sm_download_depth", "sm_render_image", "sm_set_frame", "sm_set_tick",
     "sm_stage_conflict", "sm_stage_cull", "sm_stage_splat", "sm_stage_associate_fuse",
@@ -166,6 +167,13 @@ def load():
     L.sm_destroy.argtypes = [vp]
     L.sm_process_frame.argtypes = [vp, vp, vp, vp, vp]
     L.sm_process_frame_device.argtypes = [vp, vp, vp, vp, vp]
+    L.sm_process_frame_async.argtypes = [vp, vp, vp, vp, vp]
+    L.sm_pin_host_buffer.argtypes = [vp, vp, C.c_size_t]
+    L.sm_unpin_host_buffer.argtypes = [vp, vp]
+    L.sm_inputs_consumed.argtypes = [vp]
+    L.sm_host_alloc.restype = vp
+    L.sm_host_alloc.argtypes = [vp, C.c_size_t]
+    L.sm_host_free.argtypes = [vp, vp]
     L.sm_sync.argtypes = [vp]
     L.sm_clean_points.argtypes = [vp, vp, vp, vp]
     L.sm_clean_points_ex.argtypes = [vp, vp, vp, vp, C.c_int]
@@ -280,6 +288,31 @@ class SurfelMap:
         pose = np.ascontiguousarray(pose, np.float32)
         return self._chk(self._L.sm_process_frame_device(self._h, d_rgb, d_depth, d_sem, _ptr(pose)),
                          "sm_process_frame_device")
+
+    def process_frame_async(self, rgb, depth, sem, pose):
+        """host arrays, no host wait: the copy of this frame overlaps the previous frame (sm_process_frame_async).  Arrays
+        registered with pin_host() are read in place until inputs_consumed() / sync(); others are staged inside the call."""
+        assert rgb.dtype == np.uint8 and rgb.flags.c_contiguous
+        pose = np.ascontiguousarray(pose, np.float32)
+        return self._chk(self._L.sm_process_frame_async(self._h, _ptr(rgb), _ptr(depth), _ptr(sem), _ptr(pose)), "sm_process_frame_async")
+
+    def pin_host(self, arr: np.ndarray):
+        self._chk(self._L.sm_pin_host_buffer(self._h, _ptr(arr), arr.nbytes), "sm_pin_host_buffer")
+
+    def unpin_host(self, arr: np.ndarray):
+        self._chk(self._L.sm_unpin_host_buffer(self._h, _ptr(arr)), "sm_unpin_host_buffer")
+
+    def host_array(self, shape, dtype) -> np.ndarray:
+        """a numpy array in pinned host memory owned by the context (sm_host_alloc): the fastest source for process_frame_async"""
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = self._L.sm_host_alloc(self._h, n)
+        if not p:
+            raise SurfelMapError("sm_host_alloc", SM_E_HIP, self._L.sm_last_error().decode())
+        buf = (C.c_ubyte * n).from_address(p)
+        return np.frombuffer(buf, dtype=dtype).reshape(shape)
+
+    def inputs_consumed(self):
+        self._chk(self._L.sm_inputs_consumed(self._h), "sm_inputs_consumed")
 
     def sync(self, allow=(0,)):
         return self._chk(self._L.sm_sync(self._h), "sm_sync", allow)

@@ -257,17 +257,10 @@ struct sm_ctx {
     int W = 0, H = 0, P = 0;
     uint32_t cap = 0;                 // MAX_VERTICES
     hipStream_t stream = nullptr;
-    // Second stream for the pre-processing of frame f+1 (metricise/pack/transpose/key clear, + the depth filter chain):
-    // it only depends on the caller's images, so it runs while frame f's association and append are still on `stream`.
-    // The four frame planes it writes are double-buffered (the *_nx pointers are the set of the other frame).
-    hipStream_t stream2 = nullptr;
-    hipEvent_t ev_prep = nullptr, ev_main = nullptr, ev_done[2] = {nullptr, nullptr};
-    bool chain_on_main = false;        // the last pre-processing chain ran on `stream` (a non-overlapping frame)
-    bool ev_done_valid[2] = {false, false};
+    // The four frame planes exist twice (the *_nx pointers are the set of the other frame): a frame's association is held back
+    // and runs in the NEXT frame's preparation launch, which writes the other set.  (Rounds 1-2 ran the depth filter chain of
+    // frame f+1 on a second stream instead; since round 3 the chain is a stage of the preparation launch itself.)
     int plane_set = 0;                 // which plane set the current frame uses
-    bool overlap = false;              // this frame overlaps (set per call)
-    bool overlap_capable = false;      // second stream + second plane set exist
-    bool idle_hint = true;             // the host has waited for the device since the last frame: nothing to overlap with
     Model M{};
     DevState *d_state = nullptr;
     DevState *h_state = nullptr;      // pinned mirror
@@ -280,8 +273,21 @@ struct sm_ctx {
     // row-major staging of the caller's inputs
     uint8_t *d_rgb = nullptr, *d_sem = nullptr;
     uint16_t *d_depth_raw = nullptr;
+    // sm_process_frame_async: a ring of device input sets filled on a copy stream, so that the H2D copy of frame f+1 runs while
+    // frame f computes; caller buffers registered with sm_pin_host_buffer are copied from in place, others through pinned staging
+    static constexpr int IN_RING = 3;
+    struct InSlot { uint8_t *rgb = nullptr, *sem = nullptr; uint16_t *depth = nullptr; unsigned char *h_stage = nullptr;
+                    hipEvent_t ev_in = nullptr, ev_in2 = nullptr, ev_free = nullptr; bool used = false; };
+    InSlot in[IN_RING];
+    hipStream_t stream_in = nullptr, stream_in2 = nullptr;    // two copy streams: the colour image on one DMA engine, depth + semantic on another
+    uint32_t in_next = 0;
+    const uint16_t *in_last_depth = nullptr; const uint8_t *in_last_sem = nullptr;     // device copies of the last depth / semantic image given
+    int in_depth_slot = -1, in_sem_slot = -1;                                          // ... and the input sets that hold them
+    std::vector<std::pair<const unsigned char *, size_t>> pinned;                      // host ranges registered by sm_pin_host_buffer (and the ranges below)
+    std::vector<void *> host_allocs;                                                   // pinned host buffers handed out by sm_host_alloc
     float *d_depth_f32 = nullptr;
-    float *d_xs = nullptr, *d_ys = nullptr, *d_wtab = nullptr;
+    float *d_xs = nullptr, *d_ys = nullptr;
+    float h_wtab[169];                 // depth_smooth.frag's 13 x 13 weights (host-computed, handed to the chain stage as kernel arguments)
     // cull scratch
     uint64_t *d_cm = nullptr, *d_dm = nullptr, *d_zm = nullptr;
     uint32_t *d_tile_cnt = nullptr, *d_tile_allow = nullptr, *d_tile_keep = nullptr, *d_tile_flag = nullptr;
@@ -328,8 +334,6 @@ struct sm_ctx {
     int pass_trace_grid = 0;
     unsigned long long *d_ap_trace = nullptr;     // the same for the last k_assoc_prep launch: (entry, exit) per workgroup
     int ap_trace_n[3] = {0, 0, 0};                // its association / tile-flag / image workgroups (dispatch order)
-    bool pass_compact = true;          // k_surfel_pass compacts the lanes that can be in view before the exact tests (SM_PASS_COMPACT=0: word by word)
-    int pass_nw = 2;                   // 64-slot words a wave of k_surfel_pass settles at a time (SM_PASS_NW = 1, 2, 4)
     bool merged_finalize = true;       // SM_NO_MERGED_FINALIZE=1: keep k_cull_finalize + k_cull_lazy as separate launches
     uint32_t *d_conf_sub = nullptr;    // 2 x 64 conflict sub-counters (one set per frame parity: zeroed by that frame's k_prep)
     int conf_sub_set = 0;
@@ -337,6 +341,7 @@ struct sm_ctx {
     uint32_t tb_tiles = 0;
     uint32_t cull_epoch = 0;
     int compact_grid = COMPACT_GRID;
+    int pass_grid = MAX_GRID;          // workgroups of k_surfel_pass that are resident at once (a larger grid runs its tail as a second, thin wave)
     // association scratch
     uint64_t *d_validmask = nullptr, *d_fusedmask = nullptr;
     uint32_t *d_blk_prefix = nullptr;
@@ -500,7 +505,6 @@ int pull_state(sm_ctx *s)
     if (rcf) return rcf;
     HIPCK(hipMemcpyAsync(s->h_state, s->d_state, sizeof(DevState), hipMemcpyDeviceToHost, s->stream));
     HIPCK(hipStreamSynchronize(s->stream));
-    s->idle_hint = true;
     const DevState &d = *s->h_state;
     s->counts.count = s->pending_cull ? s->count_before_cull : d.count - d.garbage;   // dead slots are not surfels
     s->counts.offset = d.offset - (d.garbage - d.holes_last);   // (empty slots of fused candidates lie above `offset`)
@@ -538,8 +542,10 @@ static inline uint32_t assoc_wgs(const sm_ctx *s)
     return s->assoc_pair ? (uint32_t)(s->n_pix_blocks + 1) / 2u : (uint32_t)s->n_pix_blocks;
 }
 
+// `chain`: the frame runs the depth pre-processing chain p0a..p0e (preprocess = 1): the launch is k_assoc_prep<., true>, whose
+// image workgroups are chain tiles (prep_chain_block) -- with or without a held-back association to carry
 int launch_prep(sm_ctx *s, const uint8_t *rgb, const uint16_t *raw, const uint8_t *sem, const float *dm,
-                const FrameParams &fp, bool clear_keys, hipStream_t st = nullptr)
+                const FrameParams &fp, bool clear_keys, hipStream_t st = nullptr, const ChainArgs *chain = nullptr)
 {
     const int tiles = ((s->W + 31) / 32) * ((s->H + 31) / 32);
     // the frame's tile skip flags for the one-pass surfel kernel: a few extra workgroups (128 tiles each per round)
@@ -552,29 +558,38 @@ int launch_prep(sm_ctx *s, const uint8_t *rgb, const uint16_t *raw, const uint8_
         tp.st = s->d_state; tp.tb = s->d_tb; tp.tile_flags = s->d_tile_flags; tp.wave_cnt = s->d_wave_cnt; tp.prep_part = s->d_prep_part;
         s->n_prep_blocks = tp.nfb;
     }
-    if (s->ev_ok) s->ev_merged[s->ev_frames % EV_RING] = s->merge_assoc;
-    if (s->merge_assoc) {
-        // the held-back association of the previous frame + this frame's tile flags + its image tiles in one launch
+    if (s->ev_ok) s->ev_merged[s->ev_frames % EV_RING] = s->merge_assoc || chain != nullptr;
+    if (s->merge_assoc || chain) {
+        // the held-back association of the previous frame (if any) + this frame's tile flags + its image / chain tiles in one launch
+        const bool carry = s->merge_assoc;
         s->merge_assoc = false;
-        s->assoc_pending = false;
+        if (carry) s->assoc_pending = false;
+        if (chain && s->ss_settle_pending) {          // (a sharded stream's settle step rides on k_prep only: stand-alone here)
+            s->ss_settle_pending = false;
+            hipLaunchKernelGGL(k_shard_settle, dim3(s->ss_settle.n), dim3(PIX_BLOCK), 0, s->stream, s->ss_settle);
+            HIPCK(hipGetLastError());
+        }
         if (tp.nfb) {
             const uint64_t ntl = ((uint64_t)s->count_bound + TILE - 1) / TILE;
             tp.nfb = (uint32_t)std::min<uint64_t>(std::max<uint64_t>((ntl + 31) / 32, 1), 256);     // 32 tiles per 256-thread workgroup and round
-            tp.grp_cand = s->assoc_args.grp_cand; tp.n_grp = s->assoc_args.n_grp; tp.prev_time = s->assoc_args.fp.time;
+            if (carry) { tp.grp_cand = s->assoc_args.grp_cand; tp.n_grp = s->assoc_args.n_grp; tp.prev_time = s->assoc_args.fp.time; }
             s->n_prep_blocks = tp.nfb;
         }
         PrepArgs pa;
         pa.rgb = rgb; pa.depth_raw = raw; pa.sem = sem; pa.depth_f32 = dm; pa.depthT = s->d_depthT; pa.rgbsT = s->d_rgbsT;
         pa.keyT = clear_keys ? s->d_keyT : nullptr; pa.dcT = s->d_dcT;
         pa.conf_sub = clear_keys ? s->d_conf_sub + SUB_SET * s->conf_sub_set : nullptr;
-        const uint32_t n_assoc = assoc_wgs(s);
-        if (s->d_ap_trace) { s->ap_trace_n[0] = (int)n_assoc; s->ap_trace_n[1] = (int)tp.nfb; s->ap_trace_n[2] = (int)tiles; }    // dispatch order
-        if (s->assoc_pair)
-            hipLaunchKernelGGL(k_assoc_prep<true>, dim3(tp.nfb + n_assoc + (uint32_t)tiles), dim3(PIX_BLOCK), 0, s->stream, s->assoc_args, pa, fp, tp,
-                               n_assoc, (uint32_t)tiles, s->d_ap_trace);
-        else
-            hipLaunchKernelGGL(k_assoc_prep<false>, dim3(tp.nfb + n_assoc + (uint32_t)tiles), dim3(PIX_BLOCK), 0, s->stream, s->assoc_args, pa, fp, tp,
-                               n_assoc, (uint32_t)tiles);
+        const uint32_t n_assoc = carry ? assoc_wgs(s) : 0u;
+        ChainArgs ca;
+        memset(&ca, 0, sizeof ca);
+        uint32_t n_img = (uint32_t)tiles;
+        if (chain) { ca = *chain; n_img = (uint32_t)(((s->W + CH_TX - 1) / CH_TX) * ((s->H + CH_TY - 1) / CH_TY)); }
+        if (s->d_ap_trace) { s->ap_trace_n[0] = (int)n_assoc; s->ap_trace_n[1] = (int)tp.nfb; s->ap_trace_n[2] = (int)n_img; }    // (chain: dispatched image | association | flags)
+        const dim3 grid(tp.nfb + n_assoc + n_img);
+#define SM_LAUNCH_AP(PAIRV, CHAINV) hipLaunchKernelGGL((k_assoc_prep<PAIRV, CHAINV>), grid, dim3(PIX_BLOCK), 0, s->stream, s->assoc_args, pa, fp, tp, n_assoc, n_img, ca, s->d_ap_trace)
+        if (chain) { if (s->assoc_pair) SM_LAUNCH_AP(true, true); else SM_LAUNCH_AP(false, true); }
+        else { if (s->assoc_pair) SM_LAUNCH_AP(true, false); else SM_LAUNCH_AP(false, false); }
+#undef SM_LAUNCH_AP
         HIPCK(hipGetLastError());
         return SM_OK;
     }
@@ -659,7 +674,12 @@ int launch_cull_lazy_frame(sm_ctx *s, const FrameParams &fp, bool timed)
 int launch_surfel_pass(sm_ctx *s, const FrameParams &fp, bool timed, bool direct)
 {
     const bool ready = s->n_prep_blocks != 0;        // k_prep evaluated the tile flags
-    const int grid = grid_surfels(s);
+    // Grid: up to 2 048 workgroups while the model is small (most tiles are skipped by their flags; a wide grid spreads the few
+    // hundred tiles with work), but no more than are RESIDENT once every workgroup has many tiles with work (>= 4 per
+    // workgroup: beyond ~8 M slots) -- the surplus would start when the first ones finish and run a second, thin wave
+    // (20 M scattered surfels: 160 us with 2 048 workgroups, 140 with 1 536 = 6 per CU, 152 with 5, 172 with 7)
+    const uint64_t tiles_b = ((uint64_t)s->count_bound + TILE - 1) / TILE;
+    const int grid = tiles_b > (uint64_t)4 * MAX_GRID ? std::min(grid_surfels(s), s->pass_grid) : grid_surfels(s);
     // fixup workers: the cap repair strides over the tiles; with direct append they first count the frame's candidate pixels, one group each
     const int fgrid = direct ? std::max(std::min(grid, s->fix_grid), (int)std::min<uint32_t>(s->n_grp, MAX_GRID)) : std::min(grid, s->fix_grid);
     const uint32_t n_fix_prev = s->n_fix_part;
@@ -673,20 +693,13 @@ int launch_surfel_pass(sm_ctx *s, const FrameParams &fp, bool timed, bool direct
     s->n_fix_part = (uint32_t)fgrid;
     uint32_t *sub = s->d_conf_sub + SUB_SET * s->conf_sub_set;
     const uint32_t tile_bound = (uint32_t)std::max<uint64_t>(((uint64_t)s->count_bound + TILE - 1) / TILE, 1);
-#define SM_LAUNCH_PASS(R, NWV)                                                                                                             \
-    hipLaunchKernelGGL((k_surfel_pass<R, NWV>), dim3(grid), dim3(256), 0, s->stream, s->M, s->d_state, fp, s->d_dcT, s->d_cm, s->d_dm /* km */, \
-                       s->d_wave_cnt, s->d_tb, s->d_tile_flags, s->d_lazy_part, s->d_alive, s->d_tile_dead, sub, s->d_keyT, s->d_undo, tile_bound,       \
-                       s->d_frame_sub, s->d_pass_trace)
-#define SM_LAUNCH_PASS_C(R)                                                                                                                \
-    hipLaunchKernelGGL((k_surfel_pass<R, 2, true>), dim3(grid), dim3(256), 0, s->stream, s->M, s->d_state, fp, s->d_dcT, s->d_cm, s->d_dm /* km */, \
+#define SM_LAUNCH_PASS(R)                                                                                                                  \
+    hipLaunchKernelGGL((k_surfel_pass<R>), dim3(grid), dim3(256), 0, s->stream, s->M, s->d_state, fp, s->d_dcT, s->d_cm, s->d_dm /* km */,     \
                        s->d_wave_cnt, s->d_tb, s->d_tile_flags, s->d_lazy_part, s->d_alive, s->d_tile_dead, sub, s->d_keyT, s->d_undo, tile_bound,       \
                        s->d_frame_sub, s->d_pass_trace)
     if (s->d_pass_trace) s->pass_trace_grid = grid;
-    if (s->pass_compact) { if (ready) SM_LAUNCH_PASS_C(true); else SM_LAUNCH_PASS_C(false); }
-    else if (ready) { if (s->pass_nw == 1) SM_LAUNCH_PASS(true, 1); else if (s->pass_nw == 2) SM_LAUNCH_PASS(true, 2); else SM_LAUNCH_PASS(true, 4); }
-    else       { if (s->pass_nw == 1) SM_LAUNCH_PASS(false, 1); else if (s->pass_nw == 2) SM_LAUNCH_PASS(false, 2); else SM_LAUNCH_PASS(false, 4); }
+    if (ready) SM_LAUNCH_PASS(true); else SM_LAUNCH_PASS(false);
 #undef SM_LAUNCH_PASS
-#undef SM_LAUNCH_PASS_C
     HIPCK(hipGetLastError());
     if (mark(s, 2, timed) || mark(s, 3, timed)) return SM_E_HIP;
     DirectArgs da;
@@ -1003,7 +1016,6 @@ int begin_frame(sm_ctx *s, const uint8_t *d_rgb, const uint16_t *d_raw, const ui
     int rc;
     if ((rc = mark(s, 8, fusing))) return rc;    // back-to-back pair 8 -> 0: the cost of an event record itself
     if ((rc = mark(s, 0, fusing))) return rc;
-    hipStream_t ps = s->stream;
     // The reference frame and the frame after reset() do not draw the index map: its textures keep what the last
     // predictIndices left (src/SurfelMapping.cpp:142-169), so the key map is neither cleared nor exchanged then.
     const bool will_splat = fusing;
@@ -1011,29 +1023,26 @@ int begin_frame(sm_ctx *s, const uint8_t *d_rgb, const uint16_t *d_raw, const ui
     // sets, so that the pre-processing of frame f+1 never touches what frame f still reads
     s->plane_set ^= 1;
     s->conf_sub_set = s->plane_set;
-    if (s->overlap_capable || s->defer_ok) {
+    if (s->defer_ok) {
         std::swap(s->d_depthT, s->d_depthT_nx); std::swap(s->d_rgbsT, s->d_rgbsT_nx);
         std::swap(s->d_dcT, s->d_dcT_nx);
         if (will_splat) std::swap(s->d_keyT, s->d_keyT_nx);
     }
-    if (s->overlap) {
-        // this frame's set is the one the frame before the previous one used: wait until that frame is through
-        ps = s->stream2;
-        if (s->ev_done_valid[s->plane_set]) HIPCK(hipStreamWaitEvent(ps, s->ev_done[s->plane_set], 0));
-        // the filter chain carries LAST / DEPTH_FILTERED from frame to frame: follow a chain that ran on the main stream
-        if (s->chain_on_main) { HIPCK(hipStreamWaitEvent(ps, s->ev_main, 0)); s->chain_on_main = false; }
+    // metriciseDepth + filterDepth + removeMovings (src/SurfelMapping.cpp:136-139,156,254-365): with preprocess = 1 the whole
+    // chain is one stage of the preparation launch (prep_chain_block); the reference frame stops before removeMovings
+    ChainArgs ca;
+    memset(&ca, 0, sizeof ca);
+    if (s->cfg.preprocess) {
+        ca.lastT = s->d_lastT; ca.filteredT = s->d_filteredT; memcpy(ca.w, s->h_wtab, sizeof ca.w);
+        ca.border = (int)std::ceil(s->cfg.stereo_border - 0.5f);
+        ca.do_movings = s->ref_set ? 1 : 0;
+        if (s->ref_set) {                                 // src/SurfelMapping.cpp:345-349
+            float linv[16];
+            invert4(s->last_pose, linv);
+            mul4(linv, s->curr_pose, ca.t_c2l.m);
+        }
     }
-    // metriciseDepth (+ filterDepth when preprocess=1)   src/SurfelMapping.cpp:136-139
-    if ((rc = launch_prep(s, d_rgb, d_raw, d_sem, nullptr, fp, will_splat, ps))) return rc;
-    const int pblocks = (s->P + 255) / 256;
-    if (s->cfg.preprocess) {                              // filterDepth src/SurfelMapping.cpp:269-334
-        const int stiles = ((s->W + 31) / 32) * ((s->H + 31) / 32);
-        const int border = (int)std::ceil(s->cfg.stereo_border - 0.5f);
-        hipLaunchKernelGGL(k_filter_depth, dim3(pblocks), dim3(256), 0, ps, s->d_depthT, s->d_rgbsT, s->d_filteredT, fp, 0.15f);
-        hipLaunchKernelGGL(k_smooth_depth, dim3(stiles), dim3(1024), 0, ps, s->d_filteredT, s->d_rgbsT, s->d_depthT, fp, s->d_wtab, border);
-        hipLaunchKernelGGL(k_filter_depth, dim3(pblocks), dim3(256), 0, ps, s->d_depthT, s->d_rgbsT, s->d_filteredT, fp, 0.1f);
-        HIPCK(hipGetLastError());
-    }
+    if ((rc = launch_prep(s, d_rgb, d_raw, d_sem, nullptr, fp, will_splat, nullptr, s->cfg.preprocess ? &ca : nullptr))) return rc;
     // preprocess == 0: DEPTH_FILTERED and LAST are the metric depth itself (nothing reads them on the
     // hot path); they alias d_depthT in sm_download_depth instead of being copied every frame.
     if (!s->ref_set) {                                    // src/SurfelMapping.cpp:142-154
@@ -1041,30 +1050,7 @@ int begin_frame(sm_ctx *s, const uint8_t *d_rgb, const uint16_t *d_raw, const ui
         memcpy(s->last_pose, s->curr_pose, 64);
         s->ref_set = true;
         s->tick++;
-        if (s->overlap) {                                 // everything later on `stream` is ordered after this pre-processing
-            HIPCK(hipEventRecord(s->ev_prep, ps));
-            HIPCK(hipStreamWaitEvent(s->stream, s->ev_prep, 0));
-        } else if (s->overlap_capable) {
-            HIPCK(hipEventRecord(s->ev_main, s->stream));
-            s->chain_on_main = true;
-        }
         return 0;
-    }
-    if (s->cfg.preprocess) {                              // removeMovings src/SurfelMapping.cpp:156,336-365
-        Mat4 t_c2l;
-        float linv[16];
-        invert4(s->last_pose, linv);
-        mul4(linv, s->curr_pose, t_c2l.m);
-        hipLaunchKernelGGL(k_remove_movings, dim3(pblocks), dim3(256), 0, ps, s->d_filteredT, s->d_rgbsT, s->d_lastT,
-                           s->d_depthT, fp, t_c2l, s->d_dcT);
-        HIPCK(hipGetLastError());
-    }
-    if (s->overlap) {
-        HIPCK(hipEventRecord(s->ev_prep, ps));
-        HIPCK(hipStreamWaitEvent(s->stream, s->ev_prep, 0));
-    } else if (s->overlap_capable) {
-        HIPCK(hipEventRecord(s->ev_main, s->stream));
-        s->chain_on_main = true;
     }
     if ((rc = mark(s, 1, fusing))) return rc;
     s->raw_valid = true;                                  // computeFeedbackBuffers (src/SurfelMapping.cpp:164,172): on demand here
@@ -1099,7 +1085,6 @@ void end_frame(sm_ctx *s, bool timed)
     memcpy(s->last_pose, s->curr_pose, 64);               // :245 (LAST aliases the metric depth when preprocess == 0)
     if (s->ev_ok && timed) s->ev_frames++;
     s->tick++;
-    if (s->overlap_capable && hipEventRecord(s->ev_done[s->plane_set], s->stream) == hipSuccess) s->ev_done_valid[s->plane_set] = true;
 }
 
 // SurfelMapping::processFrame body (src/SurfelMapping.cpp:130-251); enqueue only.
@@ -1111,7 +1096,7 @@ int enqueue_frame(sm_ctx *s, const uint8_t *d_rgb, const uint16_t *d_raw, const 
     // the one-pass surfel kernel (not when k_prep runs ahead of the previous frame on the second stream)
     const bool fusing = s->ref_set && s->tick != 0 && !s->pending_cull;
     const bool compact_now = fusing ? decide_compact(s) : true;
-    s->want_list = fusing && !compact_now && s->one_pass && s->use_list && !s->use_fused_assoc && !s->overlap;
+    s->want_list = fusing && !compact_now && s->one_pass && s->use_list && !s->use_fused_assoc;
     // a held-back association rides on this frame's k_prep launch if this is again a fusing frame; anything else (the frame
     // after reset, ...) needs its results first
     s->merge_assoc = s->assoc_pending && fusing && s->defer_ok;       // (a compacting frame too: its k_prep launch has no tile flags to make)
@@ -1127,7 +1112,7 @@ int enqueue_frame(sm_ctx *s, const uint8_t *d_rgb, const uint16_t *d_raw, const 
     if (s->ev_ok) s->ev_compacted[s->ev_frames % EV_RING] = fp.compact_now != 0u;
     // a cull that only marks the dead folds its finalize step into the cull kernel (measured: 66.0 -> 62.9 us/frame; with the
     // depth filter chain on a second stream it is the other way round, 86.5 -> 94.5 us, so those contexts keep the kernel)
-    const bool fold = !fp.compact_now && s->merged_finalize && !s->use_fused_assoc && !s->overlap_capable;
+    const bool fold = !fp.compact_now && s->merged_finalize && !s->use_fused_assoc;
     // ... and, by default, does the conflict test in the same pass over the surfels (k_surfel_pass + k_pass_fixup)
     const bool one_pass = !fp.compact_now && s->one_pass && !s->use_fused_assoc;
     if (s->ev_ok) s->ev_one_pass[s->ev_frames % EV_RING] = one_pass;
@@ -1175,12 +1160,10 @@ int ensure_seg(sm_ctx *s, size_t n)
     return SM_OK;
 }
 
-// `for_frame`: the images are consumed by begin_frame's pre-processing, which runs on the second stream when
-// frames overlap; every other consumer is on the main stream
-int upload_inputs(sm_ctx *s, const uint8_t *rgb, const uint16_t *depth, const uint8_t *sem, bool for_frame = false)
+int upload_inputs(sm_ctx *s, const uint8_t *rgb, const uint16_t *depth, const uint8_t *sem)
 {
     const size_t P = (size_t)s->P;
-    hipStream_t st = (for_frame && s->overlap) ? s->stream2 : s->stream;
+    hipStream_t st = s->stream;
     if (rgb) HIPCK(hipMemcpyAsync(s->d_rgb, rgb, P * 3, hipMemcpyHostToDevice, st));
     if (depth) HIPCK(hipMemcpyAsync(s->d_depth_raw, depth, P * 2, hipMemcpyHostToDevice, st));
     if (sem) HIPCK(hipMemcpyAsync(s->d_sem, sem, P, hipMemcpyHostToDevice, st));
@@ -1269,15 +1252,6 @@ sm_ctx *sm_create(const sm_config *c)
     const size_t nwords = (cap + 63) / 64 + TILE_WORDS, ntiles = (cap + TILE - 1) / TILE + 1;
     s->n_pix_blocks = (s->P + PIX_BLOCK - 1) / PIX_BLOCK;
     bool ok = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) == hipSuccess;
-    // Worth it only when the pre-processing is long (the depth filter chain, ~55 us at KITTI size): the cross-stream
-    // events cost ~8 us per frame, more than the bare metricise kernel they would hide.  Timed contexts keep one timeline.
-    s->overlap_capable = c->preprocess != 0 && !c->enable_timing && std::getenv("SM_NO_OVERLAP") == nullptr;
-    if (s->overlap_capable)
-        ok = ok && hipStreamCreateWithFlags(&s->stream2, hipStreamNonBlocking) == hipSuccess &&
-             hipEventCreateWithFlags(&s->ev_prep, hipEventDisableTiming) == hipSuccess &&
-             hipEventCreateWithFlags(&s->ev_main, hipEventDisableTiming) == hipSuccess &&
-             hipEventCreateWithFlags(&s->ev_done[0], hipEventDisableTiming) == hipSuccess &&
-             hipEventCreateWithFlags(&s->ev_done[1], hipEventDisableTiming) == hipSuccess;
     ok = ok && alloc_set(s->M.s[0], cap) == SM_OK;      // one SoA set: the compaction is in place
     ok = ok && dalloc(&s->d_state, 1) == SM_OK && dalloc(&s->d_log, FRAME_LOG_LEN) == SM_OK;
     ok = ok && hipHostMalloc((void **)&s->h_state, sizeof(DevState), hipHostMallocDefault) == hipSuccess;
@@ -1287,18 +1261,18 @@ sm_ctx *sm_create(const sm_config *c)
     ok = ok && dalloc(&s->d_depthT, P) == SM_OK && dalloc(&s->d_filteredT, P) == SM_OK && dalloc(&s->d_lastT, P) == SM_OK;
     ok = ok && dalloc(&s->d_rgbsT, P) == SM_OK && dalloc(&s->d_keyT, P) == SM_OK && dalloc(&s->d_dcT, P) == SM_OK &&
          hipMemset(s->d_dcT, 0, P * 8) == hipSuccess;
-    // deferred association: only plain asynchronous streams without the depth filter chain and without per-kernel timing
+    // deferred association (three launches per frame; with or without the depth filter chain)
     {
         const char *e = std::getenv("SM_DEFER_ASSOC");                    // "0": every frame launches its own association
-        s->defer_ok = c->preprocess == 0 && !(e && e[0] == '0');
+        s->defer_ok = !(e && e[0] == '0');
     }
-    if (s->overlap_capable || s->defer_ok)
+    if (s->defer_ok)
         ok = ok && dalloc(&s->d_depthT_nx, P) == SM_OK && dalloc(&s->d_rgbsT_nx, P) == SM_OK && dalloc(&s->d_keyT_nx, P) == SM_OK &&
              dalloc(&s->d_dcT_nx, P) == SM_OK && hipMemset(s->d_depthT_nx, 0, P * 4) == hipSuccess &&
              hipMemset(s->d_rgbsT_nx, 0, P * 4) == hipSuccess && hipMemset(s->d_dcT_nx, 0, P * 8) == hipSuccess;
     ok = ok && dalloc(&s->d_rgb, P * 3) == SM_OK && dalloc(&s->d_sem, P) == SM_OK && dalloc(&s->d_depth_raw, P) == SM_OK;
     ok = ok && dalloc(&s->d_depth_f32, P) == SM_OK;
-    ok = ok && dalloc(&s->d_xs, (size_t)s->W * 2) == SM_OK && dalloc(&s->d_ys, (size_t)s->H * 2) == SM_OK && dalloc(&s->d_wtab, (size_t)169) == SM_OK;
+    ok = ok && dalloc(&s->d_xs, (size_t)s->W * 2) == SM_OK && dalloc(&s->d_ys, (size_t)s->H * 2) == SM_OK;
     ok = ok && dalloc(&s->d_cm, nwords) == SM_OK && dalloc(&s->d_dm, nwords) == SM_OK && dalloc(&s->d_zm, nwords) == SM_OK;
     s->alive_words = nwords; s->dead_tiles = ntiles;
     ok = ok && dalloc(&s->d_alive, nwords) == SM_OK && hipMemset(s->d_alive, 0xFF, nwords * 8) == hipSuccess &&
@@ -1360,7 +1334,7 @@ sm_ctx *sm_create(const sm_config *c)
     for (int i = 0; i < s->W; ++i) odd += (uint32_t)((s->H + ((i & 1) ? 1 : 0)) / 2);
     s->n_odd_pixels = odd;
     // depth_smooth.frag weights: the host passes 0.5/30^2 as "sigPix" (src/SurfelMapping.cpp:292-309)
-    float wtab[169];
+    float *wtab = s->h_wtab;
     {
         const float sigma_intensity = 30.0f;
         const float sigPix = 0.5f / (sigma_intensity * sigma_intensity);
@@ -1369,8 +1343,7 @@ sm_ctx *sm_create(const sm_config *c)
                 wtab[(iy + 6) * 13 + (ix + 6)] = exp_spec(-((float)(ix * ix + iy * iy) * sigPix));
     }
     memset(s->h_state, 0, sizeof(DevState));
-    ok = hipMemcpy(s->d_wtab, wtab, sizeof wtab, hipMemcpyHostToDevice) == hipSuccess &&
-         hipMemcpy(s->d_xs, xs.data(), xs.size() * 4, hipMemcpyHostToDevice) == hipSuccess &&
+    ok = hipMemcpy(s->d_xs, xs.data(), xs.size() * 4, hipMemcpyHostToDevice) == hipSuccess &&
          hipMemcpy(s->d_ys, ys.data(), ys.size() * 4, hipMemcpyHostToDevice) == hipSuccess &&
          hipMemcpy(s->d_state, s->h_state, sizeof(DevState), hipMemcpyHostToDevice) == hipSuccess &&
          hipMemset(s->d_depthT, 0, P * 4) == hipSuccess && hipMemset(s->d_filteredT, 0, P * 4) == hipSuccess &&
@@ -1396,11 +1369,20 @@ sm_ctx *sm_create(const sm_config *c)
         if (const char *e = std::getenv("SM_TILE_FLAGS_IN_PREP")) s->use_list = e[0] != '0';
         if (const char *e = std::getenv("SM_DIRECT_APPEND")) s->direct = e[0] != '0';
         if (const char *e = std::getenv("SM_ASSOC_PAIR")) s->assoc_pair = e[0] != '0';
-        if (const char *e = std::getenv("SM_PASS_NW")) { const int v = std::atoi(e); if (v == 1 || v == 2 || v == 4) s->pass_nw = v; }
-        if (const char *e = std::getenv("SM_PASS_COMPACT")) s->pass_compact = e[0] != '0';
         if (std::getenv("SM_PASS_TRACE") && hipMalloc((void **)&s->d_pass_trace, (size_t)MAX_GRID * 64) != hipSuccess) s->d_pass_trace = nullptr;
         if (std::getenv("SM_PASS_TRACE") && hipMalloc((void **)&s->d_ap_trace, (size_t)65536 * 16) != hipSuccess) s->d_ap_trace = nullptr;
         s->defer_ok = s->defer_ok && s->one_pass && s->use_list && s->direct && !s->use_fused_assoc;
+        {
+            // k_surfel_pass: with more workgroups than the chip holds at once the surplus starts when the first ones are done --
+            // on a model where every tile has work (20 M scattered surfels: ~10 tiles per workgroup) that is a second pass at an
+            // eighth of the occupancy.  Grid = what is resident; tiles go round-robin.  (SM_PASS_WG_PER_CU overrides.)
+            int pc = 0;
+            if (cus > 0 && hipOccupancyMaxActiveBlocksPerMultiprocessor(&pc, k_surfel_pass<true>, 256, 0) == hipSuccess && pc > 0) {
+                int want = std::max(1, pc - 1);      // the occupancy API over-reports by one block per CU here (measured; MI355X_MICROARCH.md)
+                if (const char *e = std::getenv("SM_PASS_WG_PER_CU")) want = std::max(1, std::atoi(e));
+                s->pass_grid = std::max(256, std::min(cus * want, MAX_GRID));
+            }
+        }
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess && cus > 0 &&
             hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_compact<true>, 256, 0) == hipSuccess && per_cu > 0) {
             // the occupancy API can over-report by one block per CU (MI355X_MICROARCH.md): stay at <= 4 and below it
@@ -1425,9 +1407,22 @@ void sm_destroy(sm_ctx *s)
     if (!s) return;
     if (s->cfg.device >= 0 && s->cfg.device < MAX_DEV) { std::lock_guard<std::mutex> lk(g_compact_mu); g_ctx_on_dev[s->cfg.device]--; }
     (void)hipSetDevice(s->cfg.device);
-    if (s->stream2) (void)hipStreamSynchronize(s->stream2);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     if (s->ss_comm) (void)sm_shard_rccl_finalize(s);         // a communicator the caller did not finalize
+    if (s->stream_in) (void)hipStreamSynchronize(s->stream_in);
+    if (s->stream_in2) (void)hipStreamSynchronize(s->stream_in2);
+    for (auto &sl : s->in) {
+        if (sl.ev_in2) (void)hipEventDestroy(sl.ev_in2);
+        (void)hipFree(sl.rgb); (void)hipFree(sl.sem); (void)hipFree(sl.depth);
+        if (sl.h_stage) (void)hipHostFree(sl.h_stage);
+        if (sl.ev_in) (void)hipEventDestroy(sl.ev_in);
+        if (sl.ev_free) (void)hipEventDestroy(sl.ev_free);
+    }
+    if (s->stream_in) (void)hipStreamDestroy(s->stream_in);
+    if (s->stream_in2) (void)hipStreamDestroy(s->stream_in2);
+    for (auto &pr : s->pinned)
+        if (std::find(s->host_allocs.begin(), s->host_allocs.end(), (void *)pr.first) == s->host_allocs.end()) (void)hipHostUnregister(const_cast<unsigned char *>(pr.first));
+    for (void *hp : s->host_allocs) (void)hipHostFree(hp);
     if (s->d_pass_trace) {
         // SM_PASS_TRACE=<prefix>: the last k_surfel_pass launch's per-workgroup record (wall_clock64 at entry / first tile /
         // after it / exit, that tile, its compacted entries, XCC | HW_ID, tiles) -> <prefix>.<n>.bin (tools/pass_trace.py)
@@ -1452,10 +1447,6 @@ void sm_destroy(sm_ctx *s)
         (void)hipFree(s->d_ap_trace);
     }
     (void)hipFree(s->d_depthT_nx); (void)hipFree(s->d_rgbsT_nx); (void)hipFree(s->d_keyT_nx); (void)hipFree(s->d_dcT_nx);
-    if (s->ev_prep) (void)hipEventDestroy(s->ev_prep);
-    if (s->ev_main) (void)hipEventDestroy(s->ev_main);
-    for (auto &e : s->ev_done) if (e) (void)hipEventDestroy(e);
-    if (s->stream2) (void)hipStreamDestroy(s->stream2);
     free_set(s->M.s[0]); free_set(s->M.s[1]);
     (void)hipFree(s->d_state); (void)hipFree(s->d_log);
     if (s->h_state) (void)hipHostFree(s->h_state);
@@ -1463,7 +1454,7 @@ void sm_destroy(sm_ctx *s)
     (void)hipFree(s->d_depthT); (void)hipFree(s->d_filteredT); (void)hipFree(s->d_lastT);
     (void)hipFree(s->d_rgbsT); (void)hipFree(s->d_keyT); (void)hipFree(s->d_dcT);
     (void)hipFree(s->d_rgb); (void)hipFree(s->d_sem); (void)hipFree(s->d_depth_raw); (void)hipFree(s->d_depth_f32);
-    (void)hipFree(s->d_xs); (void)hipFree(s->d_ys); (void)hipFree(s->d_wtab);
+    (void)hipFree(s->d_xs); (void)hipFree(s->d_ys);
     (void)hipFree(s->d_cm); (void)hipFree(s->d_dm); (void)hipFree(s->d_zm); (void)hipFree(s->d_alive); (void)hipFree(s->d_tile_dead);
     (void)hipFree(s->d_tile_cnt); (void)hipFree(s->d_tile_allow); (void)hipFree(s->d_tile_keep); (void)hipFree(s->d_tile_flag); (void)hipFree(s->d_group_tot); (void)hipFree(s->d_group_base); (void)hipFree(s->d_tb); (void)hipFree(s->d_tile_flags); (void)hipFree(s->d_conf_part); (void)hipFree(s->d_compact_part); (void)hipFree(s->d_lazy_part); (void)hipFree(s->d_conf_sub); (void)hipFree(s->d_fix_part); (void)hipFree(s->d_blk_cand); (void)hipFree(s->d_grp_cand); (void)hipFree(s->d_frame_sub); (void)hipFree(s->d_wave_cnt); (void)hipFree(s->d_undo); (void)hipFree(s->d_prep_part);
     (void)hipFree(s->d_validmask); (void)hipFree(s->d_fusedmask); (void)hipFree(s->d_blk_prefix); (void)hipFree(s->d_desc); (void)hipFree(s->d_blk_cnt);
@@ -1493,10 +1484,6 @@ int sm_process_frame_device(sm_ctx *s, const uint8_t *d_rgb, const uint16_t *d_d
     if (!s || !d_rgb || !pose16) { g_err = "sm_process_frame_device: null argument"; return SM_E_ARG; }
     HIPCK(hipSetDevice(s->cfg.device));
     // a null depth / semantic keeps the previous texture (src/SurfelMapping.cpp:124-128)
-    // asynchronous call: this frame's pre-processing may run ahead of the previous frame's tail -- unless the caller has
-    // waited for the device in between (then the main stream is idle and the cross-stream hand-off is pure overhead)
-    s->overlap = s->overlap_capable && !s->idle_hint;
-    s->idle_hint = false;
     return enqueue_frame(s, d_rgb, d_depth_mm ? d_depth_mm : s->d_depth_raw, d_semantic ? d_semantic : s->d_sem, pose16);
 }
 
@@ -1504,12 +1491,131 @@ int sm_process_frame(sm_ctx *s, const uint8_t *rgb, const uint16_t *depth_mm, co
 {
     if (!s || !rgb || !pose16) { g_err = "sm_process_frame: null argument (rgb and pose are required)"; return SM_E_ARG; }
     HIPCK(hipSetDevice(s->cfg.device));
-    s->overlap = false;                          // the caller waits for the result: nothing to overlap with
-    int rc = upload_inputs(s, rgb, depth_mm, semantic, true);
+    int rc = upload_inputs(s, rgb, depth_mm, semantic);
     if (rc) return rc;
     rc = enqueue_frame(s, s->d_rgb, s->d_depth_raw, s->d_sem, pose16);
     if (rc) return rc;
     return sm_sync(s);
+}
+
+int sm_pin_host_buffer(sm_ctx *s, const void *host, size_t bytes)
+{
+    if (!s || !host || !bytes) return SM_E_ARG;
+    HIPCK(hipSetDevice(s->cfg.device));
+    const unsigned char *p = static_cast<const unsigned char *>(host);
+    for (auto &pr : s->pinned)
+        if (p >= pr.first && p + bytes <= pr.first + pr.second) return SM_OK;         // already registered
+    HIPCK(hipHostRegister(const_cast<void *>(host), bytes, hipHostRegisterDefault));
+    s->pinned.emplace_back(p, bytes);
+    return SM_OK;
+}
+
+void *sm_host_alloc(sm_ctx *s, size_t bytes)
+{
+    if (!s || !bytes) return nullptr;
+    if (hipSetDevice(s->cfg.device) != hipSuccess) return nullptr;
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { g_err = "sm_host_alloc: hipHostMalloc failed"; return nullptr; }
+    s->pinned.emplace_back(static_cast<const unsigned char *>(p), bytes);
+    s->host_allocs.push_back(p);
+    return p;
+}
+
+int sm_host_free(sm_ctx *s, void *p)
+{
+    if (!s || !p) return SM_E_ARG;
+    auto it = std::find(s->host_allocs.begin(), s->host_allocs.end(), p);
+    if (it == s->host_allocs.end()) { g_err = "sm_host_free: not a buffer of sm_host_alloc"; return SM_E_ARG; }
+    HIPCK(hipSetDevice(s->cfg.device));
+    if (s->stream_in) { HIPCK(hipStreamSynchronize(s->stream_in)); HIPCK(hipStreamSynchronize(s->stream_in2)); }
+    s->host_allocs.erase(it);
+    for (size_t i = 0; i < s->pinned.size(); ++i)
+        if (s->pinned[i].first == p) { s->pinned.erase(s->pinned.begin() + (long)i); break; }
+    HIPCK(hipHostFree(p));
+    return SM_OK;
+}
+
+int sm_unpin_host_buffer(sm_ctx *s, const void *host)
+{
+    if (!s || !host) return SM_E_ARG;
+    HIPCK(hipSetDevice(s->cfg.device));
+    for (size_t i = 0; i < s->pinned.size(); ++i)
+        if (s->pinned[i].first == host && std::find(s->host_allocs.begin(), s->host_allocs.end(), (void *)host) == s->host_allocs.end()) {
+            if (s->stream_in) { HIPCK(hipStreamSynchronize(s->stream_in)); HIPCK(hipStreamSynchronize(s->stream_in2)); }   // no copy may still read it
+            HIPCK(hipHostUnregister(const_cast<void *>(host)));
+            s->pinned.erase(s->pinned.begin() + (long)i);
+            return SM_OK;
+        }
+    g_err = "sm_unpin_host_buffer: not a buffer registered with sm_pin_host_buffer";
+    return SM_E_ARG;
+}
+
+int sm_process_frame_async(sm_ctx *s, const uint8_t *rgb, const uint16_t *depth_mm, const uint8_t *semantic, const float *pose16)
+{
+    if (!s || !rgb || !pose16) { g_err = "sm_process_frame_async: null argument (rgb and pose are required)"; return SM_E_ARG; }
+    HIPCK(hipSetDevice(s->cfg.device));
+    const size_t P = (size_t)s->P;
+    if (!s->stream_in) {
+        HIPCK(hipStreamCreateWithFlags(&s->stream_in, hipStreamNonBlocking));
+        HIPCK(hipStreamCreateWithFlags(&s->stream_in2, hipStreamNonBlocking));
+        for (auto &sl : s->in) {
+            HIPCK(hipEventCreateWithFlags(&sl.ev_in2, hipEventDisableTiming));
+            HIPCK(hipMalloc((void **)&sl.rgb, P * 3)); HIPCK(hipMalloc((void **)&sl.depth, P * 2)); HIPCK(hipMalloc((void **)&sl.sem, P));
+            HIPCK(hipEventCreateWithFlags(&sl.ev_in, hipEventDisableTiming));
+            HIPCK(hipEventCreateWithFlags(&sl.ev_free, hipEventDisableTiming));
+        }
+    }
+    const int slot = (int)(s->in_next++ % sm_ctx::IN_RING);
+    sm_ctx::InSlot &sl = s->in[slot];
+    // the set is free again when the frame that used it last has run its preparation launch (the only reader of the images).
+    // The HOST waits for that (three frames back: normally long past) rather than only the copy stream: it bounds the copies and
+    // frames in flight.  With the host free to run ahead, hipMemcpyAsync stalled for 7-12 ms every few dozen frames (2 k instead
+    // of 16 k frames/s) -- measured with registered and with hipHostMalloc'ed sources alike.
+    if (sl.used) HIPCK(hipEventSynchronize(sl.ev_free));
+    auto is_pinned = [&](const void *ptr, size_t n) {
+        const unsigned char *q = static_cast<const unsigned char *>(ptr);
+        for (auto &pr : s->pinned) if (q >= pr.first && q + n <= pr.first + pr.second) return true;
+        return false;
+    };
+    size_t off = 0;
+    auto copy_in = [&](void *dst, const void *src, size_t n, hipStream_t cs) -> int {
+        if (!is_pinned(src, n)) {
+            // pageable caller memory: through this set's pinned staging (one host memcpy; the previous copy out of it -- three
+            // frames ago -- must have completed)
+            if (!sl.h_stage) HIPCK(hipHostMalloc((void **)&sl.h_stage, P * 6, hipHostMallocDefault));
+            if (sl.used && off == 0) { HIPCK(hipEventSynchronize(sl.ev_in)); HIPCK(hipEventSynchronize(sl.ev_in2)); }
+            memcpy(sl.h_stage + off, src, n);
+            src = sl.h_stage + off;
+        }
+        off += n;
+        HIPCK(hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, cs));
+        return SM_OK;
+    };
+    int rc = copy_in(sl.rgb, rgb, P * 3, s->stream_in);
+    // a null depth / semantic keeps the previous texture (src/SurfelMapping.cpp:124-128)
+    if (!rc && depth_mm) { rc = copy_in(sl.depth, depth_mm, P * 2, s->stream_in2); s->in_last_depth = sl.depth; s->in_depth_slot = slot; }
+    if (!rc && semantic) { rc = copy_in(sl.sem, semantic, P, s->stream_in2); s->in_last_sem = sl.sem; s->in_sem_slot = slot; }
+    if (rc) return rc;
+    HIPCK(hipEventRecord(sl.ev_in, s->stream_in));
+    HIPCK(hipEventRecord(sl.ev_in2, s->stream_in2));
+    HIPCK(hipStreamWaitEvent(s->stream, sl.ev_in, 0));
+    HIPCK(hipStreamWaitEvent(s->stream, sl.ev_in2, 0));
+    rc = enqueue_frame(s, sl.rgb, s->in_last_depth ? s->in_last_depth : s->d_depth_raw, s->in_last_sem ? s->in_last_sem : s->d_sem, pose16);
+    HIPCK(hipEventRecord(sl.ev_free, s->stream));
+    sl.used = true;
+    // a frame without its own depth / semantic image read another set's: that set is busy until this frame has prepared too
+    for (int o : {s->in_depth_slot, s->in_sem_slot})
+        if (o >= 0 && o != slot) { HIPCK(hipEventRecord(s->in[o].ev_free, s->stream)); s->in[o].used = true; }
+    return rc;
+}
+
+int sm_inputs_consumed(sm_ctx *s)
+{
+    if (!s) return SM_E_ARG;
+    HIPCK(hipSetDevice(s->cfg.device));
+    if (s->stream_in) HIPCK(hipStreamSynchronize(s->stream_in));
+    if (s->stream_in2) HIPCK(hipStreamSynchronize(s->stream_in2));
+    return SM_OK;
 }
 
 int sm_clean_points(sm_ctx *s, const uint16_t *depth_mm, const uint8_t *semantic, const float *pose16)
@@ -2121,8 +2227,7 @@ int sm_shard_begin_frame(sm_ctx *s, const uint8_t *rgb, const uint16_t *depth_mm
     if (!s || !rgb || !pose16) return SM_E_ARG;
     HIPCK(hipSetDevice(s->cfg.device));
     if (s->sh_in_frame) { g_err = "sm_shard_begin_frame: previous frame not finished (sm_shard_append)"; return SM_E_ARG; }
-    s->overlap = false;
-    int rc = upload_inputs(s, rgb, depth_mm, semantic, true);
+    int rc = upload_inputs(s, rgb, depth_mm, semantic);
     if (rc) return rc;
     FrameParams fp;
     rc = begin_frame(s, s->d_rgb, s->d_depth_raw, s->d_sem, pose16, &fp);
@@ -2436,8 +2541,6 @@ int sm_shard_frame_device(sm_ctx *s, const uint8_t *d_rgb, const uint16_t *d_dep
     HIPCK(hipSetDevice(s->cfg.device));
     if (s->pending_cull) { g_err = "sm_stage_conflict without sm_stage_cull"; return SM_E_ARG; }
     if (s->ref_set && s->tick == 0) { g_err = "reset() is not supported in sharded mode"; return SM_E_UNSUPPORTED; }
-    s->overlap = false;
-    s->idle_hint = false;
     const bool fusing = s->ref_set && s->tick != 0;
     int rc;
     if (fusing) {
@@ -2515,8 +2618,7 @@ int sm_shard_frame(sm_ctx *s, const uint8_t *rgb, const uint16_t *depth_mm, cons
 {
     if (!s || !rgb || !pose16) { g_err = "sm_shard_frame: null argument"; return SM_E_ARG; }
     HIPCK(hipSetDevice(s->cfg.device));
-    s->overlap = false;
-    int rc = upload_inputs(s, rgb, depth_mm, semantic, true);
+    int rc = upload_inputs(s, rgb, depth_mm, semantic);
     if (rc) return rc;
     if ((rc = sm_shard_frame_device(s, s->d_rgb, s->d_depth_raw, s->d_sem, pose16))) return rc;
     return sm_sync(s);

@@ -426,130 +426,214 @@ __global__ __launch_bounds__(1024) void k_prep(const uint8_t *__restrict__ rgb,
 }
 
 // ---------------------------------------------------------------------------------------------
-// p0b / p0d  depth_filter.frag:16-80 (host src/SurfelMapping.cpp:271-288,316-332): drop classes
-// 10/11/12, keep a pixel iff >= 7 of its in-image 8-neighbours have the same class and
-// |dz| < diffThresh.  Column-major images, one pixel per thread.
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_filter_depth(const float *__restrict__ inT, const uint32_t *__restrict__ rgbsT,
-                                                      float *__restrict__ outT, FrameParams fp, float diff_thresh)
-{
-    const int q = blockIdx.x * 256 + threadIdx.x;
-    if (q >= fp.P) return;
-    const int H = fp.H, W = fp.W;
-    const int i = q / H, j = q - i * H;
-    const float depth = inT[q];
-    const uint32_t cl = rgbsT[q] >> 24;
-    float r = 0.0f;
-    if (!(depth <= fp.min_depth || depth >= 100.0f || cl == 10u || cl == 11u || cl == 12u)) {
-        int support = 0;
-#pragma unroll
-        for (int iy = -1; iy <= 1; ++iy)
-#pragma unroll
-            for (int ix = -1; ix <= 1; ++ix) {
-                if (iy == 0 && ix == 0) continue;
-                const int qi = i + ix, qj = j + iy;
-                if (qi < 0 || qi >= W || qj < 0 || qj >= H) continue;   // texX<0||texX>1 (depth_filter.frag:52)
-                const int qq = qi * H + qj;
-                if (fabsf(inT[qq] - depth) < diff_thresh && cl == (rgbsT[qq] >> 24)) support++;
-            }
-        if (support >= 7) r = depth;
-    }
-    outT[q] = r;
-}
-
-// ---------------------------------------------------------------------------------------------
-// p0c  depth_smooth.frag:17-82 (host src/SurfelMapping.cpp:291-313): 13x13 class-aware weighted
-// mean.  The weights exp(-(ix^2+iy^2)*sigPix) come precomputed from the host (169 floats, the
-// fixed exp of DESIGN.md "Arithmetic"); the accumulation order is the shader's: iy outer, ix inner.
-// 32x32-pixel tile per 1024-thread workgroup, (depth, class) staged with a 6-pixel halo in LDS.
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_smooth_depth(const float *__restrict__ inT, const uint32_t *__restrict__ rgbsT,
-                                                       float *__restrict__ outT, FrameParams fp,
-                                                       const float *__restrict__ wtab, int border)
-{
-    constexpr int R = 6, TS = 32, HS = TS + 2 * R;       // 44
-    __shared__ float s_d[HS][HS + 1];
-    __shared__ uint8_t s_c[HS][HS + 4];
-    __shared__ float s_w[13 * 13];
-    const int H = fp.H, W = fp.W;
-    const int tiles_j = (H + TS - 1) / TS;
-    const int j0 = (blockIdx.x % tiles_j) * TS, i0 = (blockIdx.x / tiles_j) * TS;
-    const int tj = threadIdx.x & 31, ti = threadIdx.x >> 5;
-    if (threadIdx.x < 169) s_w[threadIdx.x] = wtab[threadIdx.x];
-    for (int e = threadIdx.x; e < HS * HS; e += 1024) {
-        const int li = e / HS, lj = e - li * HS;
-        const int gi = i0 + li - R, gj = j0 + lj - R;
-        float d = 0.0f;
-        uint32_t c = 255u;
-        if (gi >= 0 && gi < W && gj >= 0 && gj < H) {
-            const int qq = gi * H + gj;
-            d = inT[qq];
-            c = rgbsT[qq] >> 24;
-        }
-        s_d[li][lj] = d;
-        s_c[li][lj] = (uint8_t)c;
-    }
-    __syncthreads();
-    const int i = i0 + ti, j = j0 + tj;
-    if (i >= W || j >= H) return;
-    const float depth = s_d[ti + R][tj + R];
-    const uint32_t cl = s_c[ti + R][tj + R];
-    float r = 0.0f;
-    if (!(depth <= fp.min_depth || depth >= 100.0f || cl == 10u)) {
-        float sum1 = 0.0f, sum2 = 0.0f;
-        int valid = 0;
-        for (int iy = -R; iy <= R; ++iy) {
-            const int qj = j + iy;
-            if (qj < 0 || qj >= H) continue;
-#pragma unroll
-            for (int ix = -R; ix <= R; ++ix) {
-                const int qi = i + ix;
-                if (qi < border || qi >= W) continue;            // texX < stereoBorder/cols || texX > 1
-                const float dk = s_d[ti + R + ix][tj + R + iy];
-                if (dk <= fp.min_depth || dk >= 100.0f || cl != (uint32_t)s_c[ti + R + ix][tj + R + iy]) continue;
-                const float w = s_w[(iy + R) * 13 + (ix + R)];
-                sum1 += dk * w;
-                sum2 += w;
-                valid++;
-            }
-        }
-        if (valid > 0) r = sum1 / sum2;
-    }
-    outT[i * H + j] = r;
-}
-
-// ---------------------------------------------------------------------------------------------
-// p0e  depth_movings.frag:20-82 (host src/SurfelMapping.cpp:336-365): pixels of movable classes
-// (13..18) are reprojected into the previous frame and zeroed if |z_hat - z_last| > 0.5 m.
+// The depth pre-processing chain p0a..p0e of SurfelMapping::processFrame (src/SurfelMapping.cpp:136-156,254-365) as ONE
+// LDS-tiled stage: a workgroup produces a 14 x 30-pixel tile of the frame planes and computes everything that tile needs
+// from the caller's raw images itself --
+//   p0a  metricise            depth_metric.frag:15-35      on the tile + 8 pixels of halo   (30 x 46)
+//   p0b  filter, |dz| < 0.15  depth_filter.frag:16-80      on the tile + 7                  (28 x 44)
+//   p0c  13 x 13 class-aware weighted mean  depth_smooth.frag:17-82   on the tile + 1       (16 x 32)
+//   p0d  filter, |dz| < 0.10                               on the tile
+//   p0e  moving-object removal against LAST  depth_movings.frag:20-82  on the tile
+// -- so the five dependent launches of rounds 1-2 (k_prep, k_filter_depth, k_smooth_depth, k_filter_depth, k_remove_movings:
+// ~55 us at KITTI size, most of it launch floors and boundaries) become block ranges of the frame's one preparation launch
+// (k_assoc_prep<., true>), next to the previous frame's association and this frame's tile flags, and a frame with the chain
+// has the same three launches as one without.  Every stage is a pure function of the stage before it, so recomputing the halo
+// gives the values the separate passes gave: results are bit-identical (tests/test_gpu_parity.py::test_preprocess_*).  The
+// halo costs 3.3x of the cheap stages and 512 / 420 = 1.22x of the smooth, which is where the time is (169 taps per pixel);
+// 30 x 30 tiles (1.14x) left 546 workgroups for 256 CUs -- some CUs three, most two -- and four pixels per thread.  Texture names as the reference's ping-pong leaves them: DEPTH_METRIC = p0e's output (p0c's on the reference
+// frame, which stops before p0e), DEPTH_FILTERED = p0d's, LAST <- DEPTH_FILTERED at the end of the frame.
+// 256 threads; the 16 x 32 smooth region is two pixels per thread.
 // ---------------------------------------------------------------------------------------------
 struct Mat4 { float m[16]; };
 
-__global__ __launch_bounds__(256) void k_remove_movings(const float *__restrict__ inT, const uint32_t *__restrict__ rgbsT,
-                                                        const float *__restrict__ lastT, float *__restrict__ outT,
-                                                        FrameParams fp, Mat4 t_c2l, uint2 *__restrict__ dcT)
+struct ChainArgs {
+    const float *lastT;       // LAST: the previous frame's DEPTH_FILTERED (column-major)
+    float *filteredT;         // out: DEPTH_FILTERED of this frame
+    float w[169];             // 13 x 13 weights exp(-(ix^2 + iy^2) sigPix), the host's (src/SurfelMapping.cpp:292-309): kernel arguments, read with scalar loads
+    Mat4 t_c2l;               // current camera -> last camera (src/SurfelMapping.cpp:345-349)
+    int do_movings;           // 0: the reference frame (src/SurfelMapping.cpp:142-154 returns before removeMovings)
+    int border;               // ceil(stereoBorder - 0.5): first column the smooth may read (texX < stereoBorder / cols is skipped)
+};
+
+constexpr int CH_TX = 14, CH_TY = 30;                                   // tile: 14 columns x 30 rows (column-major planes: a 30-row run is 120 contiguous bytes)
+constexpr int CH_MX = CH_TX + 16, CH_MY = CH_TY + 16;                  // metric region (tile + 8)
+constexpr int CH_FX = CH_TX + 14, CH_FY = CH_TY + 14;                  // p0b region (tile + 7)
+constexpr int CH_SX = CH_TX + 2, CH_SY = CH_TY + 2;                    // p0c region (tile + 1): 16 x 32 = 512 pixels, two per thread
+constexpr int CH_MS = CH_MY + 1, CH_CS = CH_MY + 2, CH_FS = CH_FY + 1, CH_KS = CH_FY + 2, CH_SS = CH_SY + 1;   // row strides (odd word strides: no bank conflicts along a column of lanes)
+constexpr int CH_OFF_C = CH_MX * CH_MS * 4, CH_OFF_F = CH_OFF_C + CH_MX * CH_CS, CH_OFF_K = CH_OFF_F + CH_FX * CH_FS * 4;
+constexpr int CHAIN_LDS_BYTES = (CH_OFF_K + CH_FX * CH_KS * 2 + 15) / 16 * 16;
+static_assert(CH_OFF_F % 4 == 0 && CH_OFF_K % 2 == 0 && CH_SX * CH_SY == 512, "chain tile layout");
+
+// depth_filter.frag:16-80 for the pixel at (ci, cj) of a staged plane `d` (stride ds) whose classes are in `c` (stride cs, at
+// (ki, kj)); (gi, gj) is the pixel's position in the image (neighbours outside the image do not count: depth_filter.frag:52)
+__device__ __forceinline__ float chain_filter_px(const float *d, int ds, int ci, int cj, const uint8_t *c, int cs, int ki, int kj,
+                                                 int gi, int gj, int W, int H, float min_depth, float diff_thresh)
 {
-    const int q = blockIdx.x * 256 + threadIdx.x;
-    if (q >= fp.P) return;
-    const int H = fp.H;
-    const int i = q / H, j = q - i * H;
-    const float depth = inT[q];
-    const uint32_t cl = rgbsT[q] >> 24;
-    float r = depth;
-    const float px = (float)i + 0.5f, py = (float)j + 0.5f;
-    if (!(px < fp.stereo_border || depth <= fp.min_depth) && (cl >= 13u && cl <= 18u)) {
-        const float vx = (px - fp.cx) * depth / fp.fx, vy = (py - fp.cy) * depth / fp.fy;
-        const float3 t = xform3(t_c2l.m, vx, vy, depth);
-        const float ux = fp.fx * t.x / t.z + fp.cx;
-        const float uy = fp.fy * t.y / t.z + fp.cy;
-        const float uz = t.z;
-        if (!(uz <= fp.min_depth || uz >= 100.0f || ux < fp.stereo_border || ux > fp.cols || uy < 0.0f || uy > fp.rows)) {
-            const int qi = tex_idx(ux / fp.cols, fp.W), qj = tex_idx(uy / fp.rows, fp.H);
-            const float depth_last = lastT[qi * H + qj];
-            if (fabsf(uz - depth_last) > 0.5f) r = 0.0f;
+    // branch-free: the nine depths and classes are loaded together (one wait), the support is a sum of predicates
+    float dn[9];
+    uint32_t cn[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int ix = t % 3 - 1, iy = t / 3 - 1;
+        dn[t] = d[(ci + ix) * ds + cj + iy];
+        cn[t] = c[(ki + ix) * cs + kj + iy];
+    }
+    const float depth = dn[4];
+    const uint32_t cl = cn[4];
+    int support = 0;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        if (t == 4) continue;
+        const int qi = gi + t % 3 - 1, qj = gj + t / 3 - 1;
+        const bool in = qi >= 0 && qi < W && qj >= 0 && qj < H;                // depth_filter.frag:52
+        support += (in & (fabsf(dn[t] - depth) < diff_thresh) & (cl == cn[t])) ? 1 : 0;
+    }
+    if (depth <= min_depth || depth >= 100.0f || cl == 10u || cl == 11u || cl == 12u) return 0.0f;
+    return support >= 7 ? depth : 0.0f;
+}
+
+__device__ __forceinline__ void prep_chain_block(const PrepArgs &a, const ChainArgs &ch, const FrameParams &fp, uint32_t bid,
+                                                 unsigned char *lds /* CHAIN_LDS_BYTES, 16-byte aligned */)
+{
+    float *s_m = reinterpret_cast<float *>(lds);                                   // [CH_MX][CH_MS] metric depth; later [CH_SX][CH_SS] smoothed
+    uint8_t *s_c = lds + CH_OFF_C;                                                 // [CH_MX][CH_CS] class (any value outside the image: depth 0 there)
+    float *s_f = reinterpret_cast<float *>(lds + CH_OFF_F);                        // [CH_FX][CH_FS] p0b's output; later the tile's packed colour words
+    uint16_t *s_k = reinterpret_cast<uint16_t *>(lds + CH_OFF_K);                  // [CH_FX][CH_KS] the class of a pixel p0c may average, 0x100 for one it may not
+    const int W = fp.W, H = fp.H;
+    const int tiles_x = (W + CH_TX - 1) / CH_TX;
+    const int i0 = (int)(bid % (uint32_t)tiles_x) * CH_TX, j0 = (int)(bid / (uint32_t)tiles_x) * CH_TY;
+    const int tid = (int)threadIdx.x;
+    if (a.conf_sub && bid == 0 && tid < 64) a.conf_sub[tid * SUB_STRIDE] = 0u;
+    // ---- p0a: metricise the tile + 8 (lanes along the image row: the caller's images are row-major)
+    {
+        const uint32_t lo = (uint32_t)(fp.min_depth * 1000.0f);
+        const uint32_t hi = (uint32_t)((fp.max_depth - 0.001f) * 1000.0f);
+        for (int e = tid; e < CH_MX * CH_MY; e += 256) {
+            const int lj = e / CH_MX, li = e - lj * CH_MX;
+            const int gi = i0 - 8 + li, gj = j0 - 8 + lj;
+            float d = 0.0f;
+            uint32_t c = 255u;
+            if (gi >= 0 && gi < W && gj >= 0 && gj < H) {
+                const size_t p = (size_t)gj * W + gi;
+                const uint32_t v = a.depth_raw[p];
+                if (!((float)gi + 0.5f < fp.stereo_border) && v > lo && v < hi) d = (float)v / 1000.0f;
+                c = a.sem ? (uint32_t)a.sem[p] : 0u;
+            }
+            s_m[li * CH_MS + lj] = d;
+            s_c[li * CH_CS + lj] = (uint8_t)c;
         }
     }
-    outT[q] = r;
-    reinterpret_cast<uint32_t *>(dcT)[2 * (size_t)q] = __float_as_uint(r);     // the conflict test's packed copy
+    __syncthreads();
+    // ---- p0b: filter, 0.15, on the tile + 7; with it, per pixel, what p0c's taps test -- "inside the columns the smooth may read
+    // (texX >= stereoBorder / cols, depth_smooth.frag), depth in (min, 100)" -- folded into one 16-bit word with the class
+    for (int e = tid; e < CH_FX * CH_FY; e += 256) {
+        const int fi = e / CH_FY, fj = e - fi * CH_FY;
+        const int gi = i0 - 7 + fi, gj = j0 - 7 + fj;
+        float r = 0.0f;
+        if (gi >= 0 && gi < W && gj >= 0 && gj < H)
+            r = chain_filter_px(s_m, CH_MS, fi + 1, fj + 1, s_c, CH_CS, fi + 1, fj + 1, gi, gj, W, H, fp.min_depth, 0.15f);
+        s_f[fi * CH_FS + fj] = r;
+        const bool tap_ok = gi >= ch.border && gi < W && gj >= 0 && gj < H && !(r <= fp.min_depth || r >= 100.0f);
+        s_k[fi * CH_KS + fj] = tap_ok ? (uint16_t)s_c[(fi + 1) * CH_CS + fj + 1] : (uint16_t)0x100u;
+    }
+    __syncthreads();
+    // ---- p0c: 13 x 13 class-aware weighted mean on the tile + 1; accumulation order as the shader's (iy outer, ix inner).  A
+    // thread takes two pixels side by side in a row, (2c, r) and (2c + 1, r): per window row they share 12 of their 13 columns,
+    // so 14 depths + 14 validity-class words serve both (28 LDS reads for 26 taps; lanes run along the image column: odd row
+    // strides, no bank conflicts).  The result overwrites the metric plane (dead since p0b).
+    float sm[2] = {0.0f, 0.0f};
+    {
+        const int sc = tid >> 5, sj = tid & 31;                    // column pair, row of the 16 x 32 region
+        const int si = 2 * sc;
+        const int gi = i0 - 1 + si, gj = j0 - 1 + sj;
+        const float dep0 = s_f[(si + 6) * CH_FS + sj + 6], dep1 = s_f[(si + 7) * CH_FS + sj + 6];
+        const uint32_t cl0 = s_c[(si + 7) * CH_CS + sj + 7], cl1 = s_c[(si + 8) * CH_CS + sj + 7];
+        const bool act0 = gi >= 0 && gi < W && gj >= 0 && gj < H && !(dep0 <= fp.min_depth || dep0 >= 100.0f || cl0 == 10u);
+        const bool act1 = gi + 1 >= 0 && gi + 1 < W && gj >= 0 && gj < H && !(dep1 <= fp.min_depth || dep1 >= 100.0f || cl1 == 10u);
+        if (act0 || act1) {
+            // (a pixel that is not averaged runs along with an impossible class: its sums stay 0 and are not used)
+            const uint32_t k0 = act0 ? cl0 : 0x200u, k1 = act1 ? cl1 : 0x200u;
+            float s10 = 0.0f, s20 = 0.0f, s11 = 0.0f, s21 = 0.0f;
+            // A window row at a time: its LDS reads go out together and the taps are predicated, not branched -- with a branch per
+            // tap the compiler put an s_waitcnt behind every single read, three dependent LDS round trips per tap, and a tile took
+            // 108 us.  A tap is one compare (the word of s_k: class, or 0x100 where the smooth may not read), one select, one
+            // multiply, two adds: `w' = ok ? w : 0; sum1 += dk * w'; sum2 += w'` is the shader's arithmetic -- depths are finite and
+            // >= 0, so a skipped tap adds +0, and sums that start at +0 never become -0 (round to nearest): adding +0 changes
+            // nothing, and the taken adds come in the shader's order.  Its `valid > 0` is `sum2 > 0`: every weight is positive.
+#pragma unroll 1
+            for (int iy = -6; iy <= 6; ++iy) {
+                float dk[14];
+                uint32_t ck[14];
+#pragma unroll
+                for (int x = 0; x < 14; ++x) {
+                    dk[x] = s_f[(si + x) * CH_FS + sj + 6 + iy];
+                    ck[x] = s_k[(si + x) * CH_KS + sj + 6 + iy];
+                }
+#pragma unroll
+                for (int ix = 0; ix < 13; ++ix) {
+                    const float w = ch.w[(iy + 6) * 13 + ix];               // (wave-uniform index into the kernel arguments: a scalar load)
+                    const float w0 = (k0 == ck[ix]) ? w : 0.0f, w1 = (k1 == ck[ix + 1]) ? w : 0.0f;
+                    s10 += dk[ix] * w0; s20 += w0;
+                    s11 += dk[ix + 1] * w1; s21 += w1;
+                }
+            }
+            if (act0 && s20 > 0.0f) sm[0] = s10 / s20;
+            if (act1 && s21 > 0.0f) sm[1] = s11 / s21;
+        }
+    }
+    __syncthreads();                                   // every read of the metric plane (p0b) is long done; p0c's reads of s_f are done
+    float *s_s = s_m;                                  // [CH_SX][CH_SS]
+    uint32_t *s_rgb = reinterpret_cast<uint32_t *>(s_f);   // [CH_TX][CH_TY + 1] packed class | r | g | b of the tile
+    s_s[(2 * (tid >> 5)) * CH_SS + (tid & 31)] = sm[0];
+    s_s[(2 * (tid >> 5) + 1) * CH_SS + (tid & 31)] = sm[1];
+    // the tile's colour words: read along image rows (coalesced), used along columns below
+    for (int e = tid; e < CH_TX * CH_TY; e += 256) {
+        const int oj = e / CH_TX, oi = e - oj * CH_TX;
+        const int gi = i0 + oi, gj = j0 + oj;
+        uint32_t c = 0u;
+        if (gi < W && gj < H) {
+            const size_t p = (size_t)gj * W + gi;
+            uint32_t cr = 0, cg = 0, cb = 0;
+            if (a.rgb) { cr = a.rgb[p * 3]; cg = a.rgb[p * 3 + 1]; cb = a.rgb[p * 3 + 2]; }
+            c = ((uint32_t)s_c[(oi + 8) * CH_CS + oj + 8] << 24) | (cr << 16) | (cg << 8) | cb;
+        }
+        s_rgb[oi * (CH_TY + 1) + oj] = c;
+    }
+    __syncthreads();
+    // ---- p0d: filter, 0.10, and p0e: moving objects, on the tile; lanes along the image COLUMN (the planes are column-major)
+    for (int e = tid; e < CH_TX * CH_TY; e += 256) {
+        const int oi = e / CH_TY, oj = e - oi * CH_TY;
+        const int gi = i0 + oi, gj = j0 + oj;
+        if (gi >= W || gj >= H) continue;
+        const float f2 = chain_filter_px(s_s, CH_SS, oi + 1, oj + 1, s_c, CH_CS, oi + 8, oj + 8, gi, gj, W, H, fp.min_depth, 0.1f);
+        const uint32_t rgbs = s_rgb[oi * (CH_TY + 1) + oj];
+        const uint32_t cl = rgbs >> 24;
+        float out = s_s[(oi + 1) * CH_SS + oj + 1];    // the reference frame stops after p0d: DEPTH_METRIC holds p0c's output
+        if (ch.do_movings) {
+            // depth_movings.frag:20-82 (host src/SurfelMapping.cpp:336-365): pixels of movable classes (13..18) are reprojected
+            // into the previous frame and zeroed if |z_hat - z_last| > 0.5 m
+            out = f2;
+            const float px = (float)gi + 0.5f, py = (float)gj + 0.5f;
+            if (!(px < fp.stereo_border || f2 <= fp.min_depth) && (cl >= 13u && cl <= 18u)) {
+                const float vx = (px - fp.cx) * f2 / fp.fx, vy = (py - fp.cy) * f2 / fp.fy;
+                const float3 t = xform3(ch.t_c2l.m, vx, vy, f2);
+                const float ux = fp.fx * t.x / t.z + fp.cx;
+                const float uy = fp.fy * t.y / t.z + fp.cy;
+                const float uz = t.z;
+                if (!(uz <= fp.min_depth || uz >= 100.0f || ux < fp.stereo_border || ux > fp.cols || uy < 0.0f || uy > fp.rows)) {
+                    const int qi = tex_idx(ux / fp.cols, W), qj = tex_idx(uy / fp.rows, H);
+                    const float depth_last = ch.lastT[(size_t)qi * H + qj];
+                    if (fabsf(uz - depth_last) > 0.5f) out = 0.0f;
+                }
+            }
+        }
+        const size_t q = (size_t)gi * H + gj;
+        a.depthT[q] = out;
+        ch.filteredT[q] = f2;
+        a.rgbsT[q] = rgbs;
+        a.dcT[q] = make_uint2(__float_as_uint(out), rgbs);
+        if (a.keyT) a.keyT[q] = KEY_EMPTY;
+    }
 }
 
 // column-major -> row-major read-back helper (tests / GUI textures)
@@ -1637,47 +1721,74 @@ __device__ __forceinline__ void cand_count_block(uint32_t cg, const FrameParams 
 
 struct PassAcc { uint32_t vis, killed, nconf; };
 
-// NW consecutive 64-slot words (word0 ...) settled by one wave; sk0 / sk1: the tile's skip flags (conflict volume / index
-// map), any_dead: the tile holds slots killed by earlier frames.  Returns the conflicts found.
-template <int NW>
-__device__ __forceinline__ uint32_t pass_words(const SurfelSet &set, DevState *__restrict__ st, const FrameParams &fp,
-                                               const uint2 *__restrict__ dcT, uint64_t *__restrict__ cm, uint64_t *__restrict__ km,
-                                               uint64_t *__restrict__ alive, uint64_t *__restrict__ keyT, float *__restrict__ undo,
-                                               uint32_t N, uint32_t exempt, uint32_t word0, bool sk0, bool sk1,
-                                               bool any_dead, int lane, PassAcc &acc)
+// ---------------------------------------------------------------------------------------------
+// A tile is settled with its lanes COMPACTED first.  The exact tests cost ~350 IEEE-exact VALU instructions per surfel, and a
+// wave pays them for a whole 64-slot word as soon as ONE of its lanes is in view -- on a KITTI frame 61 % of the lanes of such
+// words are, on the 20 M-surfel stress model (uniformly scattered surfels: 97 % of the words hold a surfel in view, 3.5 of 64
+// lanes on average) 5 %.  So the workgroup first runs a cheap test over a tile's 1 024 slots (one load, the 3x4 transform, one
+// v_rcp_f32 and six compares per slot) that rejects only what BOTH exact view tests are certain to reject, collects the
+// slots of the rest in an LDS list -- over SEVERAL tiles while they fit (round 3: with ~50 listed slots per tile on the
+// scattered model the exact phase was one wave's dependent chain per tile; batched, 8 tiles share it) -- and then runs the
+// exact per-surfel code over that dense list, one entry per thread and round (two entries: 91 VGPRs instead of 75 and a
+// workgroup less per CU; measured slower at both sizes).  Bit-exact by construction: the pre-test is a strict superset (2-pixel margin against a
+// <= 1e-3-pixel difference between x * rcp(z) and the correctly rounded quotient; every comparison is written so that a NaN
+// does NOT reject; a surfel with conf <= 0, which dies wherever it is, is always kept), the masks are assembled with LDS
+// atomicOr instead of ballots, and every global side effect (undo, confidence, alive, key map, counters) is per slot or a
+// sum.  Workgroup-uniform control flow; one barrier per tile plus three per flush.
+// ---------------------------------------------------------------------------------------------
+constexpr int PASS_BATCH = 8;            // tiles whose compacted lanes may share one run of the exact tests
+
+struct PassLds {
+    float4 pos[TILE];                    // (x, y, z, confidence) of the listed slots, parked by phase A: phase B starts without a global round trip
+    uint32_t list[TILE];                 // listed slots: (tile's index in the batch << 10) | slot within its tile
+    uint32_t n;                          // entries
+    uint32_t pend[3];                    // entries the tile at hand wants to add (rotating: a counter is reset two tiles after its use)
+    uint32_t btile[PASS_BATCH], bflag[PASS_BATCH], drew[PASS_BATCH];          // tiles of the batch; their flags (1: outside the conflict volume, 2: cannot reach the index map, 4: holds dead slots)
+    uint32_t cm[PASS_BATCH][2 * TILE_WORDS], km[PASS_BATCH][2 * TILE_WORDS], gone[PASS_BATCH][2 * TILE_WORDS];   // per word (lo, hi): conflicts; killed by a conflict; removed (dead | conflict & dies)
+};
+
+// ---- phase B + the tiles' bookkeeping for the `nb` tiles of the batch (workgroup-uniform; leaves the list and the masks empty)
+__device__ __forceinline__ void pass_flush(const SurfelSet &set, DevState *__restrict__ st, const FrameParams &fp,
+                                           const uint2 *__restrict__ dcT, uint64_t *__restrict__ cm, uint64_t *__restrict__ km,
+                                           uint4 *__restrict__ wave_cnt, uint64_t *__restrict__ alive,
+                                           uint32_t *__restrict__ tile_dead, uint64_t *__restrict__ keyT, float *__restrict__ undo,
+                                           uint32_t N, uint32_t exempt, uint32_t nb, uint32_t wave, int lane, PassAcc &acc,
+                                           uint32_t *__restrict__ tb, PassLds &L)
 {
     float4 *__restrict__ pc = set.pos_conf;
-    // phase 1: the wave's 16-byte loads (and the times) in flight together
-    float4 v[NW];
-    float pt[NW];
-    uint64_t valid[NW];
+    const uint32_t tid = threadIdx.x;
+    __syncthreads();                                   // the list, the batch table
+    const uint32_t n_act = L.n;
+    // the exact tests (pass_words / splat_one, per lane) over the dense list, two entries per thread at a time
+    // (a single round of four entries per thread, staged so that a full tile pays each round trip once, was measured: 79
+    // VGPRs, 64 spilled scalars, and slower at every size but the smallest)
+    uint32_t my_vis = 0;
+    for (uint32_t b0 = 0; b0 + wave * 64u < n_act; b0 += 256u) {      // wave-uniform (no barrier inside): a wave without entries is through
+        bool has[1], sk0[1], sk1[1];
+        uint32_t sl[1], k[1], bi[1];
+        float4 e[1];
+        float pt[1];
 #pragma unroll
-    for (int r = 0; r < NW; ++r) {
-        const uint32_t k = (word0 + r) * 64u + lane;
-        const uint32_t kc = min(k, N - 1u);
-        v[r] = pc[kc];
-        pt[r] = sk1 ? 0.0f : set.time[kc];
-    }
+        for (int r = 0; r < 1; ++r) {
+            const uint32_t idx = b0 + (uint32_t)r * 256u + tid;
+            has[r] = idx < n_act;
+            const uint32_t ent = L.list[min(idx, n_act - 1u)];
+            bi[r] = ent >> 10; sl[r] = ent & 1023u;
+            const uint32_t fl = L.bflag[bi[r]];
+            sk0[r] = (fl & 1u) != 0u; sk1[r] = (fl & 2u) != 0u;
+            k[r] = L.btile[bi[r]] * (uint32_t)TILE + sl[r];
+            e[r] = L.pos[min(idx, n_act - 1u)];
+            pt[r] = sk1[r] ? 0.0f : set.time[k[r]];
+        }
+        bool conf[1], kp[1];
+        float zc[1], lam[1];
+        uint32_t qq[1];
+        bool inview[1];
 #pragma unroll
-    for (int r = 0; r < NW; ++r) {
-        const uint64_t base = (uint64_t)(word0 + r) * 64u;
-        uint64_t range = 0ull;
-        if (base < N) { const uint64_t rem = (uint64_t)N - base; range = rem >= 64 ? ~0ull : ((1ull << rem) - 1ull); }
-        valid[r] = range & (any_dead ? alive[word0 + r] : ~0ull);
-    }
-    uint64_t cw[NW], kw[NW], keep[NW];
-#pragma unroll
-    for (int r = 0; r < NW; ++r) { cw[r] = 0ull; kw[r] = 0ull; }
-    if (!sk0) {
-        // phase 2: projection + view test (conflict.vert:25-49); phase 3: the dependent (depth, class) gathers together
-        float zc[NW], lam[NW];
-        uint32_t qq[NW];
-        bool inview[NW];
-#pragma unroll
-        for (int r = 0; r < NW; ++r) {
-            inview[r] = false; zc[r] = 0.f; lam[r] = 0.f; qq[r] = 0u;
-            if ((valid[r] >> lane) & 1ull) {
-                const float3 ph = xform3(fp.t_inv, v[r].x, v[r].y, v[r].z);
+        for (int r = 0; r < 1; ++r) {
+            inview[r] = false; zc[r] = 0.f; lam[r] = 0.f; qq[r] = 0u; conf[r] = false;
+            if (has[r] && !sk0[r]) {
+                const float3 ph = xform3(fp.t_inv, e[r].x, e[r].y, e[r].z);
                 if (!(ph.z <= fp.min_depth || ph.z >= fp.max_depth)) {
                     const float xl = ph.x / ph.z;
                     const float yl = ph.y / ph.z;
@@ -1693,126 +1804,98 @@ __device__ __forceinline__ uint32_t pass_words(const SurfelSet &set, DevState *_
                 }
             }
         }
-        uint2 g[NW];
+        uint2 g[1];
 #pragma unroll
-        for (int r = 0; r < NW; ++r) g[r] = dcT[qq[r]];     // unconditional (pixel 0 for out-of-view lanes)
-        // phase 4: conflict rule (conflict.vert:51-73), ballots, the cull decision
+        for (int r = 0; r < 1; ++r) g[r] = dcT[qq[r]];          // unconditional (pixel 0 for the others)
 #pragma unroll
-        for (int r = 0; r < NW; ++r) {
-            const uint32_t k = (word0 + r) * 64u + lane;
-            bool conflict = false;
+        for (int r = 0; r < 1; ++r) {
             if (inview[r]) {
                 float depth = __uint_as_float(g[r].x);
                 if ((g[r].y >> 24) == 10u) depth = fp.max_depth + 1.0f;
                 if (fp.is_clean == 0 && depth == 0.0f) depth = fp.max_depth + 20.0f;
-                conflict = (depth * lam[r] - zc[r] * lam[r] > fp.conflict_thresh * zc[r]) && (k != exempt);
+                conf[r] = (depth * lam[r] - zc[r] * lam[r] > fp.conflict_thresh * zc[r]) && (k[r] != exempt);
             }
-            const bool isv = (valid[r] >> lane) & 1ull;
-            const bool dies = isv && !(v[r].w - 1.0f > 0.0f);
-            const bool dead = isv && !(v[r].w > 0.0f);
-            const uint64_t c = __ballot(conflict), d = __ballot(dies), z = __ballot(dead);
-            cw[r] = c;
-            kw[r] = c & d & ~z;                        // killed by the conflict (and only by it)
-            keep[r] = valid[r] & ~(z | (c & d));
+            // (a tile outside the conflict volume holds no dead surfel either: its listed slots are all kept)
+            const bool dies = has[r] && !sk0[r] && !(e[r].w - 1.0f > 0.0f);
+            const bool dead = has[r] && !sk0[r] && !(e[r].w > 0.0f);
+            kp[r] = has[r] && !(dead || (conf[r] && dies));
+            const uint32_t wi = (sl[r] >> 6) * 2u + ((sl[r] >> 5) & 1u), bit = 1u << (sl[r] & 31u);
+            if (conf[r]) atomicOr(&L.cm[bi[r]][wi], bit);
+            if (conf[r] && dies && !dead) atomicOr(&L.km[bi[r]][wi], bit);
+            if (has[r] && !kp[r]) {
+                atomicOr(&L.gone[bi[r]][wi], bit);
+                if (k[r] == exempt) st->fl_dirty = 1u;               // "id 0" died: the fixup searches its successor
+            }
         }
-    } else {
 #pragma unroll
-        for (int r = 0; r < NW; ++r) keep[r] = valid[r];   // a tile outside the conflict volume holds no dead surfel either
-    }
-#pragma unroll
-    for (int r = 0; r < NW; ++r) {
-        const uint32_t word = word0 + r;
-        const uint32_t k = word * 64u + lane;
-        const bool kp = (keep[r] >> lane) & 1ull;
-        if (keep[r] != valid[r]) {
-            const uint64_t base = (uint64_t)word * 64u;
-            const uint64_t rem = (uint64_t)N - base;   // base < N here: valid[r] != 0
-            const uint64_t range = rem >= 64 ? ~0ull : ((1ull << rem) - 1ull);
-            if (lane == 0) alive[word] = keep[r] | ~range;                  // the dead keep their slots
-            acc.killed += (uint32_t)__popcll(valid[r] ^ keep[r]);
-            if (k == exempt && ((valid[r] >> lane) & 1ull) && !kp) st->fl_dirty = 1u;   // "id 0" died: the fixup searches its successor
-        }
-        if (kp && ((cw[r] >> lane) & 1ull)) {
-            undo[k] = v[r].w;
-            pc[k].w = v[r].w - 1.0f;                                         // conflict.vert:72
-        }
-        if (!sk1) {                                                          // wave-uniform
-            bool drew = false;
-            if (kp) drew = splat_one(fp, v[r].x, v[r].y, v[r].z, pt[r], k, keyT);
-            acc.vis += (uint32_t)__popcll(__ballot(drew));
+        for (int r = 0; r < 1; ++r) {
+            if (kp[r] && conf[r]) {
+                undo[k[r]] = e[r].w;
+                pc[k[r]].w = e[r].w - 1.0f;                              // conflict.vert:72
+            }
+            if (!sk1[r] && kp[r] && splat_one(fp, e[r].x, e[r].y, e[r].z, pt[r], k[r], keyT)) { ++my_vis; L.drew[bi[r]] = 1u; }
         }
     }
-    uint32_t cwave = 0;
-    if (!sk0) {
-        // the wave's 2 x NW mask words in one store instruction (lanes 0 .. 2 NW - 1)
-        uint64_t mw = 0ull;
-#pragma unroll
-        for (int r = 0; r < NW; ++r) { if (lane == r) mw = cw[r]; if (lane == NW + r) mw = kw[r]; cwave += (uint32_t)__popcll(cw[r]); }
-        if (lane < 2 * NW) (lane >= NW ? km : cm)[word0 + (uint32_t)(lane >= NW ? lane - NW : lane)] = mw;
+    acc.vis += wave_sum_u32(my_vis);
+    __syncthreads();
+    // ---- per tile of the batch: masks, alive words, dead count, quarter-tile conflict counts (a wave per tile, one lane per word)
+    for (uint32_t b = wave; b < nb; b += 4u) {
+        const uint32_t tile = L.btile[b], fl = L.bflag[b];
+        uint32_t nc = 0, ng = 0;
+        if (lane < TILE_WORDS) {
+            const uint32_t word = tile * TILE_WORDS + (uint32_t)lane;
+            const uint64_t c = (uint64_t)L.cm[b][2 * lane] | ((uint64_t)L.cm[b][2 * lane + 1] << 32);
+            const uint64_t kk = (uint64_t)L.km[b][2 * lane] | ((uint64_t)L.km[b][2 * lane + 1] << 32);
+            const uint64_t gone = (uint64_t)L.gone[b][2 * lane] | ((uint64_t)L.gone[b][2 * lane + 1] << 32);
+            L.cm[b][2 * lane] = 0u; L.cm[b][2 * lane + 1] = 0u; L.km[b][2 * lane] = 0u; L.km[b][2 * lane + 1] = 0u;
+            L.gone[b][2 * lane] = 0u; L.gone[b][2 * lane + 1] = 0u;
+            if (!(fl & 1u)) { cm[word] = c; km[word] = kk; }
+            if (gone) {
+                const uint64_t base = (uint64_t)word * 64u;
+                const uint64_t rem = (uint64_t)N - base;                 // base < N: a slot of this word was valid
+                const uint64_t range = rem >= 64 ? ~0ull : ((1ull << rem) - 1ull);
+                const uint64_t was = range & ((fl & 4u) ? alive[word] : ~0ull);
+                alive[word] = (was & ~gone) | ~range;                    // the dead keep their slots
+            }
+            nc = (uint32_t)__popcll(c);
+            ng = (uint32_t)__popcll(gone);
+        }
+        // conflicts per quarter tile = sums over four consecutive lanes (words)
+        uint32_t q = nc;
+        q += __shfl_xor(q, 1);
+        q += __shfl_xor(q, 2);
+        const uint32_t q0 = lane_bcast(q, 0), q1 = lane_bcast(q, 4), q2 = lane_bcast(q, 8), q3 = lane_bcast(q, 12);
+        const uint32_t killed = wave_sum_u32(ng);
+        if (lane == 0) {
+            wave_cnt[tile] = make_uint4(q0, q1, q2, q3);
+            if (killed) atomicAdd(&tile_dead[tile], killed);
+            // Something of this tile went into the index map, so it can be fused in this frame: stamp the tile's box with the frame's
+            // time.  (k_associate_direct leaves the time word to this kernel; "drawn at t" is never older than the last update of any
+            // surfel of the tile.  The stamp also tells the next frame's tile flags -- computed while this frame's association may
+            // still be moving surfels, k_assoc_prep -- which tiles not to skip: a tile that is merely visited must not keep itself
+            // alive that way.)
+            if (L.drew[b]) { atomicMax(&tb[(size_t)tile * 8 + 7], f2ord((float)fp.time)); L.drew[b] = 0u; }
+        }
+        acc.killed += killed;
+        acc.nconf += q0 + q1 + q2 + q3;
     }
-    return cwave;
+    if (tid == 0) L.n = 0u;
+    __syncthreads();
 }
 
-// one quarter tile (4 x 64 slots, word0 = tile * 16 + quarter * 4) settled by one wave, NW words at a time
-template <int NW>
-__device__ __forceinline__ void pass_quarter(const SurfelSet &set, DevState *__restrict__ st, const FrameParams &fp,
-                                             const uint2 *__restrict__ dcT, uint64_t *__restrict__ cm, uint64_t *__restrict__ km,
-                                             uint4 *__restrict__ wave_cnt, uint64_t *__restrict__ alive,
-                                             uint32_t *__restrict__ tile_dead, uint64_t *__restrict__ keyT, float *__restrict__ undo,
-                                             uint32_t N, uint32_t exempt, uint32_t tile, uint32_t quarter, bool sk0, bool sk1,
-                                             bool any_dead, int lane, PassAcc &acc, uint32_t *__restrict__ tb)
+// ---- phase A of one tile: the cheap superset test over its 1 024 slots (wave <-> four consecutive words, loads in flight
+// together); the slots that need the exact tests join the workgroup's list, which is flushed first if they would not fit.
+// `it` counts the workgroup's visited tiles; `nb` the tiles in the current batch.
+__device__ __forceinline__ void pass_tile_append(const SurfelSet &set, DevState *__restrict__ st, const FrameParams &fp,
+                                                 const uint2 *__restrict__ dcT, uint64_t *__restrict__ cm, uint64_t *__restrict__ km,
+                                                 uint4 *__restrict__ wave_cnt, uint64_t *__restrict__ alive,
+                                                 uint32_t *__restrict__ tile_dead, uint64_t *__restrict__ keyT, float *__restrict__ undo,
+                                                 uint32_t N, uint32_t exempt, uint32_t tile, uint32_t wave, bool sk0, bool sk1,
+                                                 bool any_dead, int lane, PassAcc &acc, uint32_t *__restrict__ tb, PassLds &L, uint32_t it,
+                                                 uint32_t &nb)
 {
-    const uint32_t word0 = tile * TILE_WORDS + quarter * 4u;
-    const uint32_t k0 = acc.killed, v0 = acc.vis;
-    uint32_t cwave = 0;
-#pragma unroll 1
-    for (int h = 0; h < 4; h += NW)
-        cwave += pass_words<NW>(set, st, fp, dcT, cm, km, alive, keyT, undo, N, exempt, word0 + (uint32_t)h, sk0, sk1, any_dead, lane, acc);
-    if (lane == 0) reinterpret_cast<uint32_t *>(wave_cnt)[(size_t)tile * 4 + quarter] = cwave;
-    const uint32_t killed = acc.killed - k0;
-    if (killed && lane == 0) atomicAdd(&tile_dead[tile], killed);
-    // Something of this quarter tile went into the index map, so it can be fused in this frame: stamp the tile's box with the
-    // frame's time.  (k_associate_direct leaves the time word to this kernel; "drawn at t" is never older than the last update
-    // of any surfel of the tile.  Stamping every VISITED tile would do for that, but the stamp also tells the next frame's
-    // tile flags -- computed while this frame's association may still be moving surfels, k_assoc_prep -- which tiles not to
-    // skip: a tile that merely keeps being visited must not keep itself alive that way.)
-    if (acc.vis != v0 && lane == 0) atomicMax(&tb[(size_t)tile * 8 + 7], f2ord((float)fp.time));
-    acc.nconf += cwave;
-}
-
-// ---------------------------------------------------------------------------------------------
-// The same tile settled with its lanes COMPACTED first (k_surfel_pass<., ., true>).  pass_words spends ~350 IEEE-exact VALU
-// instructions per 64-slot word as soon as ONE of its lanes is in view -- on a KITTI frame 61 % of the lanes of such words
-// are, on the 20 M-surfel stress model (uniformly scattered surfels: 97 % of the words hold a surfel in view, 3.5 of 64
-// lanes on average) 5 %.  So the workgroup first runs a cheap test over its 1 024 slots (one load, the 3x4 transform, one
-// v_rcp_f32 and six compares per slot) that rejects only what BOTH exact view tests are certain to reject, collects the
-// slot numbers of the rest in LDS, and then runs the exact per-surfel code -- unchanged, two entries per thread at a time
-// -- over that dense list.  Bit-exact by construction: the pre-test is a strict superset (2-pixel margin against a
-// <= 1e-3-pixel difference between x * rcp(z) and the correctly rounded quotient; every comparison is written so that a NaN
-// does NOT reject; a surfel with conf <= 0, which dies wherever it is, is always kept), the masks are assembled with LDS
-// atomicOr instead of ballots, and every global side effect (undo, confidence, alive, key map, counters) is per slot or a
-// sum.  Workgroup-uniform control flow; three barriers per tile.
-// ---------------------------------------------------------------------------------------------
-struct PassLds {
-    float4 pos[TILE];                    // their (x, y, z, confidence), parked by phase A: phase B starts without a global round trip
-    uint16_t list[TILE];                 // slots (within the tile) that need the exact tests
-    uint32_t n;                          // entries
-    uint32_t cm[2 * TILE_WORDS], km[2 * TILE_WORDS], gone[2 * TILE_WORDS];   // per word (lo, hi): conflicts; killed by a conflict; removed (dead | conflict & dies)
-    uint32_t drew;
-};
-
-__device__ __forceinline__ void pass_tile_compact(const SurfelSet &set, DevState *__restrict__ st, const FrameParams &fp,
-                                                  const uint2 *__restrict__ dcT, uint64_t *__restrict__ cm, uint64_t *__restrict__ km,
-                                                  uint4 *__restrict__ wave_cnt, uint64_t *__restrict__ alive,
-                                                  uint32_t *__restrict__ tile_dead, uint64_t *__restrict__ keyT, float *__restrict__ undo,
-                                                  uint32_t N, uint32_t exempt, uint32_t tile, uint32_t wave, bool sk0, bool sk1,
-                                                  bool any_dead, int lane, PassAcc &acc, uint32_t *__restrict__ tb, PassLds &L)
-{
-    float4 *__restrict__ pc = set.pos_conf;
+    const float4 *__restrict__ pc = set.pos_conf;
     const uint32_t tid = threadIdx.x;
-    if (tid < 2 * TILE_WORDS) { L.cm[tid] = 0u; L.km[tid] = 0u; L.gone[tid] = 0u; }
-    if (tid == 0) { L.n = 0u; L.drew = 0u; }
-    // ---- phase A: the cheap superset test over the tile's slots (wave <-> four consecutive words, loads in flight together)
     float4 v[4];
     uint64_t valid[4];
 #pragma unroll
@@ -1828,8 +1911,10 @@ __device__ __forceinline__ void pass_tile_compact(const SurfelSet &set, DevState
         if (base < N) { const uint64_t rem = (uint64_t)N - base; range = rem >= 64 ? ~0ull : ((1ull << rem) - 1ull); }
         valid[r] = range & (any_dead ? alive[word] : ~0ull);
     }
-    __syncthreads();                                   // the cleared masks and L.n
+    if (tid == 0) L.pend[(it + 1u) % 3u] = 0u;         // (last read two tiles ago: every thread has passed a barrier since)
     const float zs_max = fp.depth_cutoff * 1.5f;       // splat_one's far limit
+    uint64_t m[4];
+    uint32_t cnt = 0;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         bool act = false;
@@ -1844,142 +1929,41 @@ __device__ __forceinline__ void pass_tile_compact(const SurfelSet &set, DevState
             const bool rej_s = sk1 || ph.z >= zs_max || ph.z <= 0.0f || out_img;                             // index_map.vert:38-64 cannot pass
             act = !rej_c || !rej_s || (!sk0 && !(v[r].w > 0.0f));
         }
-        const uint64_t m = __ballot(act);
+        m[r] = __ballot(act);
+        cnt += (uint32_t)__popcll(m[r]);
+    }
+    if (lane == 0 && cnt) atomicAdd(&L.pend[it % 3u], cnt);
+    __syncthreads();                                   // this tile's demand; the previous tile's entries
+    if (L.n + L.pend[it % 3u] > (uint32_t)TILE || nb == (uint32_t)PASS_BATCH) {       // workgroup-uniform
+        pass_flush(set, st, fp, dcT, cm, km, wave_cnt, alive, tile_dead, keyT, undo, N, exempt, nb, wave, lane, acc, tb, L);
+        nb = 0u;
+        // (the tile's 16 KB again, from the cache: keeping them in registers across the flush cost the kernel 29 VGPRs -- 99
+        //  instead of 70 -- and with them two waves per SIMD)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const uint32_t k = (tile * TILE_WORDS + wave * 4u + (uint32_t)r) * 64u + (uint32_t)lane;
+            v[r] = pc[min(k, N - 1u)];
+        }
+    }
+    if (tid == 0) { L.btile[nb] = tile; L.bflag[nb] = (sk0 ? 1u : 0u) | (sk1 ? 2u : 0u) | (any_dead ? 4u : 0u); }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
         uint32_t base = 0;
-        if (lane == 0 && m) base = atomicAdd(&L.n, (uint32_t)__popcll(m));
+        if (lane == 0 && m[r]) base = atomicAdd(&L.n, (uint32_t)__popcll(m[r]));
         base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-        if (act) {
-            const uint32_t at = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-            L.list[at] = (uint16_t)((wave * 4u + (uint32_t)r) * 64u + (uint32_t)lane);
+        if ((m[r] >> lane) & 1ull) {
+            const uint32_t at = base + (uint32_t)__popcll(m[r] & ((1ull << lane) - 1ull));
+            L.list[at] = (nb << 10) | ((wave * 4u + (uint32_t)r) * 64u + (uint32_t)lane);
             L.pos[at] = v[r];
         }
     }
-    // (a workgroup with several tiles prefetching its next tile's 16 KB here, behind phase B -- 88 VGPRs, 5 waves per SIMD --
-    //  was measured on the 20 M-surfel model, ~10 tiles per workgroup: 156.5 us with, 156.6 us without)
-    __syncthreads();
-    const uint32_t n_act = L.n;
-    // ---- phase B: the exact tests (pass_words / splat_one, per lane) over the dense list, two entries per thread at a time
-    // (a single round of four entries per thread, staged so that a full tile pays each round trip once, was measured: 79
-    // VGPRs, 64 spilled scalars, and slower at every size but the smallest -- the launch is bound by what all its workgroups
-    // issue together, not by one workgroup's chain)
-    uint32_t my_vis = 0;
-    bool my_drew = false;
-    for (uint32_t b0 = 0; b0 + wave * 64u < n_act; b0 += 2u * 256u) {      // wave-uniform (no barrier inside): a wave without entries is through
-        bool has[2];
-        uint32_t sl[2], k[2];
-        float4 e[2];
-        float pt[2];
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const uint32_t idx = b0 + (uint32_t)r * 256u + tid;
-            has[r] = idx < n_act;
-            sl[r] = L.list[min(idx, n_act - 1u)];
-            k[r] = tile * (uint32_t)TILE + sl[r];
-            e[r] = L.pos[min(idx, n_act - 1u)];
-            pt[r] = sk1 ? 0.0f : set.time[k[r]];
-        }
-        bool conf[2] = {false, false}, kp[2];
-        if (!sk0) {
-            float zc[2], lam[2];
-            uint32_t qq[2];
-            bool inview[2];
-#pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                inview[r] = false; zc[r] = 0.f; lam[r] = 0.f; qq[r] = 0u;
-                if (has[r]) {
-                    const float3 ph = xform3(fp.t_inv, e[r].x, e[r].y, e[r].z);
-                    if (!(ph.z <= fp.min_depth || ph.z >= fp.max_depth)) {
-                        const float xl = ph.x / ph.z;
-                        const float yl = ph.y / ph.z;
-                        const float u = fp.fx * xl + fp.cx;
-                        const float vv = fp.fy * yl + fp.cy;
-                        if (!(u < fp.stereo_border || u > fp.cols || vv < 0.0f || vv > fp.rows)) {
-                            const int ti = tex_idx(u / fp.cols, fp.W), tj = tex_idx(vv / fp.rows, fp.H);
-                            qq[r] = (uint32_t)(ti * fp.H + tj);
-                            lam[r] = sqrtf((xl * xl + yl * yl) + 1.0f);
-                            zc[r] = ph.z;
-                            inview[r] = true;
-                        }
-                    }
-                }
-            }
-            uint2 g[2];
-#pragma unroll
-            for (int r = 0; r < 2; ++r) g[r] = dcT[qq[r]];          // unconditional (pixel 0 for the others)
-#pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                if (inview[r]) {
-                    float depth = __uint_as_float(g[r].x);
-                    if ((g[r].y >> 24) == 10u) depth = fp.max_depth + 1.0f;
-                    if (fp.is_clean == 0 && depth == 0.0f) depth = fp.max_depth + 20.0f;
-                    conf[r] = (depth * lam[r] - zc[r] * lam[r] > fp.conflict_thresh * zc[r]) && (k[r] != exempt);
-                }
-                const bool dies = has[r] && !(e[r].w - 1.0f > 0.0f);
-                const bool dead = has[r] && !(e[r].w > 0.0f);
-                kp[r] = has[r] && !(dead || (conf[r] && dies));
-                const uint32_t wi = (sl[r] >> 6) * 2u + ((sl[r] >> 5) & 1u), bit = 1u << (sl[r] & 31u);
-                if (conf[r]) atomicOr(&L.cm[wi], bit);
-                if (conf[r] && dies && !dead) atomicOr(&L.km[wi], bit);
-                if (has[r] && !kp[r]) {
-                    atomicOr(&L.gone[wi], bit);
-                    if (k[r] == exempt) st->fl_dirty = 1u;               // "id 0" died: the fixup searches its successor
-                }
-            }
-        } else {
-#pragma unroll
-            for (int r = 0; r < 2; ++r) kp[r] = has[r];                  // a tile outside the conflict volume holds no dead surfel either
-        }
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            if (kp[r] && conf[r]) {
-                undo[k[r]] = e[r].w;
-                pc[k[r]].w = e[r].w - 1.0f;                              // conflict.vert:72
-            }
-            if (!sk1 && kp[r] && splat_one(fp, e[r].x, e[r].y, e[r].z, pt[r], k[r], keyT)) { ++my_vis; my_drew = true; }
-        }
-    }
-    if (my_drew) L.drew = 1u;
-    acc.vis += wave_sum_u32(my_vis);
-    __syncthreads();
-    // ---- the tile's masks, alive words, dead count and quarter-tile conflict counts (wave 0: one lane per word)
-    if (wave == 0) {
-        uint32_t nc = 0, ng = 0;
-        if (lane < TILE_WORDS) {
-            const uint32_t word = tile * TILE_WORDS + (uint32_t)lane;
-            const uint64_t c = (uint64_t)L.cm[2 * lane] | ((uint64_t)L.cm[2 * lane + 1] << 32);
-            const uint64_t kk = (uint64_t)L.km[2 * lane] | ((uint64_t)L.km[2 * lane + 1] << 32);
-            const uint64_t gone = (uint64_t)L.gone[2 * lane] | ((uint64_t)L.gone[2 * lane + 1] << 32);
-            if (!sk0) { cm[word] = c; km[word] = kk; }
-            if (gone) {
-                const uint64_t base = (uint64_t)word * 64u;
-                const uint64_t rem = (uint64_t)N - base;                 // base < N: a slot of this word was valid
-                const uint64_t range = rem >= 64 ? ~0ull : ((1ull << rem) - 1ull);
-                const uint64_t was = range & (any_dead ? alive[word] : ~0ull);
-                alive[word] = (was & ~gone) | ~range;                    // the dead keep their slots
-            }
-            nc = (uint32_t)__popcll(c);
-            ng = (uint32_t)__popcll(gone);
-        }
-        // conflicts per quarter tile = sums over four consecutive lanes (words)
-        uint32_t q = nc;
-        q += __shfl_xor(q, 1);
-        q += __shfl_xor(q, 2);
-        const uint32_t q0 = lane_bcast(q, 0), q1 = lane_bcast(q, 4), q2 = lane_bcast(q, 8), q3 = lane_bcast(q, 12);
-        const uint32_t killed = wave_sum_u32(ng);
-        if (lane == 0) {
-            wave_cnt[tile] = make_uint4(q0, q1, q2, q3);
-            if (killed) atomicAdd(&tile_dead[tile], killed);
-            if (L.drew) atomicMax(&tb[(size_t)tile * 8 + 7], f2ord((float)fp.time));      // as pass_quarter
-        }
-        acc.killed += killed;
-        acc.nconf += q0 + q1 + q2 + q3;
-    }
+    ++nb;
 }
 
 // READY = true: k_prep evaluated the tile skip flags of the frame (one byte per tile, loaded together with DevState);
 // READY = false: the kernel evaluates them itself (frames whose k_prep ran before the previous frame had finished: the
 // depth filter chain on the second stream).  Workgroup <-> tile round-robin, wave <-> quarter tile.
-template <bool READY, int NW, bool COMPACT = false>
+template <bool READY>
 __global__ __launch_bounds__(256) void k_surfel_pass(Model M, DevState *__restrict__ st, FrameParams fp,
                                                      const uint2 *__restrict__ dcT, uint64_t *__restrict__ cm,
                                                      uint64_t *__restrict__ km, uint4 *__restrict__ wave_cnt,
@@ -2003,7 +1987,7 @@ __global__ __launch_bounds__(256) void k_surfel_pass(Model M, DevState *__restri
     const uint32_t tile_grid = gridDim.x, bid = gridDim.x - 1u - blockIdx.x;
     __shared__ uint8_t s_flags[64];
     __shared__ uint32_t s_a[4], s_b[4], s_c[4];
-    __shared__ PassLds s_pass;                         // (COMPACT only)
+    __shared__ PassLds s_pass;
     const int lane = threadIdx.x & 63;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     // flags and dead counts of this workgroup's first 64 tiles: addresses known without DevState, issued with it
@@ -2022,6 +2006,14 @@ __global__ __launch_bounds__(256) void k_surfel_pass(Model M, DevState *__restri
     uint64_t skip0 = 0, skip1 = 0;
     const uint32_t n_it = bid < ntiles ? (ntiles - 1u - bid) / tile_grid + 1u : 0u;       // this workgroup's tiles: bid + iter * grid
     const bool desc = n_it <= 64u;                      // (all of them fit the one-per-lane flags: highest first)
+    uint32_t n_visited = 0, n_batch = 0;               // tiles this workgroup has read; tiles in the current batch
+    {
+        for (uint32_t i = threadIdx.x; i < (uint32_t)PASS_BATCH * 2u * TILE_WORDS; i += 256u) { (&s_pass.cm[0][0])[i] = 0u; (&s_pass.km[0][0])[i] = 0u; (&s_pass.gone[0][0])[i] = 0u; }
+        if (threadIdx.x < (uint32_t)PASS_BATCH) s_pass.drew[threadIdx.x] = 0u;
+        if (threadIdx.x < 3u) s_pass.pend[threadIdx.x] = 0u;
+        if (threadIdx.x == 0) s_pass.n = 0u;
+        __syncthreads();
+    }
     for (uint32_t it = 0; it < n_it; ++it) {
         const uint32_t iter = desc ? n_it - 1u - it : it;
         const uint32_t tile = bid + iter * tile_grid;
@@ -2054,23 +2046,18 @@ __global__ __launch_bounds__(256) void k_surfel_pass(Model M, DevState *__restri
             if (!READY && threadIdx.x == 0) wave_cnt[tile] = make_uint4(0u, 0u, 0u, 0u);
             continue;
         }
-        if (COMPACT) {
+        {
             const bool tr_now = tr && tr_first;
             tr_first = false;
             if (tr_now && threadIdx.x == 0) { tr[1] = wall_clock64(); tr[4] = tile; }
-            pass_tile_compact(set, st, fp, dcT, cm, km, wave_cnt, alive, tile_dead, keyT, undo, N, exempt, tile, wave, sk0, sk1,
-                              lane_bcast(m_dead, sl) != 0u, lane, acc, tb, s_pass);
+            pass_tile_append(set, st, fp, dcT, cm, km, wave_cnt, alive, tile_dead, keyT, undo, N, exempt, tile, wave, sk0, sk1,
+                             lane_bcast(m_dead, sl) != 0u, lane, acc, tb, s_pass, n_visited, n_batch);
+            ++n_visited;
             if (tr_now && threadIdx.x == 0) { tr[2] = wall_clock64(); tr[5] = s_pass.n; }
-            __syncthreads();                           // s_pass is reused by the workgroup's next tile
-        } else {
-            const bool tr_now = tr && tr_first;
-            tr_first = false;
-            if (tr_now && threadIdx.x == 0) { tr[1] = wall_clock64(); tr[4] = tile; }
-            pass_quarter<NW>(set, st, fp, dcT, cm, km, wave_cnt, alive, tile_dead, keyT, undo, N, exempt, tile, wave, sk0, sk1,
-                             lane_bcast(m_dead, sl) != 0u, lane, acc, tb);
-            if (tr_now && threadIdx.x == 0) tr[2] = wall_clock64();
         }
     }
+    if (n_batch)                                       // workgroup-uniform
+        pass_flush(set, st, fp, dcT, cm, km, wave_cnt, alive, tile_dead, keyT, undo, N, exempt, n_batch, wave, lane, acc, tb, s_pass);
     __syncthreads();
     if (lane == 0) { s_a[wave] = acc.vis; s_b[wave] = acc.killed; s_c[wave] = acc.nconf; }
     __syncthreads();
@@ -2927,22 +2914,29 @@ __global__ __launch_bounds__(PIX_BLOCK) void k_associate_direct(AssocArgs a, Sha
 // Block ranges: the 32x32-pixel image tiles, the frame's tile flags (tile_prep_block with the "may still change" rule),
 // the association blocks.
 // ---------------------------------------------------------------------------------------------
-template <bool PAIR>
+template <bool PAIR, bool CHAIN>
 __global__ __launch_bounds__(PIX_BLOCK) void k_assoc_prep(AssocArgs a, PrepArgs p, FrameParams fp_new, TilePrep tp, uint32_t n_assoc,
-                                                          uint32_t n_img, unsigned long long *__restrict__ trace = nullptr /* SM_PASS_TRACE */)
+                                                          uint32_t n_img, ChainArgs ch, unsigned long long *__restrict__ trace = nullptr /* SM_PASS_TRACE */)
 {
     struct Stamp {              // entry / exit time of every workgroup (thread 0), for tools/pass_trace.py
         unsigned long long *t; unsigned long long t0;
         __device__ Stamp(unsigned long long *tr) : t(tr), t0(tr ? wall_clock64() : 0ull) {}
         __device__ ~Stamp() { if (t && threadIdx.x == 0 && blockIdx.x < 65536u) { t[(size_t)blockIdx.x * 2] = t0; t[(size_t)blockIdx.x * 2 + 1] = wall_clock64(); } }   // (the buffer holds 65 536 records)
     } stamp(trace);
-    // dispatch order: the short, streaming image tiles first.  (The chip holds ~2 048 workgroups of this size at once and the
-    // three parts together are ~2 300 at KITTI size, so the launch takes 16.4 us where the association alone takes 12.2 and
-    // k_prep alone 8.5: the parts overlap only partly.  Letting each image workgroup do four tiles in turn, so that
-    // everything is resident at once, made those workgroups the long pole: 25 us.)
-    // (round 2, second half: the association first.  All ~1 500 workgroups are in the chip within 0.3 us and their loads are one
-    //  burst served roughly in dispatch order; the association is the part with two or three DEPENDENT round trips, the image
-    //  tiles have one.)
+    // Dispatch order.  Without the chain: the association first -- all ~1 500 workgroups are in the chip within 0.3 us and their
+    // loads are one burst served roughly in dispatch order; the association is the part with two or three DEPENDENT round trips,
+    // the image tiles have one.  With the chain (CHAIN): the chain tiles first -- they are the long workgroups of the launch (169
+    // taps per pixel), the association fills the chip around them.
+    __shared__ __align__(16) unsigned char s_chain[CHAIN ? CHAIN_LDS_BYTES : 16];
+    if (CHAIN) {
+        if (blockIdx.x < n_img) { prep_chain_block(p, ch, fp_new, blockIdx.x, s_chain); return; }      // workgroup-uniform
+        const uint32_t b = blockIdx.x - n_img;
+        if (b >= n_assoc) { tile_prep_block(fp_new, tp, n_img + n_assoc); return; }
+        ShardArgs none;
+        none.validmask = nullptr; none.ownmask = nullptr; none.gmask = nullptr; none.nwords = 0u; none.owner = 1;
+        associate_direct_block<false, PAIR>(a, none, b);
+        return;
+    }
     if (blockIdx.x >= n_assoc) {                                                                  // workgroup-uniform
         const uint32_t b = blockIdx.x - n_assoc;
         if (b < tp.nfb) { tile_prep_block(fp_new, tp, n_assoc); return; }
@@ -2952,6 +2946,12 @@ __global__ __launch_bounds__(PIX_BLOCK) void k_assoc_prep(AssocArgs a, PrepArgs 
     ShardArgs none;
     none.validmask = nullptr; none.ownmask = nullptr; none.gmask = nullptr; none.nwords = 0u; none.owner = 1;
     associate_direct_block<false, PAIR>(a, none, blockIdx.x);
+}
+
+// stand-alone form (when something reads the frame's counters before the next frame's k_prep has run)
+__global__ __launch_bounds__(PIX_BLOCK) void k_shard_settle(ShardSettle a)
+{
+    shard_settle_body<1>(a, blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -3079,12 +3079,6 @@ __global__ __launch_bounds__(256) void k_shard_cap_repair(Model M, DevState *__r
         if (v) atomicAdd(&st->visible_count, v);
         if (rs) atomicSub(&st->n_kill, rs);
     }
-}
-
-// stand-alone form (when something reads the frame's counters before the next frame's k_prep has run)
-__global__ __launch_bounds__(PIX_BLOCK) void k_shard_settle(ShardSettle a)
-{
-    shard_settle_body<1>(a, blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------

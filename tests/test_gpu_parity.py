@@ -295,9 +295,8 @@ def test_fused_associate_append_variant_matches_oracle():
 
 
 @pytest.mark.parametrize("env", [{"SM_COMPACT_TICKETS": "1"}, {"SM_ONE_PASS": "0"}, {"SM_ONE_PASS": "0", "SM_NO_MERGED_FINALIZE": "1"},
-                                 {"SM_DIRECT_APPEND": "0"}, {"SM_DIRECT_APPEND": "0", "SM_TILE_FLAGS_IN_PREP": "0", "SM_PASS_NW": "4"},
+                                 {"SM_DIRECT_APPEND": "0"}, {"SM_DIRECT_APPEND": "0", "SM_TILE_FLAGS_IN_PREP": "0"},
                                  {"SM_DEFER_ASSOC": "0"}, {"SM_ASSOC_PAIR": "0"}, {"SM_ASSOC_PAIR": "0", "SM_DEFER_ASSOC": "0"},
-                                 {"SM_PASS_COMPACT": "0"}, {"SM_PASS_COMPACT": "0", "SM_TILE_FLAGS_IN_PREP": "0"},
                                  {"SM_PASS_TRACE": "@tmp"}])
 def test_kernel_variants_behind_switches_stay_bit_exact(env):
     """SM_COMPACT_TICKETS=1: the in-place compaction hands its moving tiles out from a ticket counter (the form used as
@@ -474,3 +473,31 @@ def test_raw_feedback_cloud_matches_oracle():
         assert_models_equal_nan_tolerant(o.download_raw_cloud(), h.download_raw_cloud(), f"raw cloud after reset pre={pre}")
         assert o.counts() == h.counts()
         assert_models_equal_nan_tolerant(o.download_model(), h.download_model(), f"model after raw-cloud downloads pre={pre}")
+
+
+def test_async_host_buffers_match_oracle():
+    """sm_process_frame_async: host images, no host wait -- the copy of frame f+1 overlaps frame f on a second stream (three
+    device input sets).  Registered (pinned) caller buffers and pageable ones (staged inside the call), a null depth / semantic
+    (keeps the previous texture, src/SurfelMapping.cpp:124-128), with the depth filter chain and without."""
+    for pre in (0, 1):
+        seq = moving_boxes_sequence(SMALL, 14, seed=8) if pre else synth.make_sequence(SMALL, synth.kitti_trajectory(14), seed=8, noise_mm=3.0)
+        o, h = pair(SMALL, preprocess=pre, stereo_border=20.0, max_sqrt_vertices=700, fuse_thresh=0.03, compact_period=4)
+        keep = []
+        for k, (rgb, d, s_, p) in enumerate(seq):
+            dd, ss = (None, None) if k == 6 else (d, s_)          # frame 6: rgb only
+            o.process_frame(rgb, seq[k - 1][1] if k == 6 else d, seq[k - 1][2] if k == 6 else s_, p)
+            if k % 2 == 0:                                       # every other frame from registered memory
+                bufs = [np.ascontiguousarray(x) for x in (rgb, d, s_)]
+                for b in bufs:
+                    h.pin_host(b)
+                keep.append(bufs)
+                h.process_frame_async(bufs[0], None if dd is None else bufs[1], None if ss is None else bufs[2], p)
+            else:
+                h.process_frame_async(rgb, dd, ss, p)
+            if k == 9:
+                h.inputs_consumed()
+        h.sync()
+        check(o, h, f"async host buffers, preprocess={pre}")
+        for bufs in keep:
+            for b in bufs:
+                h.unpin_host(b)
