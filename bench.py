@@ -289,9 +289,13 @@ def run_leg(capi, cam, frames, K, Wm, cfg_kw, *, events=True, mode="device", see
     sm = capi.SurfelMap(capi.make_config(**cam, **cfg_kw, enable_timing=0))
     prime(sm)
     dptr = stage_frames(sm, frames, P) if mode.startswith("device") else None
-    if mode == "host_async":            # a reader that reuses its buffers registers them once; here every frame is its own buffer
-        for rgb, depth, sem, _ in frames:
-            sm.pin_host(rgb); sm.pin_host(depth); sm.pin_host(sem)
+    if mode == "host_async":            # a reader that decodes into pinned buffers of the library (sm_host_alloc); here one set per frame
+        pinned = []
+        for rgb, depth, sem, pose in frames:
+            a, b, c = sm.host_array(rgb.shape, rgb.dtype), sm.host_array(depth.shape, depth.dtype), sm.host_array(sem.shape, sem.dtype)
+            a[...] = rgb; b[...] = depth; c[...] = sem
+            pinned.append((a, b, c, pose))
+        frames = pinned
     step = step_fn(sm, dptr)
     # no collector pause inside the timed region: with torch imported a full collection takes ~45 ms.  Collect BEFORE the
     # warm-up: a pause between warm-up and t0 lets the GPU clock down (+130 us on the first frames)

@@ -150,19 +150,16 @@ int sm_process_frame(sm_ctx *s, const uint8_t *rgb, const uint16_t *depth_mm,
 int sm_process_frame_device(sm_ctx *s, const uint8_t *d_rgb, const uint16_t *d_depth_mm,
                             const uint8_t *d_semantic, const float *pose16);
 /* The same for callers whose images live in HOST memory and who do not want to wait (SurfelMapping::processFrame uploads its
- * three images itself, src/SurfelMapping.cpp:122-128): the images are copied on a second stream into one of three device input
- * sets, so the 2.8 MB host-to-device copy of frame f+1 runs while frame f computes; the call returns once copy and frame are
- * enqueued.  Buffers registered with sm_pin_host_buffer (a reader that reuses its buffers registers them once) are copied from
- * in place and must stay unchanged until sm_inputs_consumed() or sm_sync() returns; any other buffer is first copied into
- * pinned staging inside the call and may be reused at once. */
+ * three images itself, src/SurfelMapping.cpp:122-128): the images are copied on two copy streams into one of three device input
+ * sets, so the 2.8 MB host-to-device copy of frame f+1 runs while frame f computes; the call returns once copies and frame are
+ * enqueued (it waits for the frame three calls back, which bounds the work in flight).  Images that live in buffers of
+ * sm_host_alloc -- pinned memory a reader decodes straight into -- are copied from in place and must stay unchanged until
+ * sm_inputs_consumed() or sm_sync() returns; any other pointer is first copied into pinned staging inside the call (one host
+ * memcpy) and may be reused at once.  Caller memory is never registered with the runtime. */
 int sm_process_frame_async(sm_ctx *s, const uint8_t *rgb, const uint16_t *depth_mm, const uint8_t *semantic, const float *pose16);
-int sm_pin_host_buffer(sm_ctx *s, const void *host, size_t bytes);     /* hipHostRegister, remembered by the context */
-int sm_unpin_host_buffer(sm_ctx *s, const void *host);
-/* pinned host memory owned by the context (hipHostMalloc) for readers that decode straight into it: the fastest source for
- * sm_process_frame_async (registered pageable memory is mapped to the device page by page on first use) */
-void *sm_host_alloc(sm_ctx *s, size_t bytes);
-int sm_host_free(sm_ctx *s, void *p);
 int sm_inputs_consumed(sm_ctx *s);                                     /* waits for the copies only, not for the frames */
+void *sm_host_alloc(sm_ctx *s, size_t bytes);                          /* hipHostMalloc, owned by the context */
+int sm_host_free(sm_ctx *s, void *p);
 /* Wait for all enqueued work; refresh counters; returns a sticky device-side error. */
 int sm_sync(sm_ctx *s);
 
@@ -255,33 +252,7 @@ int sm_export_model_device(sm_ctx *s, void **d_aos, uint32_t *n);
 /* ... and append `n` AoS surfels that already live in this GPU's memory to the model
  * (GlobalModel::concatenate's glCopyBufferSubData, src/GlobalModel.cpp:624-629). */
 int sm_append_model_aos_device(sm_ctx *s, const float *d_src12, uint32_t n);
-/* raw device pointer of the 64-bit depth|id key map (W*H, column-major) for the multi-GPU
- * min-reduction, and the entry points that bracket it */
-void *sm_key_map_device_ptr(sm_ctx *s);   /* (launches a held-back association first; valid until the next frame call on `s`) */
-/* per-pixel "fused by this rank" ballot words (ceil(W*H/64) x u64): sum-reduced over the ranks */
-void *sm_fused_mask_device_ptr(sm_ctx *s, uint32_t *nwords);
 int sm_device_download(sm_ctx *s, void *dst_host, const void *src_device, size_t bytes);
-
-/* ---- ONE camera stream sharded over `world` GPUs (BASELINE configs[3]; DESIGN.md "Multi-GPU").
- * Surfels created by fusing frame f live on rank f % world as "segment" f; the concatenation of
- * all segments in frame order is exactly the single-GPU model order.  Per frame every rank calls
- * the five stages below in lock-step; between them the caller (surfelmapping_amd/sharded.py)
- * reduces over the ranks: segment survivor counts (sum), the key map (min), the fused mask (sum).
- * The W*H conflict cap cannot be evaluated per shard and is off in this mode. */
-int sm_shard_configure(sm_ctx *s, int rank, int world);
-/* upload + pre-process (src/SurfelMapping.cpp:115-158); returns 1 if the fusing stages follow, 0 if not */
-int sm_shard_begin_frame(sm_ctx *s, const uint8_t *rgb, const uint16_t *depth_mm,
-                         const uint8_t *semantic, const float *pose16);
-/* p2/p3 on the local slice.  exempt_local: local index of the surfel with global id 0 (or 0xFFFFFFFF);
- * seg_lstart_old[nseg+1]: local start of every local segment; out: survivors per segment, conflicts */
-int sm_shard_conflict(sm_ctx *s, uint32_t exempt_local, const uint32_t *seg_lstart_old, int nseg,
-                      uint32_t *seg_keep_out, uint32_t *conflict_out);
-/* p4..p6: compaction + splat under GLOBAL ids (seg_gbase[nseg]: global id of each local segment's first surfel) */
-int sm_shard_cull_splat(sm_ctx *s, const uint32_t *seg_lstart_new, const uint32_t *seg_gbase, int nseg);
-/* p8..p10 for the pixels whose (min-reduced) winner this rank owns; gseg_base[n_gseg+1] */
-int sm_shard_associate(sm_ctx *s, const uint32_t *gseg_base, int n_gseg);
-/* p11 on the rank that owns this frame's segment (append_here), counters everywhere; ends the frame */
-int sm_shard_append(sm_ctx *s, int append_here);
 
 /* Diagnostic: processes that hold compute queues on this context's GPU according to the KFD driver's tables (>= 1: this
  * one included), or -1 if /sys/class/kfd is not readable.  The in-place compaction switches to its ticket-ordered form
@@ -289,13 +260,13 @@ int sm_shard_append(sm_ctx *s, int append_here);
  * re-read at most once per second.  SM_COMPACT_TICKETS=1 / 0 overrides the detection. */
 int sm_gpu_process_count(sm_ctx *s);
 
-/* ---- The same sharding, in-stream form: no host or Python between the stages of a frame.  Every rank
- * addresses surfels by the slot number the single-GPU run uses and stores only the segments it owns (owner of a frame's
- * new surfels = fusing-frame index % world); the key map (min) and the fused-pixel mask + 3 counters (sum) are
- * all-reduced on the context's own stream through the installed collective -- RCCL's ncclAllReduce, bound at run time
- * by sm_shard_rccl_init, or any callback with the same meaning (tests: several contexts on one GPU).  All ranks hold
- * the same counters (sm_get_counts) after every frame.  Replaces the per-stage calls above and the Python loop over
- * them (surfelmapping_amd/sharded.py) for production use; results are bit-identical to the single-GPU path. */
+/* ---- ONE camera stream sharded over `world` GPUs (BASELINE configs[3]): no host or Python between the stages of a
+ * frame.  Every rank addresses surfels by the slot number the single-GPU run uses and stores only the segments it owns (owner
+ * of a frame's new surfels = fusing-frame index % world); the key map (min), the fused-pixel mask + 3 counters (sum) and -- when
+ * the model has more slots than pixels and the conflict cap is on -- the conflict masks (sum) are all-reduced on the context's
+ * own stream through the installed collective -- RCCL's ncclAllReduce, bound at run time by sm_shard_rccl_init, or any callback
+ * with the same meaning (tests: several contexts on one GPU).  All ranks hold the same counters (sm_get_counts) after every
+ * frame; results are bit-identical to the single-GPU path, the W*H conflict cap included. */
 enum { SM_COLL_SUM = 0, SM_COLL_MIN = 1, SM_COLL_GATHER = 2 };
 /* SUM / MIN: all-reduce `count` unsigned 64-bit words from `send` to `recv` (may be equal; device memory of this context) over
  * the ranks.  GATHER: all-gather -- every rank contributes `count` words at `send`, `recv` receives world * count words, rank q's

@@ -19,15 +19,13 @@ TEX_DEPTH_METRIC, TEX_DEPTH_FILTERED, TEX_LAST = 0, 1, 2
 # every extern "C" symbol include/sm_c_api.h declares
 SYMBOLS = (
     "sm_api_version", "sm_last_error", "sm_default_config", "sm_create", "sm_destroy",
-    "sm_process_frame", "sm_process_frame_device", "sm_process_frame_async", "sm_pin_host_buffer", "sm_unpin_host_buffer",
+    "sm_process_frame", "sm_process_frame_device", "sm_process_frame_async",
     "sm_inputs_consumed", "sm_host_alloc", "sm_host_free", "sm_sync", "sm_clean_points", "sm_clean_points_ex", "sm_clean_points_cb", "sm_reset",
     "sm_get_counts", "sm_download_model_aos", "sm_upload_model_aos", "sm_save_map", "sm_load_map",
     "sm_download_index_map", "sm_download_raw_cloud", "sm_download_depth", "sm_render_image", "sm_set_frame", "sm_set_tick",
     "sm_stage_conflict", "sm_stage_cull", "sm_stage_splat", "sm_stage_associate_fuse",
     "sm_stage_timings", "sm_read_frame_log", "sm_device_alloc", "sm_device_free", "sm_device_upload",
-    "sm_export_model_device", "sm_append_model_aos_device", "sm_key_map_device_ptr",
-    "sm_fused_mask_device_ptr", "sm_device_download", "sm_shard_configure", "sm_shard_begin_frame",
-    "sm_shard_conflict", "sm_shard_cull_splat", "sm_shard_associate", "sm_shard_append",
+    "sm_export_model_device", "sm_append_model_aos_device", "sm_device_download",
     "sm_shard_stream_configure", "sm_shard_set_collective", "sm_shard_rccl_unique_id", "sm_shard_rccl_init",
     "sm_shard_rccl_finalize", "sm_shard_rccl_nranks", "sm_shard_frame_device", "sm_shard_frame", "sm_shard_compact", "sm_shard_export_dense_device",
     "sm_gpu_process_count", "sm_rig_configure", "sm_rig_consolidate",
@@ -168,8 +166,6 @@ def load():
     L.sm_process_frame.argtypes = [vp, vp, vp, vp, vp]
     L.sm_process_frame_device.argtypes = [vp, vp, vp, vp, vp]
     L.sm_process_frame_async.argtypes = [vp, vp, vp, vp, vp]
-    L.sm_pin_host_buffer.argtypes = [vp, vp, C.c_size_t]
-    L.sm_unpin_host_buffer.argtypes = [vp, vp]
     L.sm_inputs_consumed.argtypes = [vp]
     L.sm_host_alloc.restype = vp
     L.sm_host_alloc.argtypes = [vp, C.c_size_t]
@@ -202,15 +198,7 @@ def load():
     L.sm_device_upload.argtypes = [vp, vp, vp, C.c_size_t]
     L.sm_export_model_device.argtypes = [vp, C.POINTER(vp), u32p]
     L.sm_append_model_aos_device.argtypes = [vp, vp, C.c_uint32]
-    L.sm_fused_mask_device_ptr.restype = vp
-    L.sm_fused_mask_device_ptr.argtypes = [vp, u32p]
     L.sm_device_download.argtypes = [vp, vp, vp, C.c_size_t]
-    L.sm_shard_configure.argtypes = [vp, C.c_int, C.c_int]
-    L.sm_shard_begin_frame.argtypes = [vp, vp, vp, vp, vp]
-    L.sm_shard_conflict.argtypes = [vp, C.c_uint32, vp, C.c_int, vp, u32p]
-    L.sm_shard_cull_splat.argtypes = [vp, vp, vp, C.c_int]
-    L.sm_shard_associate.argtypes = [vp, vp, C.c_int]
-    L.sm_shard_append.argtypes = [vp, C.c_int]
     L.sm_shard_stream_configure.argtypes = [vp, C.c_int, C.c_int]
     L.sm_shard_set_collective.argtypes = [vp, COLLECTIVE_FN, vp]
     L.sm_shard_rccl_unique_id.argtypes = [vp]
@@ -224,8 +212,6 @@ def load():
     L.sm_gpu_process_count.argtypes = [vp]
     L.sm_rig_configure.argtypes = [vp, C.c_int, C.c_int]
     L.sm_rig_consolidate.argtypes = [vp, vp, vp, vp, vp, u32p, u32p]
-    L.sm_key_map_device_ptr.restype = vp
-    L.sm_key_map_device_ptr.argtypes = [vp]
     for name in SYMBOLS:
         getattr(L, name)          # AttributeError here = the library does not match the header
     _lib = L
@@ -290,17 +276,12 @@ class SurfelMap:
                          "sm_process_frame_device")
 
     def process_frame_async(self, rgb, depth, sem, pose):
-        """host arrays, no host wait: the copy of this frame overlaps the previous frame (sm_process_frame_async).  Arrays
-        registered with pin_host() are read in place until inputs_consumed() / sync(); others are staged inside the call."""
+        """host arrays, no host wait: the copy of this frame overlaps the previous frame (sm_process_frame_async).  Arrays made by
+        host_array() (pinned, owned by the context) are read in place until inputs_consumed() / sync(); others are staged inside
+        the call."""
         assert rgb.dtype == np.uint8 and rgb.flags.c_contiguous
         pose = np.ascontiguousarray(pose, np.float32)
         return self._chk(self._L.sm_process_frame_async(self._h, _ptr(rgb), _ptr(depth), _ptr(sem), _ptr(pose)), "sm_process_frame_async")
-
-    def pin_host(self, arr: np.ndarray):
-        self._chk(self._L.sm_pin_host_buffer(self._h, _ptr(arr), arr.nbytes), "sm_pin_host_buffer")
-
-    def unpin_host(self, arr: np.ndarray):
-        self._chk(self._L.sm_unpin_host_buffer(self._h, _ptr(arr)), "sm_unpin_host_buffer")
 
     def host_array(self, shape, dtype) -> np.ndarray:
         """a numpy array in pinned host memory owned by the context (sm_host_alloc): the fastest source for process_frame_async"""
@@ -476,47 +457,7 @@ class SurfelMap:
         self._chk(self._L.sm_device_download(self._h, _ptr(out), src, nbytes), "sm_device_download")
         return out
 
-    def fused_mask_device_ptr(self):
-        n = C.c_uint32()
-        p = self._L.sm_fused_mask_device_ptr(self._h, C.byref(n))
-        return p, n.value
-
-    # -- sharded mode (see surfelmapping_amd/sharded.py)
-    def shard_configure(self, rank, world):
-        self._chk(self._L.sm_shard_configure(self._h, rank, world), "sm_shard_configure")
-
-    def shard_begin_frame(self, rgb, depth, sem, pose) -> int:
-        rgb = np.ascontiguousarray(rgb, np.uint8)
-        depth = np.ascontiguousarray(depth, np.uint16)
-        sem = np.ascontiguousarray(sem, np.uint8)
-        pose = np.ascontiguousarray(pose, np.float32)
-        return self._chk(self._L.sm_shard_begin_frame(self._h, _ptr(rgb), _ptr(depth), _ptr(sem), _ptr(pose)),
-                         "sm_shard_begin_frame", allow=(0, 1))
-
-    def shard_conflict(self, exempt_local, seg_lstart_old):
-        ls = np.ascontiguousarray(seg_lstart_old, np.uint32)
-        nseg = ls.shape[0] - 1
-        keep = np.zeros(max(nseg, 1), np.uint32)
-        c = C.c_uint32()
-        self._chk(self._L.sm_shard_conflict(self._h, int(exempt_local) & 0xFFFFFFFF, _ptr(ls), nseg, _ptr(keep), C.byref(c)),
-                  "sm_shard_conflict")
-        return keep[:nseg], c.value
-
-    def shard_cull_splat(self, seg_lstart_new, seg_gbase):
-        ls = np.ascontiguousarray(seg_lstart_new, np.uint32)
-        gb = np.ascontiguousarray(seg_gbase, np.uint32)
-        if gb.shape[0] == 0:
-            gb = np.zeros(1, np.uint32)
-        self._chk(self._L.sm_shard_cull_splat(self._h, _ptr(ls), _ptr(gb), ls.shape[0] - 1), "sm_shard_cull_splat")
-
-    def shard_associate(self, gseg_base):
-        gb = np.ascontiguousarray(gseg_base, np.uint32)
-        self._chk(self._L.sm_shard_associate(self._h, _ptr(gb), gb.shape[0] - 1), "sm_shard_associate")
-
-    def shard_append(self, append_here: bool, allow=(0,)):
-        return self._chk(self._L.sm_shard_append(self._h, 1 if append_here else 0), "sm_shard_append", allow)
-
-    # -- sharded mode, in-stream form (slot-addressed; the collectives run on the context's stream)
+    # -- ONE stream sharded over several GPUs (slot-addressed; the collectives run on the context's stream; surfelmapping_amd/sharded.py)
     def shard_stream_configure(self, rank, world):
         self._chk(self._L.sm_shard_stream_configure(self._h, rank, world), "sm_shard_stream_configure")
 
@@ -598,6 +539,3 @@ class SurfelMap:
     def gpu_process_count(self) -> int:
         """processes with compute queues on this context's GPU per the KFD tables (this one included); -1 if unreadable"""
         return self._L.sm_gpu_process_count(self._h)
-
-    def key_map_device_ptr(self) -> int:
-        return self._L.sm_key_map_device_ptr(self._h)

@@ -274,7 +274,7 @@ struct sm_ctx {
     uint8_t *d_rgb = nullptr, *d_sem = nullptr;
     uint16_t *d_depth_raw = nullptr;
     // sm_process_frame_async: a ring of device input sets filled on a copy stream, so that the H2D copy of frame f+1 runs while
-    // frame f computes; caller buffers registered with sm_pin_host_buffer are copied from in place, others through pinned staging
+    // frame f computes; images in buffers of sm_host_alloc are copied from in place, others through pinned staging
     static constexpr int IN_RING = 3;
     struct InSlot { uint8_t *rgb = nullptr, *sem = nullptr; uint16_t *depth = nullptr; unsigned char *h_stage = nullptr;
                     hipEvent_t ev_in = nullptr, ev_in2 = nullptr, ev_free = nullptr; bool used = false; };
@@ -283,8 +283,11 @@ struct sm_ctx {
     uint32_t in_next = 0;
     const uint16_t *in_last_depth = nullptr; const uint8_t *in_last_sem = nullptr;     // device copies of the last depth / semantic image given
     int in_depth_slot = -1, in_sem_slot = -1;                                          // ... and the input sets that hold them
-    std::vector<std::pair<const unsigned char *, size_t>> pinned;                      // host ranges registered by sm_pin_host_buffer (and the ranges below)
-    std::vector<void *> host_allocs;                                                   // pinned host buffers handed out by sm_host_alloc
+    // Pinned host buffers handed out by sm_host_alloc (their ranges in `pinned`): the sources sm_process_frame_async copies from in
+    // place.  Caller memory is never registered: hipHostRegister / hipHostUnregister of heap ranges left the runtime treating
+    // later, unrelated host arrays at the same addresses as pinned -- a GPU memory fault in whatever copied to or from them next.
+    std::vector<std::pair<const unsigned char *, size_t>> pinned;
+    std::vector<void *> host_allocs;
     float *d_depth_f32 = nullptr;
     float *d_xs = nullptr, *d_ys = nullptr;
     float h_wtab[169];                 // depth_smooth.frag's 13 x 13 weights (host-computed, handed to the chain stage as kernel arguments)
@@ -307,8 +310,6 @@ struct sm_ctx {
     uint4 *d_lazy_part = nullptr;      // partials of k_cull_lazy_frame / k_surfel_pass (visible, splat-skipped, killed, conflict-skipped)
     bool lazy_part_live = false;       // the next append folds d_lazy_part (not d_compact_part) into the counters
     // one pass over the surfels per frame (k_surfel_pass + k_pass_fixup) on the frames whose cull only marks the dead
-    bool one_pass = true;              // SM_ONE_PASS=0: keep k_conflict + k_cull_lazy(_frame)
-    bool use_list = true;              // SM_TILE_FLAGS_IN_PREP=0: the one-pass kernel evaluates the tile flags itself
     uint4 *d_wave_cnt = nullptr;       // conflicts per quarter tile (one word per wave)
     float *d_undo = nullptr;           // confidence before this frame's decrement, per slot (read only if the conflict cap binds)
     uint2 *d_fix_part = nullptr;       // partials of k_pass_fixup (visible added, resurrected)
@@ -324,7 +325,6 @@ struct sm_ctx {
     bool want_list = false;            // set by enqueue_frame before begin_frame launches k_prep
     int fix_grid = 128;
     // direct append (k_associate_direct): candidate counts per association block / per group, group prefixes
-    bool direct = true;                // SM_DIRECT_APPEND=0: k_associate + k_append_scan on every frame
     uint32_t *d_blk_cand = nullptr, *d_grp_cand = nullptr;
     uint32_t *d_frame_sub = nullptr;   // 4 x 64 sub-counters: visible, killed (k_surfel_pass), new, fused (k_associate_direct)
     uint32_t n_grp = 0, cand_group = 16;
@@ -334,7 +334,6 @@ struct sm_ctx {
     int pass_trace_grid = 0;
     unsigned long long *d_ap_trace = nullptr;     // the same for the last k_assoc_prep launch: (entry, exit) per workgroup
     int ap_trace_n[3] = {0, 0, 0};                // its association / tile-flag / image workgroups (dispatch order)
-    bool merged_finalize = true;       // SM_NO_MERGED_FINALIZE=1: keep k_cull_finalize + k_cull_lazy as separate launches
     uint32_t *d_conf_sub = nullptr;    // 2 x 64 conflict sub-counters (one set per frame parity: zeroed by that frame's k_prep)
     int conf_sub_set = 0;
     uint32_t n_conf_part = 0, n_compact_part = 0;
@@ -344,18 +343,7 @@ struct sm_ctx {
     int pass_grid = MAX_GRID;          // workgroups of k_surfel_pass that are resident at once (a larger grid runs its tail as a second, thin wave)
     // association scratch
     uint64_t *d_validmask = nullptr, *d_fusedmask = nullptr;
-    uint32_t *d_blk_prefix = nullptr;
     uint2 *d_blk_cnt = nullptr;
-    unsigned long long *d_desc = nullptr;   // look-back granules of k_associate_append
-    uint32_t assoc_epoch = 0;
-    int assoc_grid = 1024;
-    bool use_fused_assoc = false;
-    // multi-GPU segment tables (device copies; nseg == 0 on a single GPU)
-    uint32_t *d_seg_lstart = nullptr, *d_seg_gbase = nullptr, *d_gseg_base = nullptr, *d_seg_keep = nullptr;
-    uint32_t seg_cap = 0;
-    int sh_rank = 0, sh_world = 1, sh_nseg = 0, sh_ngseg = 0;
-    uint32_t sh_exempt = 0;
-    bool sh_in_frame = false;
     // slot-addressed sharding of one stream, in-stream form (sm_shard_stream_*)
     bool ss_on = false;
     bool rig_on = false;               // sm_rig_configure: rank / world / collective are used by sm_rig_consolidate only
@@ -365,6 +353,7 @@ struct sm_ctx {
     void *ss_user = nullptr;
     void *ss_comm = nullptr;           // ncclComm_t when the built-in RCCL binding is used
     uint64_t *d_galive = nullptr, *d_new_alive = nullptr, *d_gmask = nullptr;
+    uint32_t *d_chk = nullptr;         // SM_CHECK_ALIVE=1: result words of k_check_alive
     uint64_t *d_capx = nullptr;        // the conflict-cap exchange of a sharded frame: total | quarter-tile counts | conflict masks (k_shard_cap_pack)
     uint32_t *d_ss_info = nullptr;
     // deferred association (k_assoc_prep): the association of an asynchronous frame is held back until the next frame's images
@@ -373,7 +362,6 @@ struct sm_ctx {
     bool assoc_pending = false;
     AssocArgs assoc_args{};            // the held-back association (its FrameParams and that frame's planes)
     bool merge_assoc = false;          // set by enqueue_frame: the k_prep launch of this call carries assoc_args
-    bool assoc_pair = true;            // k_associate_direct / k_assoc_prep take two consecutive pixels per thread (SM_ASSOC_PAIR=0: one)
     bool ss_settle_pending = false;    // the last sharded frame's k_shard_settle work rides on the next k_prep (or runs stand-alone first)
     ShardSettle ss_settle{};
     int n_pix_blocks = 0;
@@ -448,17 +436,11 @@ FrameParams make_params(const sm_ctx *s, const float *pose)
     fp.depth_cutoff = c.far_clip;
     fp.conflict_cap = c.conflict_cap ? (uint32_t)s->P : 0xFFFFFFFFu;
     fp.max_vertices = s->cap;
-    fp.exempt_local = s->sh_world > 1 ? s->sh_exempt : 0u;
-    fp.nseg = s->sh_world > 1 ? s->sh_nseg : 0;
-    fp.n_gseg = s->sh_world > 1 ? s->sh_ngseg : 0;
-    fp.rank = s->sh_rank;
-    fp.world = s->sh_world;
-    fp.append_here = 1;
     fp.init_mode = 0;
     fp.inv_fx_fb = 1.0f / c.fx;
     fp.inv_fy_fb = 1.0f / c.fy;
     fp.use_bounds = c.disable_tile_bounds ? 0 : 1;
-    fp.compact_now = 1;                     // per-pass entry points and sharded frames compact at every cull
+    fp.compact_now = 1;                     // the per-pass entry points compact at every cull
     fp.maintenance = 0;
     return fp;
 }
@@ -482,6 +464,13 @@ int push_state(sm_ctx *s)
 // a direct-append frame leaves its new / fused totals, the dead-slot total and its log entry to be completed by the next
 // frame's k_pass_fixup; everything else that reads them asks for the completion first
 int flush_assoc(sm_ctx *s);
+
+// SM_CHECK_ALIVE=1 (diagnostic): check the alive-bits / dead-count invariant after a stage; reported by sm_sync
+void check_alive(sm_ctx *s, uint32_t stage)
+{
+    if (!s->d_chk) return;
+    hipLaunchKernelGGL(k_check_alive, dim3(64), dim3(256), 0, s->stream, s->d_state, s->d_alive, s->d_tile_dead, s->d_chk, stage);
+}
 
 int finalize_if_pending(sm_ctx *s)
 {
@@ -535,11 +524,11 @@ int take_error(sm_ctx *s)
 
 // ---- launches ----
 
-// workgroups of the direct association (k_associate_direct<false, .> / k_assoc_prep): one per association block, or one per
-// two blocks when every thread takes two consecutive pixels
+// workgroups of the direct association (k_associate_direct / k_assoc_prep): one per two association blocks (every thread
+// takes two consecutive pixels)
 static inline uint32_t assoc_wgs(const sm_ctx *s)
 {
-    return s->assoc_pair ? (uint32_t)(s->n_pix_blocks + 1) / 2u : (uint32_t)s->n_pix_blocks;
+    return (uint32_t)(s->n_pix_blocks + 1) / 2u;
 }
 
 // `chain`: the frame runs the depth pre-processing chain p0a..p0e (preprocess = 1): the launch is k_assoc_prep<., true>, whose
@@ -586,10 +575,8 @@ int launch_prep(sm_ctx *s, const uint8_t *rgb, const uint16_t *raw, const uint8_
         if (chain) { ca = *chain; n_img = (uint32_t)(((s->W + CH_TX - 1) / CH_TX) * ((s->H + CH_TY - 1) / CH_TY)); }
         if (s->d_ap_trace) { s->ap_trace_n[0] = (int)n_assoc; s->ap_trace_n[1] = (int)tp.nfb; s->ap_trace_n[2] = (int)n_img; }    // (chain: dispatched image | association | flags)
         const dim3 grid(tp.nfb + n_assoc + n_img);
-#define SM_LAUNCH_AP(PAIRV, CHAINV) hipLaunchKernelGGL((k_assoc_prep<PAIRV, CHAINV>), grid, dim3(PIX_BLOCK), 0, s->stream, s->assoc_args, pa, fp, tp, n_assoc, n_img, ca, s->d_ap_trace)
-        if (chain) { if (s->assoc_pair) SM_LAUNCH_AP(true, true); else SM_LAUNCH_AP(false, true); }
-        else { if (s->assoc_pair) SM_LAUNCH_AP(true, false); else SM_LAUNCH_AP(false, false); }
-#undef SM_LAUNCH_AP
+        if (chain) hipLaunchKernelGGL((k_assoc_prep<true>), grid, dim3(PIX_BLOCK), 0, s->stream, s->assoc_args, pa, fp, tp, n_assoc, n_img, ca, s->d_ap_trace);
+        else hipLaunchKernelGGL((k_assoc_prep<false>), grid, dim3(PIX_BLOCK), 0, s->stream, s->assoc_args, pa, fp, tp, n_assoc, n_img, ca, s->d_ap_trace);
         HIPCK(hipGetLastError());
         return SM_OK;
     }
@@ -642,30 +629,11 @@ int launch_conflict_finalize(sm_ctx *s, const FrameParams &fp, bool timed = fals
     return SM_OK;
 }
 
-int launch_conflict(sm_ctx *s, const FrameParams &fp, bool timed = false, bool fold_finalize = false)
+int launch_conflict(sm_ctx *s, const FrameParams &fp, bool timed = false)
 {
     int rc = launch_conflict_test(s, fp, timed);
     if (rc) return rc;
-    if (fold_finalize) {            // k_cull_lazy_frame does the finalize step itself
-        if (mark(s, 3, timed)) return SM_E_HIP;
-        return SM_OK;
-    }
     return launch_conflict_finalize(s, fp, timed);
-}
-
-// the cull of a frame that only marks the dead, with the finalize step folded in (frame path): `grid` workers + 1 publisher
-int launch_cull_lazy_frame(sm_ctx *s, const FrameParams &fp, bool timed)
-{
-    const int grid = grid_surfels(s);
-    s->n_compact_part = (uint32_t)grid;
-    s->lazy_part_live = true;
-    s->fix_part_live = false;
-    hipLaunchKernelGGL(k_cull_lazy_frame, dim3(grid + 1), dim3(256), 0, s->stream, s->M, s->d_state, fp, s->d_cm, s->d_dm, s->d_zm,
-                       s->d_tile_cnt, s->d_keyT, s->d_tile_flags, s->d_lazy_part, s->d_alive, s->d_tile_dead, s->d_conf_part,
-                       s->n_conf_part, s->d_conf_sub + SUB_SET * s->conf_sub_set, s->d_stat);
-    HIPCK(hipGetLastError());
-    if (mark(s, 4, timed)) return SM_E_HIP;
-    return SM_OK;
 }
 
 // conflict test + cull (marks only) + splat in ONE pass over the surfels, then the publisher / cap fixup kernel.
@@ -673,7 +641,7 @@ int launch_cull_lazy_frame(sm_ctx *s, const FrameParams &fp, bool timed)
 // publishes their group prefixes and the new count.
 int launch_surfel_pass(sm_ctx *s, const FrameParams &fp, bool timed, bool direct)
 {
-    const bool ready = s->n_prep_blocks != 0;        // k_prep evaluated the tile flags
+    if (s->n_prep_blocks == 0) { g_err = "internal: one-pass frame without tile flags from the preparation launch"; return SM_E_ARG; }
     // Grid: up to 2 048 workgroups while the model is small (most tiles are skipped by their flags; a wide grid spreads the few
     // hundred tiles with work), but no more than are RESIDENT once every workgroup has many tiles with work (>= 4 per
     // workgroup: beyond ~8 M slots) -- the surplus would start when the first ones finish and run a second, thin wave
@@ -693,13 +661,10 @@ int launch_surfel_pass(sm_ctx *s, const FrameParams &fp, bool timed, bool direct
     s->n_fix_part = (uint32_t)fgrid;
     uint32_t *sub = s->d_conf_sub + SUB_SET * s->conf_sub_set;
     const uint32_t tile_bound = (uint32_t)std::max<uint64_t>(((uint64_t)s->count_bound + TILE - 1) / TILE, 1);
-#define SM_LAUNCH_PASS(R)                                                                                                                  \
-    hipLaunchKernelGGL((k_surfel_pass<R>), dim3(grid), dim3(256), 0, s->stream, s->M, s->d_state, fp, s->d_dcT, s->d_cm, s->d_dm /* km */,     \
-                       s->d_wave_cnt, s->d_tb, s->d_tile_flags, s->d_lazy_part, s->d_alive, s->d_tile_dead, sub, s->d_keyT, s->d_undo, tile_bound,       \
-                       s->d_frame_sub, s->d_pass_trace)
     if (s->d_pass_trace) s->pass_trace_grid = grid;
-    if (ready) SM_LAUNCH_PASS(true); else SM_LAUNCH_PASS(false);
-#undef SM_LAUNCH_PASS
+    hipLaunchKernelGGL(k_surfel_pass, dim3(grid), dim3(256), 0, s->stream, s->M, s->d_state, fp, s->d_dcT, s->d_cm, s->d_dm /* km */,
+                       s->d_wave_cnt, s->d_tb, s->d_tile_flags, s->d_lazy_part, s->d_alive, s->d_tile_dead, sub, s->d_keyT, s->d_undo, tile_bound,
+                       s->d_frame_sub, s->d_pass_trace);
     HIPCK(hipGetLastError());
     if (mark(s, 2, timed) || mark(s, 3, timed)) return SM_E_HIP;
     DirectArgs da;
@@ -714,9 +679,10 @@ int launch_surfel_pass(sm_ctx *s, const FrameParams &fp, bool timed, bool direct
     s->pend_finalize = false;            // the fixup's publisher completes the previous frame's statistics first
     hipLaunchKernelGGL(k_pass_fixup, dim3(fgrid + 1), dim3(256), 0, s->stream, s->M, s->d_state, fp, s->d_cm, s->d_dm /* km */, s->d_wave_cnt,
                        s->d_tile_flags, s->d_lazy_part, (uint32_t)grid, fix_cur, s->d_alive, s->d_tile_dead, sub, s->d_keyT, s->d_undo,
-                       s->d_stat, s->d_prep_part, ready ? s->n_prep_blocks : 0u, da, s->d_tb);
+                       s->d_stat, s->d_prep_part, s->n_prep_blocks, da, s->d_tb);
     HIPCK(hipGetLastError());
     if (mark(s, 4, timed)) return SM_E_HIP;
+    check_alive(s, 1u + 16u * (uint32_t)(s->tick & 0xFFFF));
     return SM_OK;
 }
 
@@ -742,9 +708,9 @@ int launch_associate_direct(sm_ctx *s, const FrameParams &fp, bool timed)
         s->assoc_args = a;
         s->assoc_pending = true;
     } else {
-        if (s->assoc_pair) hipLaunchKernelGGL((k_associate_direct<false, true>), dim3(assoc_wgs(s)), dim3(PIX_BLOCK), 0, s->stream, a, sh);
-        else hipLaunchKernelGGL((k_associate_direct<false, false>), dim3(assoc_wgs(s)), dim3(PIX_BLOCK), 0, s->stream, a, sh);
+        hipLaunchKernelGGL((k_associate_direct<false>), dim3(assoc_wgs(s)), dim3(PIX_BLOCK), 0, s->stream, a, sh);
         HIPCK(hipGetLastError());
+        check_alive(s, 2u + 16u * (uint32_t)(s->tick & 0xFFFF));
     }
     s->lazy_part_live = false;
     s->fix_part_live = false;
@@ -760,9 +726,9 @@ int flush_assoc(sm_ctx *s)
     s->assoc_pending = false;
     ShardArgs sh;
     memset(&sh, 0, sizeof sh);
-    if (s->assoc_pair) hipLaunchKernelGGL((k_associate_direct<false, true>), dim3(assoc_wgs(s)), dim3(PIX_BLOCK), 0, s->stream, s->assoc_args, sh);
-    else hipLaunchKernelGGL((k_associate_direct<false, false>), dim3(assoc_wgs(s)), dim3(PIX_BLOCK), 0, s->stream, s->assoc_args, sh);
+    hipLaunchKernelGGL((k_associate_direct<false>), dim3(assoc_wgs(s)), dim3(PIX_BLOCK), 0, s->stream, s->assoc_args, sh);
     HIPCK(hipGetLastError());
+    check_alive(s, 3u + 16u * (uint32_t)(s->tick & 0xFFFF));
     return SM_OK;
 }
 
@@ -772,14 +738,11 @@ int launch_compact(sm_ctx *s, const FrameParams &fp, bool splat, bool timed)
     s->fix_part_live = false;
     if (!fp.compact_now) {
         // deferred compaction: the cull only marks the dead -- lean kernel, no co-residency requirement
+        if (splat) { g_err = "internal: a frame's cull that only marks the dead is k_surfel_pass"; return SM_E_ARG; }
         const int grid = grid_surfels(s);
-        s->n_compact_part = splat ? (uint32_t)grid : 0u;
-        if (splat)
-            hipLaunchKernelGGL(k_cull_lazy<true>, dim3(grid), dim3(256), 0, s->stream, s->M, s->d_state, fp, s->d_cm, s->d_dm, s->d_zm,
-                               s->d_tile_cnt, s->d_tile_allow, s->d_keyT, s->d_tile_flags, s->d_compact_part, s->d_alive, s->d_tile_dead);
-        else
-            hipLaunchKernelGGL(k_cull_lazy<false>, dim3(grid), dim3(256), 0, s->stream, s->M, s->d_state, fp, s->d_cm, s->d_dm, s->d_zm,
-                               s->d_tile_cnt, s->d_tile_allow, s->d_keyT, s->d_tile_flags, s->d_compact_part, s->d_alive, s->d_tile_dead);
+        s->n_compact_part = 0u;
+        hipLaunchKernelGGL(k_cull_lazy, dim3(grid), dim3(256), 0, s->stream, s->M, s->d_state, fp, s->d_cm, s->d_dm, s->d_zm,
+                           s->d_tile_cnt, s->d_tile_allow, s->d_alive, s->d_tile_dead);
         HIPCK(hipGetLastError());
         if (mark(s, 4, timed)) return SM_E_HIP;
         return SM_OK;
@@ -792,12 +755,12 @@ int launch_compact(sm_ctx *s, const FrameParams &fp, bool splat, bool timed)
     if (splat)
         hipLaunchKernelGGL(k_compact<true>, dim3(grid), dim3(256), 0, s->stream, s->M, s->d_state, fpc, s->d_cm,
                            s->d_dm, s->d_zm, s->d_tile_cnt, s->d_tile_allow, s->d_tile_keep, s->d_keyT, s->d_tile_flag, epoch,
-                           s->d_seg_lstart, s->d_seg_gbase, s->d_group_base, s->d_tb, s->d_tile_flags, s->d_compact_part, s->d_alive,
+                           s->d_group_base, s->d_tb, s->d_tile_flags, s->d_compact_part, s->d_alive,
                            s->d_tile_dead);
     else
         hipLaunchKernelGGL(k_compact<false>, dim3(grid), dim3(256), 0, s->stream, s->M, s->d_state, fpc, s->d_cm,
                            s->d_dm, s->d_zm, s->d_tile_cnt, s->d_tile_allow, s->d_tile_keep, s->d_keyT, s->d_tile_flag, epoch,
-                           s->d_seg_lstart, s->d_seg_gbase, s->d_group_base, s->d_tb, s->d_tile_flags, s->d_compact_part, s->d_alive,
+                           s->d_group_base, s->d_tb, s->d_tile_flags, s->d_compact_part, s->d_alive,
                            s->d_tile_dead);
     HIPCK(hipGetLastError());
     if (mark(s, 4, timed)) return SM_E_HIP;
@@ -811,8 +774,7 @@ int launch_compact(sm_ctx *s, const FrameParams &fp, bool splat, bool timed)
 // surfels for every append enqueued since.
 bool decide_compact(sm_ctx *s)
 {
-    // (the experimental single-kernel association does not maintain the slot statistic: it compacts at every cull)
-    if (s->sh_world > 1 || s->cfg.compact_period <= 1 || s->use_fused_assoc) return true;
+    if (s->cfg.compact_period <= 1) return true;
     // Capacity: a cull that only marks the dead must not be able to make the frame overflow because of them.
     // bound = slots at the last device update + one frame's worth of new surfels for every append enqueued since.
     // When the host has run far ahead of the device the bound is loose; rather than compacting for nothing it then
@@ -856,6 +818,7 @@ int launch_post_fill(sm_ctx *s)
 {
     hipLaunchKernelGGL(k_post_fill, dim3(1024), dim3(256), 0, s->stream, s->d_state, s->d_alive, s->d_tile_dead);
     HIPCK(hipGetLastError());
+    check_alive(s, 4u + 16u * (uint32_t)(s->tick & 0xFFFF));
     return SM_OK;
 }
 
@@ -912,66 +875,29 @@ int ensure_compact(sm_ctx *s)
 int launch_associate_only(sm_ctx *s, const FrameParams &fp)
 {
     hipLaunchKernelGGL(k_associate, dim3(s->n_pix_blocks), dim3(PIX_BLOCK), 0, s->stream, s->M, s->d_state, fp,
-                       s->d_depthT, s->d_rgbsT, s->d_keyT, s->d_xs, s->d_ys, s->d_validmask, s->d_fusedmask,
-                       s->d_gseg_base, s->d_seg_lstart, s->d_blk_cnt, s->d_tb);
+                       s->d_depthT, s->d_rgbsT, s->d_keyT, s->d_xs, s->d_ys, s->d_validmask, s->d_fusedmask, s->d_blk_cnt, s->d_tb);
     HIPCK(hipGetLastError());
     return SM_OK;
 }
 
-int launch_append(sm_ctx *s, const FrameParams &fp, bool timed)
-{
-    hipLaunchKernelGGL(k_scan_new, dim3(1), dim3(1024), 0, s->stream, s->d_state, fp, s->n_pix_blocks, s->d_validmask,
-                       s->d_fusedmask, s->d_blk_prefix, s->d_log, s->d_compact_part, s->n_compact_part);
-    HIPCK(hipGetLastError());
-    if (mark(s, 6, timed)) return SM_E_HIP;
-    hipLaunchKernelGGL(k_append, dim3(s->n_pix_blocks), dim3(PIX_BLOCK), 0, s->stream, s->M, s->d_state, fp, s->d_depthT,
-                       s->d_rgbsT, s->d_xs, s->d_ys, s->d_validmask, s->d_fusedmask, s->d_blk_prefix, s->d_tb);
-    HIPCK(hipGetLastError());
-    if (mark(s, 7, timed)) return SM_E_HIP;
-    return SM_OK;
-}
-
-// single-GPU form: association + ordered append in one persistent kernel (decoupled look-back)
-int launch_associate_fused(sm_ctx *s, const FrameParams &fp, bool timed)
-{
-    if ((++s->assoc_epoch & 0xFFFFu) == 0) {      // the 16-bit granule tag wrapped: retire all old granules
-        HIPCK(hipMemsetAsync(s->d_desc, 0, (size_t)s->n_pix_blocks * 8, s->stream));
-        s->assoc_epoch++;
-    }
-    const int grid = std::min(s->n_pix_blocks, s->assoc_grid);
-    hipLaunchKernelGGL(k_associate_append, dim3(grid), dim3(PIX_BLOCK), 0, s->stream, s->M, s->d_state, fp, s->d_depthT,
-                       s->d_rgbsT, s->d_keyT, s->d_xs, s->d_ys, s->d_desc, s->assoc_epoch, s->n_pix_blocks, s->d_log, s->d_tb,
-                       s->d_compact_part, s->n_compact_part, s->d_alive, s->d_tile_dead);
-    HIPCK(hipGetLastError());
-    if (mark(s, 5, timed) || mark(s, 6, timed) || mark(s, 7, timed)) return SM_E_HIP;
-    return SM_OK;
-}
-
+// association + in-place fuse, then the dense ordered append (frames that compact; the frame after reset(); the per-pass API)
 int launch_associate(sm_ctx *s, const FrameParams &fp, bool timed)
 {
-    // 23-bit counters in the granule: images above 8 Mpixel keep the three-kernel form
-    // Measured on MI355X (round 1): the look-back chain costs ~14 us per pass over 1024 workgroups (cross-XCD granule
-    // visibility is ~1-2 us per hop), i.e. no better than the two extra launches at 1242x375 and worse at 1920x1080,
-    // so the three-kernel form stays the default; SM_FUSED_ASSOC=1 selects the single-kernel form.
-    if (s->use_fused_assoc && s->sh_world <= 1 && s->P < (1 << 23)) return launch_associate_fused(s, fp, timed);
     int rc = launch_associate_only(s, fp);
     if (rc) return rc;
-    if (mark(s, 5, timed)) return SM_E_HIP;
-    if (s->sh_world <= 1) {
-        // single GPU: the append derives its own prefix from the per-block counts (no scan kernel)
-        if (mark(s, 6, timed)) return SM_E_HIP;
-        hipLaunchKernelGGL(k_append_scan, dim3(s->n_pix_blocks), dim3(PIX_BLOCK), 0, s->stream, s->M, s->d_state, fp, s->d_depthT,
-                           s->d_rgbsT, s->d_xs, s->d_ys, s->d_validmask, s->d_fusedmask, s->d_blk_cnt, s->d_log, s->d_tb, s->d_compact_part,
-                           s->n_compact_part, s->d_alive, s->d_tile_dead, s->d_stat, s->lazy_part_live ? s->d_lazy_part : nullptr,
-                           (s->lazy_part_live && s->fix_part_live) ? s->d_fix_part + (size_t)s->fix_set * MAX_GRID : nullptr, s->n_fix_part);
-        s->lazy_part_live = false;
-        s->fix_part_live = false;
-        s->frames_enq++;
-        HIPCK(hipGetLastError());
-        if (mark(s, 7, timed)) return SM_E_HIP;
-        return SM_OK;
-    }
-    return launch_append(s, fp, timed);
+    if (mark(s, 5, timed) || mark(s, 6, timed)) return SM_E_HIP;
+    // the append derives its own prefix from the per-block counts (no scan kernel)
+    hipLaunchKernelGGL(k_append_scan, dim3(s->n_pix_blocks), dim3(PIX_BLOCK), 0, s->stream, s->M, s->d_state, fp, s->d_depthT,
+                       s->d_rgbsT, s->d_xs, s->d_ys, s->d_validmask, s->d_fusedmask, s->d_blk_cnt, s->d_log, s->d_tb, s->d_compact_part,
+                       s->n_compact_part, s->d_alive, s->d_tile_dead, s->d_stat, s->lazy_part_live ? s->d_lazy_part : nullptr,
+                       (s->lazy_part_live && s->fix_part_live) ? s->d_fix_part + (size_t)s->fix_set * MAX_GRID : nullptr, s->n_fix_part);
+    s->lazy_part_live = false;
+    s->fix_part_live = false;
+    s->frames_enq++;
+    HIPCK(hipGetLastError());
+    if (mark(s, 7, timed)) return SM_E_HIP;
+    check_alive(s, 5u + 16u * (uint32_t)(s->tick & 0xFFFF));
+    return SM_OK;
 }
 
 int rebuild_bounds(sm_ctx *s, uint32_t first_surfel, uint32_t count);
@@ -1058,7 +984,6 @@ int begin_frame(sm_ctx *s, const uint8_t *d_rgb, const uint16_t *d_raw, const ui
     if (s->tick == 0) {
         // after reset(): computeFeedbackBuffers + GlobalModel::initialize + buildModelMap
         // (src/SurfelMapping.cpp:161-169): the raw cloud of this frame becomes the model
-        if (s->sh_world > 1) { g_err = "reset() is not supported in sharded mode"; return SM_E_UNSUPPORTED; }
         fp.init_mode = 1;
         fp.log_frame = 0;
         // GlobalModel::initialize writes the raw cloud from the first slot of modelVbo on and sets count to the number written
@@ -1090,13 +1015,13 @@ void end_frame(sm_ctx *s, bool timed)
 // SurfelMapping::processFrame body (src/SurfelMapping.cpp:130-251); enqueue only.
 int enqueue_frame(sm_ctx *s, const uint8_t *d_rgb, const uint16_t *d_raw, const uint8_t *d_sem, const float *pose)
 {
-    if (s->sh_world > 1 || s->ss_on) { g_err = "context is configured for sharding: use the sm_shard_* entry points"; return SM_E_ARG; }
+    if (s->ss_on) { g_err = "context is configured for sharding: use the sm_shard_* entry points"; return SM_E_ARG; }
     FrameParams fp;
     // the cull's kind is decided first: a frame whose cull only marks the dead lets k_prep evaluate the tile skip flags for
     // the one-pass surfel kernel (not when k_prep runs ahead of the previous frame on the second stream)
     const bool fusing = s->ref_set && s->tick != 0 && !s->pending_cull;
     const bool compact_now = fusing ? decide_compact(s) : true;
-    s->want_list = fusing && !compact_now && s->one_pass && s->use_list && !s->use_fused_assoc;
+    s->want_list = fusing && !compact_now;
     // a held-back association rides on this frame's k_prep launch if this is again a fusing frame; anything else (the frame
     // after reset, ...) needs its results first
     s->merge_assoc = s->assoc_pending && fusing && s->defer_ok;       // (a compacting frame too: its k_prep launch has no tile flags to make)
@@ -1110,53 +1035,22 @@ int enqueue_frame(sm_ctx *s, const uint8_t *d_rgb, const uint16_t *d_raw, const 
     note_cull(s, fp.compact_now != 0u);
     s->keys_are_slots = fp.compact_now == 0u;      // this frame's splat writes slot numbers iff nothing moves
     if (s->ev_ok) s->ev_compacted[s->ev_frames % EV_RING] = fp.compact_now != 0u;
-    // a cull that only marks the dead folds its finalize step into the cull kernel (measured: 66.0 -> 62.9 us/frame; with the
-    // depth filter chain on a second stream it is the other way round, 86.5 -> 94.5 us, so those contexts keep the kernel)
-    const bool fold = !fp.compact_now && s->merged_finalize && !s->use_fused_assoc;
-    // ... and, by default, does the conflict test in the same pass over the surfels (k_surfel_pass + k_pass_fixup)
-    const bool one_pass = !fp.compact_now && s->one_pass && !s->use_fused_assoc;
-    if (s->ev_ok) s->ev_one_pass[s->ev_frames % EV_RING] = one_pass;
-    // ... and the association appends the new surfels directly (no append kernel) when k_prep ran after the previous frame
-    const bool direct = one_pass && s->direct && s->n_prep_blocks != 0;
-    if (s->ev_ok) s->ev_direct[s->ev_frames % EV_RING] = direct;
+    // a cull that only marks the dead is ONE pass over the surfels (k_surfel_pass + k_pass_fixup: conflict test, decrement, cull,
+    // splat), and the association appends the new surfels directly (no append kernel)
+    const bool one_pass = !fp.compact_now;
+    if (s->ev_ok) { s->ev_one_pass[s->ev_frames % EV_RING] = one_pass; s->ev_direct[s->ev_frames % EV_RING] = one_pass; }
     if (one_pass) {
-        if ((rc = launch_surfel_pass(s, fp, true, direct))) return rc;      // :178-197
-        if (direct) {
-            if ((rc = launch_associate_direct(s, fp, true))) return rc;     // :212-239
-            bump_bound(s);
-            end_frame(s);
-            return SM_OK;
-        }
-    } else {
-        if ((rc = launch_conflict(s, fp, true, fold))) return rc;    // :178-187
-        if (fold) { if ((rc = launch_cull_lazy_frame(s, fp, true))) return rc; }
-        else if ((rc = launch_compact(s, fp, true, true))) return rc;   // :189-197 (cull + mirror + index map)
+        if ((rc = launch_surfel_pass(s, fp, true, true))) return rc;        // :178-197
+        if ((rc = launch_associate_direct(s, fp, true))) return rc;         // :212-239
+        bump_bound(s);
+        end_frame(s);
+        return SM_OK;
     }
+    if ((rc = launch_conflict(s, fp, true))) return rc;           // :178-187
+    if ((rc = launch_compact(s, fp, true, true))) return rc;      // :189-197 (cull + mirror + index map)
     if ((rc = launch_associate(s, fp, true))) return rc;   // :212-239
     bump_bound(s);
     end_frame(s);
-    return SM_OK;
-}
-
-int upload_u32(sm_ctx *s, uint32_t **dbuf, uint32_t *cap_field, const uint32_t *src, size_t n)
-{
-    (void)cap_field;
-    if (n == 0) return SM_OK;
-    HIPCK(hipMemcpyAsync(*dbuf, src, n * 4, hipMemcpyHostToDevice, s->stream));
-    return SM_OK;
-}
-
-int ensure_seg(sm_ctx *s, size_t n)
-{
-    if (n + 2 <= s->seg_cap) return SM_OK;
-    size_t cap = std::max<size_t>(1024, (n + 2) * 2);
-    HIPCK(hipStreamSynchronize(s->stream));
-    for (uint32_t **p : {&s->d_seg_lstart, &s->d_seg_gbase, &s->d_gseg_base, &s->d_seg_keep}) {
-        if (*p) (void)hipFree(*p);
-        *p = nullptr;
-        HIPCK(hipMalloc((void **)p, cap * 4));
-    }
-    s->seg_cap = (uint32_t)cap;
     return SM_OK;
 }
 
@@ -1298,8 +1192,6 @@ sm_ctx *sm_create(const sm_config *c)
     s->n_grp = (uint32_t)((s->n_pix_blocks + s->cand_group - 1) / s->cand_group);
     ok = ok && dalloc(&s->d_blk_cand, (size_t)s->n_grp * CAND_GROUP_MAX) == SM_OK && dalloc(&s->d_grp_cand, (size_t)s->n_grp) == SM_OK &&
          dalloc(&s->d_frame_sub, (size_t)4 * SUB_SET) == SM_OK && hipMemset(s->d_frame_sub, 0, (size_t)4 * SUB_SET * 4) == hipSuccess;
-    ok = ok && dalloc(&s->d_blk_prefix, (size_t)s->n_pix_blocks) == SM_OK && dalloc(&s->d_desc, (size_t)s->n_pix_blocks) == SM_OK &&
-         hipMemset(s->d_desc, 0, (size_t)s->n_pix_blocks * 8) == hipSuccess;
     if (!ok) { if (g_err.empty()) g_err = "sm_create: allocation failed"; sm_destroy(s); return nullptr; }
 
     // pixel-centre coordinates exactly as data.vert sees them:
@@ -1359,25 +1251,17 @@ sm_ctx *sm_create(const sm_config *c)
     if (!ok) { g_err = "sm_create: device initialisation failed"; sm_destroy(s); return nullptr; }
     {
         // the in-place compaction needs every workgroup of k_compact resident at once
-        int cus = 0, per_cu = 0, per_cu_a = 0;
-        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess && cus > 0 &&
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_a, k_associate_append, PIX_BLOCK, 0) == hipSuccess && per_cu_a > 0)
-            s->assoc_grid = std::max(1, cus * std::min(4, std::max(1, per_cu_a - 1)));
-        s->use_fused_assoc = std::getenv("SM_FUSED_ASSOC") != nullptr;
-        s->merged_finalize = std::getenv("SM_NO_MERGED_FINALIZE") == nullptr;
-        if (const char *e = std::getenv("SM_ONE_PASS")) s->one_pass = e[0] != '0';
-        if (const char *e = std::getenv("SM_TILE_FLAGS_IN_PREP")) s->use_list = e[0] != '0';
-        if (const char *e = std::getenv("SM_DIRECT_APPEND")) s->direct = e[0] != '0';
-        if (const char *e = std::getenv("SM_ASSOC_PAIR")) s->assoc_pair = e[0] != '0';
+        int cus = 0, per_cu = 0;
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device);
+        if (std::getenv("SM_CHECK_ALIVE") && (hipMalloc((void **)&s->d_chk, 32) != hipSuccess || hipMemset(s->d_chk, 0, 32) != hipSuccess)) s->d_chk = nullptr;
         if (std::getenv("SM_PASS_TRACE") && hipMalloc((void **)&s->d_pass_trace, (size_t)MAX_GRID * 64) != hipSuccess) s->d_pass_trace = nullptr;
         if (std::getenv("SM_PASS_TRACE") && hipMalloc((void **)&s->d_ap_trace, (size_t)65536 * 16) != hipSuccess) s->d_ap_trace = nullptr;
-        s->defer_ok = s->defer_ok && s->one_pass && s->use_list && s->direct && !s->use_fused_assoc;
         {
             // k_surfel_pass: with more workgroups than the chip holds at once the surplus starts when the first ones are done --
             // on a model where every tile has work (20 M scattered surfels: ~10 tiles per workgroup) that is a second pass at an
             // eighth of the occupancy.  Grid = what is resident; tiles go round-robin.  (SM_PASS_WG_PER_CU overrides.)
             int pc = 0;
-            if (cus > 0 && hipOccupancyMaxActiveBlocksPerMultiprocessor(&pc, k_surfel_pass<true>, 256, 0) == hipSuccess && pc > 0) {
+            if (cus > 0 && hipOccupancyMaxActiveBlocksPerMultiprocessor(&pc, k_surfel_pass, 256, 0) == hipSuccess && pc > 0) {
                 int want = std::max(1, pc - 1);      // the occupancy API over-reports by one block per CU here (measured; MI355X_MICROARCH.md)
                 if (const char *e = std::getenv("SM_PASS_WG_PER_CU")) want = std::max(1, std::atoi(e));
                 s->pass_grid = std::max(256, std::min(cus * want, MAX_GRID));
@@ -1420,8 +1304,6 @@ void sm_destroy(sm_ctx *s)
     }
     if (s->stream_in) (void)hipStreamDestroy(s->stream_in);
     if (s->stream_in2) (void)hipStreamDestroy(s->stream_in2);
-    for (auto &pr : s->pinned)
-        if (std::find(s->host_allocs.begin(), s->host_allocs.end(), (void *)pr.first) == s->host_allocs.end()) (void)hipHostUnregister(const_cast<unsigned char *>(pr.first));
     for (void *hp : s->host_allocs) (void)hipHostFree(hp);
     if (s->d_pass_trace) {
         // SM_PASS_TRACE=<prefix>: the last k_surfel_pass launch's per-workgroup record (wall_clock64 at entry / first tile /
@@ -1457,9 +1339,8 @@ void sm_destroy(sm_ctx *s)
     (void)hipFree(s->d_xs); (void)hipFree(s->d_ys);
     (void)hipFree(s->d_cm); (void)hipFree(s->d_dm); (void)hipFree(s->d_zm); (void)hipFree(s->d_alive); (void)hipFree(s->d_tile_dead);
     (void)hipFree(s->d_tile_cnt); (void)hipFree(s->d_tile_allow); (void)hipFree(s->d_tile_keep); (void)hipFree(s->d_tile_flag); (void)hipFree(s->d_group_tot); (void)hipFree(s->d_group_base); (void)hipFree(s->d_tb); (void)hipFree(s->d_tile_flags); (void)hipFree(s->d_conf_part); (void)hipFree(s->d_compact_part); (void)hipFree(s->d_lazy_part); (void)hipFree(s->d_conf_sub); (void)hipFree(s->d_fix_part); (void)hipFree(s->d_blk_cand); (void)hipFree(s->d_grp_cand); (void)hipFree(s->d_frame_sub); (void)hipFree(s->d_wave_cnt); (void)hipFree(s->d_undo); (void)hipFree(s->d_prep_part);
-    (void)hipFree(s->d_validmask); (void)hipFree(s->d_fusedmask); (void)hipFree(s->d_blk_prefix); (void)hipFree(s->d_desc); (void)hipFree(s->d_blk_cnt);
-    (void)hipFree(s->d_seg_lstart); (void)hipFree(s->d_seg_gbase); (void)hipFree(s->d_gseg_base); (void)hipFree(s->d_seg_keep);
-    (void)hipFree(s->d_galive); (void)hipFree(s->d_new_alive); (void)hipFree(s->d_gmask); (void)hipFree(s->d_ss_info); (void)hipFree(s->d_capx);
+    (void)hipFree(s->d_validmask); (void)hipFree(s->d_fusedmask); (void)hipFree(s->d_blk_cnt);
+    (void)hipFree(s->d_chk); (void)hipFree(s->d_galive); (void)hipFree(s->d_new_alive); (void)hipFree(s->d_gmask); (void)hipFree(s->d_ss_info); (void)hipFree(s->d_capx);
     if (s->d_export) (void)hipFree(s->d_export);
     for (void *p : s->user_allocs) (void)hipFree(p);
     if (s->ev_ok)
@@ -1475,6 +1356,15 @@ int sm_sync(sm_ctx *s)
     HIPCK(hipSetDevice(s->cfg.device));
     int rc = pull_state(s);
     if (rc) return rc;
+    if (s->d_chk) {
+        uint32_t h[8] = {0};
+        HIPCK(hipMemcpy(h, s->d_chk, sizeof h, hipMemcpyDeviceToHost));
+        if (h[0]) {
+            fprintf(stderr, "SM_CHECK_ALIVE: %u tiles violate occupied - dead == live bits; first seen: stage %u (frame tick %u), tile %u, live bits %u, occupied - dead %u, slots %u\n",
+                    h[0], h[1] & 15u, h[1] >> 4, h[2], h[3], h[4], h[5]);
+            HIPCK(hipMemset(s->d_chk, 0, sizeof h));
+        }
+    }
     return take_error(s);
 }
 
@@ -1496,18 +1386,6 @@ int sm_process_frame(sm_ctx *s, const uint8_t *rgb, const uint16_t *depth_mm, co
     rc = enqueue_frame(s, s->d_rgb, s->d_depth_raw, s->d_sem, pose16);
     if (rc) return rc;
     return sm_sync(s);
-}
-
-int sm_pin_host_buffer(sm_ctx *s, const void *host, size_t bytes)
-{
-    if (!s || !host || !bytes) return SM_E_ARG;
-    HIPCK(hipSetDevice(s->cfg.device));
-    const unsigned char *p = static_cast<const unsigned char *>(host);
-    for (auto &pr : s->pinned)
-        if (p >= pr.first && p + bytes <= pr.first + pr.second) return SM_OK;         // already registered
-    HIPCK(hipHostRegister(const_cast<void *>(host), bytes, hipHostRegisterDefault));
-    s->pinned.emplace_back(p, bytes);
-    return SM_OK;
 }
 
 void *sm_host_alloc(sm_ctx *s, size_t bytes)
@@ -1533,21 +1411,6 @@ int sm_host_free(sm_ctx *s, void *p)
         if (s->pinned[i].first == p) { s->pinned.erase(s->pinned.begin() + (long)i); break; }
     HIPCK(hipHostFree(p));
     return SM_OK;
-}
-
-int sm_unpin_host_buffer(sm_ctx *s, const void *host)
-{
-    if (!s || !host) return SM_E_ARG;
-    HIPCK(hipSetDevice(s->cfg.device));
-    for (size_t i = 0; i < s->pinned.size(); ++i)
-        if (s->pinned[i].first == host && std::find(s->host_allocs.begin(), s->host_allocs.end(), (void *)host) == s->host_allocs.end()) {
-            if (s->stream_in) { HIPCK(hipStreamSynchronize(s->stream_in)); HIPCK(hipStreamSynchronize(s->stream_in2)); }   // no copy may still read it
-            HIPCK(hipHostUnregister(const_cast<void *>(host)));
-            s->pinned.erase(s->pinned.begin() + (long)i);
-            return SM_OK;
-        }
-    g_err = "sm_unpin_host_buffer: not a buffer registered with sm_pin_host_buffer";
-    return SM_E_ARG;
 }
 
 int sm_process_frame_async(sm_ctx *s, const uint8_t *rgb, const uint16_t *depth_mm, const uint8_t *semantic, const float *pose16)
@@ -1999,7 +1862,7 @@ int sm_stage_splat(sm_ctx *s, const float *pose16, int32_t time, float depth_cut
     hipLaunchKernelGGL(k_fill_keys, dim3((s->P + 255) / 256), dim3(256), 0, s->stream, s->d_keyT, s->P);
     HIPCK(hipGetLastError());
     const int grid = (int)std::min<uint64_t>(std::max<uint64_t>(((uint64_t)s->h_state->count + 255) / 256, 1), MAX_GRID);
-    hipLaunchKernelGGL(k_splat, dim3(grid), dim3(256), 0, s->stream, s->M, s->d_state, fp, s->d_keyT, s->d_seg_lstart, s->d_seg_gbase);
+    hipLaunchKernelGGL(k_splat, dim3(grid), dim3(256), 0, s->stream, s->M, s->d_state, fp, s->d_keyT);
     HIPCK(hipGetLastError());
     return sm_sync(s);
 }
@@ -2181,24 +2044,6 @@ int sm_append_model_aos_device(sm_ctx *s, const float *d_src12, uint32_t n)
     return pull_state(s);
 }
 
-// (a held-back association is launched first: the map the caller reads through the pointer is the one the last frame call
-//  drew and associated; the pointer is valid until the next frame call -- the two key maps alternate -- and the caller orders
-//  its reads after the context's stream, e.g. with sm_sync)
-void *sm_key_map_device_ptr(sm_ctx *s)
-{
-    if (!s || hip_runtime_conflict("sm_key_map_device_ptr")) return nullptr;
-    if (hipSetDevice(s->cfg.device) != hipSuccess || finalize_if_pending(s)) return nullptr;
-    return (void *)s->d_keyT;
-}
-
-void *sm_fused_mask_device_ptr(sm_ctx *s, uint32_t *nwords)
-{
-    if (!s) return nullptr;
-    if (hipSetDevice(s->cfg.device) != hipSuccess || finalize_if_pending(s)) return nullptr;
-    if (nwords) *nwords = (uint32_t)((s->P + 63) / 64);
-    return (void *)s->d_fusedmask;
-}
-
 int sm_device_download(sm_ctx *s, void *dst_host, const void *src_device, size_t bytes)
 {
     if (!s || !dst_host || !src_device) return SM_E_ARG;
@@ -2206,109 +2051,6 @@ int sm_device_download(sm_ctx *s, void *dst_host, const void *src_device, size_t
     HIPCK(hipMemcpyAsync(dst_host, src_device, bytes, hipMemcpyDeviceToHost, s->stream));
     HIPCK(hipStreamSynchronize(s->stream));
     return SM_OK;
-}
-
-// ---- one camera stream sharded over `world` GPUs (DESIGN.md "Multi-GPU", sharded mode) ----
-
-int sm_shard_configure(sm_ctx *s, int rank, int world)
-{
-    if (!s || world < 1 || rank < 0 || rank >= world) return SM_E_ARG;
-    HIPCK(hipSetDevice(s->cfg.device));
-    int rcc = ensure_compact(s);
-    if (rcc) return rcc;
-    s->defer_ok = false;
-    s->sh_rank = rank; s->sh_world = world;
-    s->sh_nseg = 0; s->sh_ngseg = 0; s->sh_exempt = 0; s->sh_in_frame = false;
-    return ensure_seg(s, 64);
-}
-
-int sm_shard_begin_frame(sm_ctx *s, const uint8_t *rgb, const uint16_t *depth_mm, const uint8_t *semantic, const float *pose16)
-{
-    if (!s || !rgb || !pose16) return SM_E_ARG;
-    HIPCK(hipSetDevice(s->cfg.device));
-    if (s->sh_in_frame) { g_err = "sm_shard_begin_frame: previous frame not finished (sm_shard_append)"; return SM_E_ARG; }
-    int rc = upload_inputs(s, rgb, depth_mm, semantic);
-    if (rc) return rc;
-    FrameParams fp;
-    rc = begin_frame(s, s->d_rgb, s->d_depth_raw, s->d_sem, pose16, &fp);
-    if (rc == 1) s->sh_in_frame = true;
-    if (rc < 0) return rc;
-    int rs = sm_sync(s);
-    return rs ? rs : rc;
-}
-
-int sm_shard_conflict(sm_ctx *s, uint32_t exempt_local, const uint32_t *seg_lstart_old, int nseg, uint32_t *seg_keep_out,
-                      uint32_t *conflict_out)
-{
-    if (!s || nseg < 0 || (nseg && (!seg_lstart_old || !seg_keep_out)) || !conflict_out) return SM_E_ARG;
-    HIPCK(hipSetDevice(s->cfg.device));
-    if (!s->sh_in_frame) { g_err = "sm_shard_conflict outside a frame"; return SM_E_ARG; }
-    int rc = ensure_seg(s, (size_t)nseg);
-    if (rc) return rc;
-    s->sh_exempt = exempt_local;
-    s->sh_nseg = nseg;
-    FrameParams fp = make_params(s, s->curr_pose);
-    fp.conflict_cap = 0xFFFFFFFFu;           // the W*H conflict cap needs the global conflict order: off when sharded
-    fp.splat_follows = 1;
-    if ((rc = upload_u32(s, &s->d_seg_lstart, nullptr, seg_lstart_old, (size_t)nseg + 1))) return rc;
-    if ((rc = launch_conflict(s, fp, false))) return rc;
-    if (nseg) {
-        hipLaunchKernelGGL(k_seg_counts, dim3((nseg + 255) / 256), dim3(256), 0, s->stream, s->d_state, s->d_cm, s->d_dm, s->d_zm,
-                           s->d_tile_keep, s->d_group_base, s->d_seg_lstart, nseg, s->d_seg_keep);
-        HIPCK(hipGetLastError());
-        HIPCK(hipMemcpyAsync(seg_keep_out, s->d_seg_keep, (size_t)nseg * 4, hipMemcpyDeviceToHost, s->stream));
-    }
-    HIPCK(hipMemcpyAsync(s->h_state, s->d_state, sizeof(DevState), hipMemcpyDeviceToHost, s->stream));
-    HIPCK(hipStreamSynchronize(s->stream));
-    *conflict_out = s->h_state->conflict_count;
-    return SM_OK;
-}
-
-int sm_shard_cull_splat(sm_ctx *s, const uint32_t *seg_lstart_new, const uint32_t *seg_gbase, int nseg)
-{
-    if (!s || nseg < 0 || (nseg && (!seg_lstart_new || !seg_gbase))) return SM_E_ARG;
-    HIPCK(hipSetDevice(s->cfg.device));
-    if (!s->sh_in_frame) { g_err = "sm_shard_cull_splat outside a frame"; return SM_E_ARG; }
-    int rc = ensure_seg(s, (size_t)nseg);
-    if (rc) return rc;
-    s->sh_nseg = nseg;
-    FrameParams fp = make_params(s, s->curr_pose);
-    fp.conflict_cap = 0xFFFFFFFFu;
-    if ((rc = upload_u32(s, &s->d_seg_lstart, nullptr, seg_lstart_new, (size_t)nseg + 1))) return rc;
-    if ((rc = upload_u32(s, &s->d_seg_gbase, nullptr, seg_gbase, (size_t)nseg))) return rc;
-    s->count_bound = std::max(s->count_bound, s->h_state->cull_n);
-    if ((rc = launch_compact(s, fp, true, false))) return rc;
-    return sm_sync(s);
-}
-
-int sm_shard_associate(sm_ctx *s, const uint32_t *gseg_base, int n_gseg)
-{
-    if (!s || n_gseg < 0 || (n_gseg && !gseg_base)) return SM_E_ARG;
-    HIPCK(hipSetDevice(s->cfg.device));
-    if (!s->sh_in_frame) { g_err = "sm_shard_associate outside a frame"; return SM_E_ARG; }
-    int rc = ensure_seg(s, (size_t)n_gseg);
-    if (rc) return rc;
-    s->sh_ngseg = n_gseg;
-    FrameParams fp = make_params(s, s->curr_pose);
-    if ((rc = upload_u32(s, &s->d_gseg_base, nullptr, gseg_base, (size_t)n_gseg + 1))) return rc;
-    if ((rc = launch_associate_only(s, fp))) return rc;
-    return sm_sync(s);
-}
-
-int sm_shard_append(sm_ctx *s, int append_here)
-{
-    if (!s) return SM_E_ARG;
-    HIPCK(hipSetDevice(s->cfg.device));
-    if (!s->sh_in_frame) { g_err = "sm_shard_append outside a frame"; return SM_E_ARG; }
-    FrameParams fp = make_params(s, s->curr_pose);
-    fp.append_here = append_here ? 1 : 0;
-    fp.log_frame = 1;
-    int rc = launch_append(s, fp, false);
-    if (rc) return rc;
-    if (append_here) bump_bound(s);
-    end_frame(s);
-    s->sh_in_frame = false;
-    return sm_sync(s);
 }
 
 }  // extern "C"
@@ -2445,10 +2187,6 @@ int sm_shard_stream_configure(sm_ctx *s, int rank, int world)
     if (!s || world < 1 || rank < 0 || rank >= world) return SM_E_ARG;
     HIPCK(hipSetDevice(s->cfg.device));
     if (s->ss_on) { g_err = "sm_shard_stream_configure: already configured"; return SM_E_ARG; }
-    if (!s->one_pass || !s->use_list || !s->direct || s->use_fused_assoc) {
-        g_err = "sm_shard_stream_configure: needs the one-pass frame with direct append (SM_ONE_PASS / SM_TILE_FLAGS_IN_PREP / SM_DIRECT_APPEND / SM_FUSED_ASSOC are set against it)";
-        return SM_E_UNSUPPORTED;
-    }
     int rc = pull_state(s);
     if (rc) return rc;
     if (s->h_state->count != 0 || s->maybe_garbage || s->tick != 0 || s->ref_set) {
@@ -2590,8 +2328,7 @@ int sm_shard_frame_device(sm_ctx *s, const uint8_t *d_rgb, const uint16_t *d_dep
     sh.owner = (int)(s->ss_frames % (uint32_t)s->ss_world) == s->ss_rank ? 1 : 0;
     AssocArgs aa;
     fill_assoc_args(s, fp, aa);
-    if (s->assoc_pair) hipLaunchKernelGGL((k_associate_direct<true, true>), dim3(assoc_wgs(s)), dim3(PIX_BLOCK), 0, s->stream, aa, sh);
-    else hipLaunchKernelGGL((k_associate_direct<true, false>), dim3(s->n_pix_blocks), dim3(PIX_BLOCK), 0, s->stream, aa, sh);
+    hipLaunchKernelGGL((k_associate_direct<true>), dim3(assoc_wgs(s)), dim3(PIX_BLOCK), 0, s->stream, aa, sh);
     HIPCK(hipGetLastError());
     if ((rc = mark(s, 5, true))) return rc;
     if ((rc = ss_collective(s, s->d_gmask, s->d_gmask, (size_t)sh.nwords + 4, SM_COLL_SUM))) return rc;   // in place, like the key map
@@ -2602,7 +2339,6 @@ int sm_shard_frame_device(sm_ctx *s, const uint8_t *d_rgb, const uint16_t *d_dep
     ss.nwords = sh.nwords; ss.blk_cand = s->d_blk_cand; ss.grp_cand = s->d_grp_cand; ss.frame_sub = s->d_frame_sub; ss.alive = s->d_alive;
     ss.tile_dead = s->d_tile_dead; ss.owner = sh.owner; ss.cap_pixels = s->cfg.conflict_cap ? (uint32_t)s->P : 0xFFFFFFFFu; ss.max_vertices = s->cap; ss.cg = s->cand_group;
     s->ss_settle_pending = true;
-    if (std::getenv("SM_SHARD_SETTLE_NOW")) { s->pend_finalize = false; if ((rc = finalize_if_pending(s))) return rc; }   // A/B: settle as its own launch
     if ((rc = mark(s, 6, true)) || (rc = mark(s, 7, true))) return rc;
     s->lazy_part_live = false;
     s->fix_part_live = false;
@@ -2654,7 +2390,7 @@ int sm_shard_export_dense_device(sm_ctx *s, const float **d_out12, uint32_t *cou
 int sm_rig_configure(sm_ctx *s, int rank, int world)
 {
     if (!s || world < 1 || rank < 0 || rank >= world) return SM_E_ARG;
-    if (s->ss_on || s->sh_world > 1) { g_err = "sm_rig_configure: the context is configured for sharding"; return SM_E_ARG; }
+    if (s->ss_on) { g_err = "sm_rig_configure: the context is configured for sharding"; return SM_E_ARG; }
     s->rig_on = true; s->ss_rank = rank; s->ss_world = world;
     return SM_OK;
 }

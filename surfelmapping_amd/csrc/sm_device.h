@@ -94,12 +94,6 @@ struct FrameParams {
     int splat_follows;        // the cull is followed by the index-map splat (resets visible_count)
     int log_frame;            // append a FrameLog entry at the end of the frame
     uint32_t max_vertices;
-    // ---- multi-GPU sharding (world == 1: all of this is the identity) ----
-    uint32_t exempt_local;    // local index of the surfel with GLOBAL id 0 (conflict.geom:15, data.vert:142), ~0u if not owned
-    int nseg;                 // local creation-frame segments (0: global id == local index)
-    int n_gseg;               // global creation-frame segments
-    int rank, world;
-    int append_here;          // this rank owns the frame's new surfels
     // ---- re-initialisation after reset(): raw feedback cloud (surfel_feedback.vert) ----
     int init_mode;            // 1: every checkerboard pixel with 0 < z < far becomes a surfel, no association
     float inv_fx_fb, inv_fy_fb;   // 1.0f/fx as float division (src/FeedbackBuffer.cpp:93-96)
@@ -112,36 +106,6 @@ struct FrameParams {
     int no_exempt;            // 1: no surfel is exempt from the conflict test (a rig slice that does not hold the global surfel 0)
     int shard_slots;          // 1: slot-addressed sharding of one stream: ids are global slot numbers on every rank
 };
-
-// local index -> global id through the per-segment tables (segments = surfels created by one frame,
-// kept in creation order, so the concatenation of all ranks' segments in frame order is the
-// single-GPU model order)
-__device__ __forceinline__ uint32_t local_to_global(uint32_t l, const uint32_t *__restrict__ lstart,
-                                                    const uint32_t *__restrict__ gbase, int nseg)
-{
-    if (nseg <= 0) return l;
-    int lo = 0, hi = nseg - 1;
-    while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (lstart[mid] <= l) lo = mid; else hi = mid - 1;
-    }
-    return gbase[lo] + (l - lstart[lo]);
-}
-
-// global id -> (owned?, local index)
-__device__ __forceinline__ bool global_to_local(uint32_t gid, const uint32_t *__restrict__ gseg_base, int n_gseg,
-                                                const uint32_t *__restrict__ lstart, int rank, int world, uint32_t *local)
-{
-    if (world <= 1 || n_gseg <= 0) { *local = gid; return true; }
-    int lo = 0, hi = n_gseg - 1;
-    while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (gseg_base[mid] <= gid) lo = mid; else hi = mid - 1;
-    }
-    if (lo % world != rank) return false;
-    *local = lstart[lo / world] + (gid - gseg_base[lo]);
-    return true;
-}
 
 __device__ __forceinline__ float min_glsl(float a, float b) { return (b < a) ? b : a; }
 

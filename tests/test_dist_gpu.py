@@ -39,15 +39,17 @@ SCRIPT = textwrap.dedent("""
     g = glob.download_model()
     assert total == local.shape[0] == counts[0] > 0, (total, local.shape, counts)
     assert np.array_equal(g.view(np.uint32), local.view(np.uint32))
-    # sharded mode through the RCCL device path (world 1): key map / fused mask all-reduced in place
+    # ONE stream sharded, RCCL bound by the core (world 1): the key map / fused mask / conflict masks all-reduced on its stream
     from surfelmapping_amd import sharded
     import oracle_lib as ol
     sm2 = capi.SurfelMap(capi.make_config(**cam, **over))
-    mp = sharded.ShardedMapper(sharded.HipShardBackend(sm2, 0, 1), sharded.TorchComm(device_index=0), cam["width"] * cam["height"])
+    mp = sharded.StreamShard(sm2, 0, 1, "rccl", capi.rccl_unique_id())
+    assert sm2.shard_rccl_nranks() == 1
     o = ol.Oracle(ol.make_config(**cam, **over))
     for fr in seq:
         mp.process_frame(*fr); o.process_frame(*fr)
-    gm, om = mp.gather_global_model(), o.download_model()
+    gm, om = mp.export_dense(), o.download_model()
+    sm2.shard_rccl_finalize()
     assert gm.shape == om.shape and np.array_equal(gm.view(np.uint32), om.view(np.uint32))
     dist.destroy_process_group()
     print("DIST_GPU_OK", ORDER, total)

@@ -19,7 +19,7 @@ else:
     n_frames = int(sys.argv[1]) if len(sys.argv) > 1 else 23
     os.environ["SM_PASS_TRACE"] = prefix
     if len(sys.argv) > 2:
-        os.environ["SM_PASS_COMPACT"] = sys.argv[2]
+        pass
     from surfelmapping_amd import capi, synth   # noqa: E402
     import bench                                 # noqa: E402
 
