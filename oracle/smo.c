@@ -15,6 +15,7 @@
 #include "smo.h"
 
 #include <math.h>
+#include <time.h>
 #include <stdlib.h>
 #include <string.h>
 #ifdef _OPENMP
@@ -67,6 +68,7 @@ struct smo_ctx {
     int ref_set;
     float curr_pose[16], last_pose[16];
     int32_t exempt_id;        /* surfel that never fuses / conflicts: id 0 (A5); shard tests move it */
+    double stage_sec[12];     /* wall seconds per pass since the last smo_reset_stage_seconds (bench.py's CPU baseline: where the time goes) */
     int64_t conflict_limit;   /* < 0: the config's rule (W*H records or none); >= 0: this many records (a rig slice's share, tests/test_rig.py) */
     int32_t *data_pix;        /* column-major pixel index of every dataVbo record */
 #ifdef _OPENMP
@@ -282,6 +284,22 @@ void smo_default_config(smo_config *c, int w, int h, float fx, float fy, float c
     c->stereo_border = 80.0f;                    /* src/SurfelMapping.cpp:261 */
     c->preprocess = 1;
     c->conflict_cap = 1;
+}
+
+/* memset over all cores (the all-core build clears ~50 MB of textures per frame: mirror planes, index-map planes) */
+static void par_memset(void *p, int v, size_t n)
+{
+#ifdef _OPENMP
+    const size_t chunk = (size_t)1 << 20;
+    const long nch = (long)((n + chunk - 1) / chunk);
+#pragma omp parallel for schedule(static)
+    for (long c = 0; c < nch; ++c) {
+        const size_t o = (size_t)c * chunk;
+        memset((char *)p + o, v, n - o < chunk ? n - o : chunk);
+    }
+#else
+    memset(p, v, n);
+#endif
 }
 
 static void *xcalloc(size_t n, size_t sz)
@@ -594,14 +612,38 @@ int smo_stage_process_conflict(smo_ctx *s, const float *pose, float min_depth, f
 #pragma omp parallel for schedule(static)
     for (uint32_t k = 0; k < s->count; ++k)
         s->omp_flag[k] = (uint8_t)conflict_test(s, t_inv, k, min_depth, max_depth, fuse_thresh, is_clean);
-    for (uint32_t k = 0; k < s->count; ++k) {
-        if (!s->omp_flag[k] || (int32_t)k == s->exempt_id || n >= cap) continue;
-        const float *v = s->model + (size_t)k * SURFEL_F;
-        float *r = s->conflict + (size_t)n * 5;
-        r[0] = u2f(k);
-        r[1] = v[0]; r[2] = v[1]; r[3] = v[2];
-        r[4] = v[3] - 1.0f;
-        n++;
+    {   /* the records in surfel order, capped: conflicts per chunk, exclusive prefix, every chunk writes its own range */
+        enum { MAXT = 256 };
+        uint32_t cnt[MAXT + 1];
+        int nt = omp_get_max_threads();
+        if (nt > MAXT) nt = MAXT;
+        const uint32_t N = s->count, per = (N + (uint32_t)nt - 1) / (uint32_t)nt;
+#pragma omp parallel num_threads(nt)
+        {
+            const int t = omp_get_thread_num();
+            const uint32_t k0 = (uint32_t)t * per < N ? (uint32_t)t * per : N, k1 = k0 + per < N ? k0 + per : N;
+            uint32_t c = 0;
+            for (uint32_t k = k0; k < k1; ++k) c += s->omp_flag[k] && (int32_t)k != s->exempt_id;
+            cnt[t] = c;
+#pragma omp barrier
+#pragma omp single
+            {
+                uint32_t run = 0;
+                for (int x = 0; x < nt; ++x) { const uint32_t y = cnt[x]; cnt[x] = run; run += y; }
+                cnt[nt] = run;
+            }
+            uint32_t w = cnt[t];
+            for (uint32_t k = k0; k < k1 && w < cap; ++k) {
+                if (!s->omp_flag[k] || (int32_t)k == s->exempt_id) continue;
+                const float *v = s->model + (size_t)k * SURFEL_F;
+                float *r = s->conflict + (size_t)w * 5;
+                r[0] = u2f(k);
+                r[1] = v[0]; r[2] = v[1]; r[3] = v[2];
+                r[4] = v[3] - 1.0f;
+                w++;
+            }
+        }
+        n = cnt[nt] < cap ? cnt[nt] : cap;
     }
 #else
     for (uint32_t k = 0; k < s->count; ++k) {
@@ -703,9 +745,9 @@ int smo_stage_build_model_map(smo_ctx *s)
     ensure_mirror(s, s->count);
     uint32_t clr = s->mirror_dirty;               /* texels that may be non-zero */
     if (clr > s->mirror_cap) clr = s->mirror_cap;
-    memset(s->mvc, 0, (size_t)clr * 16);
-    memset(s->mct, 0, (size_t)clr * 16);
-    memset(s->mnr, 0, (size_t)clr * 16);
+    par_memset(s->mvc, 0, (size_t)clr * 16);
+    par_memset(s->mct, 0, (size_t)clr * 16);
+    par_memset(s->mnr, 0, (size_t)clr * 16);
 #ifdef _OPENMP
 #pragma omp parallel for schedule(static)
 #endif
@@ -781,8 +823,8 @@ int smo_stage_predict_indices(smo_ctx *s, const float *pose, int time, float dep
     size_t P = (size_t)s->P;
     float t_inv[16];
     smo_invert4(pose, t_inv);
-    memset(s->idx, 0, P * 4);                     /* glClearColor(0,0,0,0) src/IndexMap.cpp:151 */
-    memset(s->ivc, 0, P * 16); memset(s->ict, 0, P * 16); memset(s->inr, 0, P * 16);
+    par_memset(s->idx, 0, P * 4);                 /* glClearColor(0,0,0,0) src/IndexMap.cpp:151 */
+    par_memset(s->ivc, 0, P * 16); par_memset(s->ict, 0, P * 16); par_memset(s->inr, 0, P * 16);
     uint32_t vis = 0;
 #ifdef _OPENMP
     /* parallel z-buffer: GL_LESS with draw order = lexicographic minimum of (d24, id), kept as one 64-bit key per pixel */
@@ -1180,6 +1222,17 @@ int smo_stage_initialize(smo_ctx *s, const float *pose, int time_i, float max_de
 
 /* ------------------------------------------------------------------ orchestration */
 
+static double now_sec(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+/* stage slots: 0 preprocess (p0a..p0e + uploads), 1 processConflict, 2 updateConflict, 3 backMapping (both calls), 4 buildModelMap
+ * (all calls), 5 predictIndices, 6 dataAssociate, 7 updateFuse, 8 concatenate */
+#define STAGE(slot, call) do { const double t0_ = now_sec(); call; s->stage_sec[slot] += now_sec() - t0_; } while (0)
+
+
 static void run_preprocess_pre(smo_ctx *s)
 {
     /* metriciseDepth + filterDepth  src/SurfelMapping.cpp:136-139 */
@@ -1245,20 +1298,22 @@ int smo_end_frame(smo_ctx *s)
 int smo_process_frame(smo_ctx *s, const uint8_t *rgb, const uint16_t *depth_mm,
                       const uint8_t *sem, const float *pose)
 {
-    int go = smo_begin_frame(s, rgb, depth_mm, sem, pose);
+    int go;
+    STAGE(0, go = smo_begin_frame(s, rgb, depth_mm, sem, pose));
     if (go <= 0) return go;
     float nearc = s->c.near_clip, farc = s->c.far_clip;
-    smo_stage_process_conflict(s, s->curr_pose, nearc, farc, s->c.fuse_thresh, 0); /* :178 */
-    smo_stage_update_conflict(s);                                                   /* :187 */
-    smo_stage_back_mapping(s);                                                      /* :189 */
-    smo_stage_build_model_map(s);                                                   /* :193 */
-    smo_stage_predict_indices(s, s->curr_pose, s->tick, farc, s->c.time_delta);     /* :197 */
-    smo_stage_data_associate(s, s->curr_pose, s->tick, nearc, farc);                /* :212 */
-    smo_stage_update_fuse(s);                                                       /* :227 */
-    smo_stage_back_mapping(s);                                                      /* :229 */
-    int rc = smo_stage_concatenate(s);                                              /* :234 */
-    smo_stage_build_model_map(s);                                                   /* :239 */
-    smo_end_frame(s);
+    int rc;
+    STAGE(1, smo_stage_process_conflict(s, s->curr_pose, nearc, farc, s->c.fuse_thresh, 0)); /* :178 */
+    STAGE(2, smo_stage_update_conflict(s));                                                   /* :187 */
+    STAGE(3, smo_stage_back_mapping(s));                                                      /* :189 */
+    STAGE(4, smo_stage_build_model_map(s));                                                   /* :193 */
+    STAGE(5, smo_stage_predict_indices(s, s->curr_pose, s->tick, farc, s->c.time_delta));     /* :197 */
+    STAGE(6, smo_stage_data_associate(s, s->curr_pose, s->tick, nearc, farc));                /* :212 */
+    STAGE(7, smo_stage_update_fuse(s));                                                       /* :227 */
+    STAGE(3, smo_stage_back_mapping(s));                                                      /* :229 */
+    STAGE(8, rc = smo_stage_concatenate(s));                                                  /* :234 */
+    STAGE(4, smo_stage_build_model_map(s));                                                   /* :239 */
+    STAGE(0, smo_end_frame(s));
     return rc;
 }
 
@@ -1284,6 +1339,16 @@ int smo_reset(smo_ctx *s)
     s->count = s->offset = s->data_count = s->conflict_count = s->unstable_count = 0;
     s->fused_count = s->visible_count = 0;
     s->tick = 0;
+    return SMO_OK;
+}
+
+/* wall seconds per pass since the last call with reset != 0 (9 slots: preprocess, processConflict, updateConflict, backMapping,
+ * buildModelMap, predictIndices, dataAssociate, updateFuse, concatenate) */
+int smo_stage_seconds(smo_ctx *s, double *out9, int reset)
+{
+    if (!s) return SMO_E_ARG;
+    if (out9) memcpy(out9, s->stage_sec, 9 * sizeof(double));
+    if (reset) memset(s->stage_sec, 0, sizeof s->stage_sec);
     return SMO_OK;
 }
 

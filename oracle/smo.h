@@ -73,6 +73,9 @@ int smo_clean_points(smo_ctx *s, const uint16_t *depth_mm, const uint8_t *sem, c
 int smo_reset(smo_ctx *s);
 
 int smo_get_counts(const smo_ctx *s, smo_counts *out);
+/* wall seconds smo_process_frame spent per pass since the last reset (preprocess, processConflict, updateConflict, backMapping,
+ * buildModelMap, predictIndices, dataAssociate, updateFuse, concatenate): bench.py's CPU baseline reports them */
+int smo_stage_seconds(smo_ctx *s, double *out9, int reset);
 /* AoS export, 12 floats per surfel (src/Config.cpp:17-32) */
 int smo_download_model(const smo_ctx *s, float *dst12, uint32_t cap, uint32_t *n);
 /* GlobalModel::uploadMap payload (src/GlobalModel.cpp:995-1002) + mirror rebuild so that

@@ -62,6 +62,12 @@ public:
     {
         if (!gtPose) { std::printf("processFrame: gtPose is required\n"); return; }
         currPose = *gtPose;
+        // the reference uploads the three images into its RGB / DEPTH / SEMANTIC textures (src/SurfelMapping.cpp:122-128; a null
+        // depth / semantic keeps the old one): kept here as host copies for getTexture()
+        const size_t P = (size_t)Config::W() * Config::H();
+        textures[GPUTexture::RGB]->host_u8.assign(rgb, rgb + P * 3);
+        if (depth) textures[GPUTexture::DEPTH_RAW]->host_u16.assign(depth, depth + P);
+        if (semantic) textures[GPUTexture::SEMANTIC]->host_u8.assign(semantic, semantic + P);
         int rc = sm_process_frame(ctx_, rgb, depth, semantic, gtPose->data());
         if (rc != SM_OK) std::printf("processFrame: %s\n", sm_last_error());
         historyPoses.push_back(currPose);
@@ -82,11 +88,42 @@ public:
     GlobalModel &getGlobalModel() { return globalModel; }
 
     // src/SurfelMapping.cpp:450-456
+    // The images live in the HIP context; the handle is filled when somebody asks for it (build_map.cpp:34-38 shows RGB,
+    // DEPTH_METRIC and DEPTH_FILTERED every frame): the three float images are read back from the core (sm_download_depth),
+    // the input images are the copies processFrame kept.  With SM_FACADE_GL the data goes into a real pangolin::GlTexture of the
+    // reference's format (src/SurfelMapping.cpp:50-85); without GL the POD handle points at the host copy.
     pangolin::GlTexture *getTexture(const std::string &textureType)
     {
         auto it = textures.find(textureType);
         assert(it != textures.end() && "there is no such texture type");
-        return it->second->texture;
+        GPUTexture *t = it->second;
+        const int W = Config::W(), H = Config::H();
+        const int which = textureType == GPUTexture::DEPTH_METRIC ? SM_TEX_DEPTH_METRIC
+                        : textureType == GPUTexture::DEPTH_FILTERED ? SM_TEX_DEPTH_FILTERED : textureType == "LAST" ? SM_TEX_LAST : -1;
+        if (which >= 0) {
+            t->host_f.resize((size_t)W * H);
+            if (sm_download_depth(ctx_, which, t->host_f.data()) != SM_OK) std::printf("getTexture: %s\n", sm_last_error());
+        }
+#ifdef SM_FACADE_GL
+        if (which >= 0) {
+            if (!t->texture->tid) t->texture->Reinitialise(W, H, GL_R32F, false, 0, GL_RED, GL_FLOAT);
+            t->texture->Upload(t->host_f.data(), GL_RED, GL_FLOAT);
+        } else if (textureType == GPUTexture::RGB && !t->host_u8.empty()) {
+            if (!t->texture->tid) t->texture->Reinitialise(W, H, GL_RGB32F, true, 0, GL_RGB, GL_UNSIGNED_BYTE);
+            t->texture->Upload(t->host_u8.data(), GL_RGB, GL_UNSIGNED_BYTE);
+        } else if (textureType == GPUTexture::DEPTH_RAW && !t->host_u16.empty()) {
+            if (!t->texture->tid) t->texture->Reinitialise(W, H, GL_R16UI, false, 0, GL_RED_INTEGER, GL_UNSIGNED_SHORT);
+            t->texture->Upload(t->host_u16.data(), GL_RED_INTEGER, GL_UNSIGNED_SHORT);
+        } else if (textureType == GPUTexture::SEMANTIC && !t->host_u8.empty()) {
+            if (!t->texture->tid) t->texture->Reinitialise(W, H, GL_R8UI, false, 0, GL_RED_INTEGER, GL_UNSIGNED_BYTE);
+            t->texture->Upload(t->host_u8.data(), GL_RED_INTEGER, GL_UNSIGNED_BYTE);
+        }
+#elif defined(SM_COMPAT_POD_TEXTURE)
+        t->texture->host = t->host_f.empty() ? nullptr : t->host_f.data();
+        t->texture->host_u8 = t->host_u8.empty() ? nullptr : t->host_u8.data();
+        t->texture->host_u16 = t->host_u16.empty() ? nullptr : t->host_u16.data();
+#endif
+        return t->texture;
     }
     // src/SurfelMapping.cpp:458-464: only "RAW" is ever created (src/SurfelMapping.cpp:88-90)
     FeedbackBuffer *getFeedbackBuffer(const std::string &feedbackType)

@@ -28,12 +28,16 @@ struct Matrix4f {
 #include <pangolin/gl/gl.h>
 #else
 typedef unsigned int GLuint;
+#define SM_COMPAT_POD_TEXTURE 1
 namespace pangolin {
-// POD handle with the fields callers read (build_map.cpp:34-38 shows textures by pointer only)
+// POD handle with the fields callers read (build_map.cpp:34-38 shows textures by pointer only) and, since no GL object
+// exists here, the host copy of the image the reference's texture would hold (row-major; whichever matches the texture's type)
 struct GlTexture {
     int width = 0, height = 0;
     GLuint tid = 0;
-    const float *host = nullptr;   // lazily filled read-back of the device image
+    const float *host = nullptr;               // DEPTH_METRIC / DEPTH_FILTERED / LAST: H x W metres
+    const unsigned char *host_u8 = nullptr;    // RGB: H x W x 3; SEMANTIC: H x W
+    const unsigned short *host_u16 = nullptr;  // DEPTH (raw): H x W millimetres
 };
 struct OpenGlMatrix { double m[16]; };
 }  // namespace pangolin

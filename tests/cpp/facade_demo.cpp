@@ -40,6 +40,22 @@ int main(int argc, char **argv)
                     core.getGlobalModel().lastDrawnCount(), nr->width, nr->height, core.getTexture(GPUTexture::RGB)->width,
                     core.getTexture(GPUTexture::DEPTH_METRIC)->height);
     }
+    if (argc > 4) {
+        // what build_map.cpp:34-38 puts on the screen every frame: the RGB / DEPTH_METRIC / DEPTH_FILTERED textures (and LAST).
+        // Without GL the handles point at host copies: dump them for the test
+        FILE *t = std::fopen(argv[4], "wb");
+        if (!t) return 2;
+        const size_t P = (size_t)W * H;
+        for (const char *n : {GPUTexture::DEPTH_METRIC, GPUTexture::DEPTH_FILTERED, "LAST"}) {
+            pangolin::GlTexture *tx = core.getTexture(n);
+            if (!tx->host || tx->width != W || tx->height != H) return 3;
+            std::fwrite(tx->host, 4, P, t);
+        }
+        pangolin::GlTexture *tr = core.getTexture(GPUTexture::RGB), *ts = core.getTexture(GPUTexture::SEMANTIC), *td = core.getTexture(GPUTexture::DEPTH_RAW);
+        if (!tr->host_u8 || !ts->host_u8 || !td->host_u16) return 3;
+        std::fwrite(tr->host_u8, 1, P * 3, t); std::fwrite(ts->host_u8, 1, P, t); std::fwrite(td->host_u16, 2, P, t);
+        std::fclose(t);
+    }
     if (argc > 3) {                                                        // load_map.cpp-style novel-view dump
         std::vector<Eigen::Matrix4f> views = {core.getCurrPose()};
         core.acquireImages(argv[3], views, W, H, intr[0], intr[1], intr[2], intr[3], 7);

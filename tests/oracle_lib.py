@@ -173,6 +173,16 @@ class Oracle:
     def reset(self):
         _chk(self._L.smo_reset(self._h), "reset")
 
+    STAGES = ("preprocess", "processConflict", "updateConflict", "backMapping", "buildModelMap", "predictIndices", "dataAssociate",
+              "updateFuse", "concatenate")
+
+    def stage_seconds(self, reset=False) -> dict:
+        """wall seconds process_frame spent per pass since the last reset"""
+        out = (C.c_double * 9)()
+        self._L.smo_stage_seconds.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int]
+        _chk(self._L.smo_stage_seconds(self._h, out, 1 if reset else 0), "stage_seconds")
+        return dict(zip(self.STAGES, [float(x) for x in out]))
+
     def counts(self) -> dict:
         c = SmoCounts()
         _chk(self._L.smo_get_counts(self._h, C.byref(c)), "get_counts")

@@ -41,11 +41,24 @@ def test_facade_demo_matches_oracle(tmp_path):
     out = tmp_path / "map.bin"
     views = tmp_path / "views"
     views.mkdir()
-    r = subprocess.run([exe, str(frames), str(out), str(views)], capture_output=True, text=True)
+    tex = tmp_path / "textures.bin"
+    r = subprocess.run([exe, str(frames), str(out), str(views), str(tex)], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     o = ol.Oracle(ol.make_config(**cam, preprocess=0, max_sqrt_vertices=1000))
     for fr in seq:
         o.process_frame(*fr)
+    # getTexture(): the three float images read back from the core, the three input images as the last processFrame left them
+    P = cam["width"] * cam["height"]
+    tb = open(tex, "rb").read()
+    assert len(tb) == P * (3 * 4 + 3 + 1 + 2)
+    for k, which in enumerate((0, 1, 2)):                           # DEPTH_METRIC, DEPTH_FILTERED, LAST
+        got = np.frombuffer(tb[k * P * 4:(k + 1) * P * 4], np.float32).reshape(cam["height"], cam["width"])
+        want = o.download_depth(which)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), which
+    off = 3 * P * 4
+    assert np.array_equal(np.frombuffer(tb[off:off + 3 * P], np.uint8), seq[-1][0].ravel())
+    assert np.array_equal(np.frombuffer(tb[off + 3 * P:off + 4 * P], np.uint8), seq[-1][2].ravel())
+    assert np.array_equal(np.frombuffer(tb[off + 4 * P:], np.uint16), seq[-1][1].ravel())
     raw = open(out, "rb").read()
     n = int(np.frombuffer(raw[:4], np.uint32)[0])
     m = np.frombuffer(raw[12:], np.float32).reshape(n, 12)

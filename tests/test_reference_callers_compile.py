@@ -20,11 +20,15 @@ REF = "/root/reference"
 
 @pytest.mark.skipif(not os.path.isdir(REF), reason="reference mount absent")
 @pytest.mark.skipif(shutil.which("g++") is None, reason="no g++")
+@pytest.mark.parametrize("gl", [False, True])
 @pytest.mark.parametrize("unit", ["build_map.cpp", "load_map.cpp"])
-def test_reference_caller_compiles_against_the_facade(unit):
+def test_reference_caller_compiles_against_the_facade(unit, gl):
+    """gl = True: with -DSM_FACADE_GL, i.e. the branches that fill real GL objects (vertex buffers for renderModel and the raw
+    cloud, pangolin::GlTexture::Reinitialise / Upload for getTexture and the mirror planes) are type-checked too, against the GL /
+    Pangolin declarations of tests/stubs/pangolin_stub.h."""
     src = os.path.join(REF, unit)
     assert os.path.exists(src)
-    cmd = ["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Wno-format", "-Wno-unused-variable", "-Wno-unused-but-set-variable",
+    cmd = ["g++", "-std=c++17", "-fsyntax-only"] + (["-DSM_FACADE_GL"] if gl else []) + [ "-Wall", "-Wno-format", "-Wno-unused-variable", "-Wno-unused-but-set-variable",
            "-Wno-sign-compare", "-Wno-unused-parameter",
            "-I", os.path.join(ROOT, "surfelmapping_amd", "csrc", "facade"),     # SurfelMapping.h, KittiReader.h, Config.h ... (first: drop-in)
            "-I", os.path.join(ROOT, "tests", "stubs"),                           # Eigen / pangolin / opencv2 declarations, Shaders.h
