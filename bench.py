@@ -402,13 +402,22 @@ def bench_ranks(args, cam, rank, world, local_rank, K, Wm, workers, emit):
         return ids[0]
 
     cfg = dict(preprocess=args.preprocess, device=local_rank, conflict_cap=1, compact_period=args.compact_period)
+    msv_global = int(math.ceil(math.sqrt(world) * 5000))
     # ---- rig leg: one camera stream per GPU, no collective inside a frame
     sm = capi.SurfelMap(capi.make_config(**cam, **cfg))
     dptr = stage_frames(sm, frames, P)
+    # the single GlobalModel DURING the run (sm_rig_consolidate_step: new-surfel lists all-gathered, the union cleaned against every
+    # camera's latest view): one step after the warm-up, one after the timed frames -- the second is timed, outside `value`
+    sm_inc = capi.SurfelMap(capi.make_config(**cam, preprocess=0, device=local_rank, max_sqrt_vertices=msv_global))
+    rig = smd.RigMapper(sm, smsh.TorchComm(device_index=local_rank), P)
+    rig.enable_native("rccl", bcast_id())
+    nranks_rig = sm.shard_rccl_nranks()
     gc.collect(); gc.disable()
     for k in range(Wm):
         sm.process_frame_device(*dptr[k])
     sm.sync()
+    rig.last = (frames[Wm - 1][1], frames[Wm - 1][2], frames[Wm - 1][3])
+    rig.consolidate_step_native(sm_inc)
     barrier()
     t0 = time.perf_counter()
     for k in range(Wm, Wm + K):
@@ -427,12 +436,14 @@ def bench_ranks(args, cam, rank, world, local_rank, K, Wm, workers, emit):
     dist.broadcast(own_t, src=0)
     plain_ms = float(own_t[0]) / K * 1e3           # rank 0's camera IS the shared stream: the plain single-GPU time of those frames
     # ---- consolidation into a single GlobalModel (sm_rig_consolidate: all-gathers + per-slice cleanPoints, inside the core)
-    sm_global = capi.SurfelMap(capi.make_config(**cam, preprocess=0, device=local_rank,
-                                                max_sqrt_vertices=int(math.ceil(math.sqrt(world) * 5000))))
-    rig = smd.RigMapper(sm, smsh.TorchComm(device_index=local_rank), P)
     rig.last = (frames[Wm + K - 1][1], frames[Wm + K - 1][2], frames[Wm + K - 1][3])     # the camera's latest view
-    rig.enable_native("rccl", bcast_id())
-    nranks_rig = sm.shard_rccl_nranks()
+    barrier()
+    s0 = time.perf_counter()
+    step_new, step_total = rig.consolidate_step_native(sm_inc)
+    torch.cuda.synchronize()
+    step_ms = max_over_ranks((time.perf_counter() - s0) * 1e3)
+    sm_inc.close()
+    sm_global = capi.SurfelMap(capi.make_config(**cam, preprocess=0, device=local_rank, max_sqrt_vertices=msv_global))
     barrier()
     g0 = time.perf_counter()
     global_count, view_conflicts = rig.consolidate_native(sm_global)
@@ -495,7 +506,11 @@ def bench_ranks(args, cam, rank, world, local_rank, K, Wm, workers, emit):
                    "multi_gpu": {"consolidation": "after the timed frames: every slice cleaned against all latest views (cleanPoints per view, the W*H "
                                                   "conflict cap shared exactly across the slices), slices all-gathered in rank order into a single "
                                                   "GlobalModel on every rank, inside the HIP core over RCCL (sm_rig_consolidate); not in `value`",
-                                 "consolidation_ms": gather_ms, "consolidation_ms_per_frame_if_every_K": gather_ms / K,
+                                 "consolidation_ms": gather_ms,
+                                 "incremental": {"what": "sm_rig_consolidate_step once per K frames: the ranks' new-surfel lists all-gathered into the single "
+                                                         "GlobalModel (kept on every rank), which is then cleaned against every camera's latest view",
+                                                 "every_K_frames": K, "step_ms": step_ms, "ms_per_frame": step_ms / K,
+                                                 "new_surfels_exchanged": int(step_new), "global_model_surfels": int(step_total)},
                                  "global_model_surfels": int(global_count), "conflicts_per_view": [int(c) for c in view_conflicts]},
                    "host_sync": "none inside the timed region", "surfels_end_rank0": int(counts["count"])},
         "rccl": {"nranks": nranks_rig, "world_size": world, "backend": "RCCL bound by the HIP core (ncclCommInitRank / ncclCommCount); torch.distributed "

@@ -307,6 +307,13 @@ int sm_shard_export_dense_device(sm_ctx *s, const float **d_out12, uint32_t *cou
 int sm_rig_configure(sm_ctx *s, int rank, int world);
 int sm_rig_consolidate(sm_ctx *s, const uint16_t *depth_mm, const uint8_t *semantic, const float *pose16, sm_ctx *global,
                        uint32_t *view_conflicts, uint32_t *total);
+/* The single GlobalModel DURING a run, one step (collective; call it every K frames): every rank's surfels created since its
+ * previous step are all-gathered -- per-GPU new-surfel lists, SURVEY.md 8e -- and appended to `global` in rank order
+ * (GlobalModel::concatenate), then `global` is cleaned against every camera's latest view in rank order (SurfelMapping::cleanPoints)
+ * -- the same on every rank, on `global`'s stream.  The camera's own model is not changed.  new_surfels / global_count (may be
+ * null): surfels exchanged in this step, surfels in `global` after it. */
+int sm_rig_consolidate_step(sm_ctx *s, const uint16_t *depth_mm, const uint8_t *semantic, const float *pose16, sm_ctx *global,
+                            uint32_t *new_surfels, uint32_t *global_count);
 
 #ifdef __cplusplus
 }

@@ -28,7 +28,7 @@ SYMBOLS = (
     "sm_export_model_device", "sm_append_model_aos_device", "sm_device_download",
     "sm_shard_stream_configure", "sm_shard_set_collective", "sm_shard_rccl_unique_id", "sm_shard_rccl_init",
     "sm_shard_rccl_finalize", "sm_shard_rccl_nranks", "sm_shard_frame_device", "sm_shard_frame", "sm_shard_compact", "sm_shard_export_dense_device",
-    "sm_gpu_process_count", "sm_rig_configure", "sm_rig_consolidate",
+    "sm_gpu_process_count", "sm_rig_configure", "sm_rig_consolidate", "sm_rig_consolidate_step",
 )
 
 SM_COLL_SUM, SM_COLL_MIN, SM_COLL_GATHER = 0, 1, 2
@@ -212,6 +212,7 @@ def load():
     L.sm_gpu_process_count.argtypes = [vp]
     L.sm_rig_configure.argtypes = [vp, C.c_int, C.c_int]
     L.sm_rig_consolidate.argtypes = [vp, vp, vp, vp, vp, u32p, u32p]
+    L.sm_rig_consolidate_step.argtypes = [vp, vp, vp, vp, vp, u32p, u32p]
     for name in SYMBOLS:
         getattr(L, name)          # AttributeError here = the library does not match the header
     _lib = L
@@ -535,6 +536,19 @@ class SurfelMap:
             raise e
         self._chk(rc, "sm_rig_consolidate")
         return total.value, [int(x) for x in per_view]
+
+    def rig_consolidate_step(self, depth, sem, pose, sm_global):
+        """collective, every K frames: -> (new surfels exchanged in this step, surfels in the single GlobalModel `sm_global` after it)"""
+        depth = np.ascontiguousarray(depth, np.uint16)
+        sem = np.ascontiguousarray(sem, np.uint8)
+        pose = np.ascontiguousarray(pose, np.float32)
+        new, tot = C.c_uint32(), C.c_uint32()
+        rc = self._L.sm_rig_consolidate_step(self._h, _ptr(depth), _ptr(sem), _ptr(pose), sm_global._h, C.byref(new), C.byref(tot))
+        if rc and getattr(self, "_coll_error", None) is not None:
+            e, self._coll_error = self._coll_error, None
+            raise e
+        self._chk(rc, "sm_rig_consolidate_step")
+        return new.value, tot.value
 
     def gpu_process_count(self) -> int:
         """processes with compute queues on this context's GPU per the KFD tables (this one included); -1 if unreadable"""

@@ -347,6 +347,7 @@ struct sm_ctx {
     // slot-addressed sharding of one stream, in-stream form (sm_shard_stream_*)
     bool ss_on = false;
     bool rig_on = false;               // sm_rig_configure: rank / world / collective are used by sm_rig_consolidate only
+    float rig_last_time = -1.0e30f;    // creation time stamp up to which this rank's surfels are in the incremental GlobalModel (sm_rig_consolidate_step)
     int ss_rank = 0, ss_world = 1;
     uint32_t ss_frames = 0;            // fusing frames so far = index of the next segment (its owner: index % world)
     sm_collective_fn ss_coll = nullptr;
@@ -2423,6 +2424,86 @@ struct RigXchg {
     unsigned long long conflicts(int q) const { return h[(size_t)q * 4 + 1]; }
 };
 }  // namespace
+
+// The single GlobalModel DURING a run ("all-gather of per-GPU new-surfel lists into the single GlobalModel, followed by
+// one conflict pass of every camera's depth against the union").  One step, collective:
+//   1. every rank's NEW surfels -- created since its previous step, still alive, in creation order (the model is kept in creation
+//      order, so they are a suffix of the compacted model) -- are all-gathered and appended to `global` in rank order
+//      (GlobalModel::concatenate's order for W append lists), on every rank;
+//   2. the cameras' latest views are all-gathered and `global` is cleaned against each of them in rank order with
+//      SurfelMapping::cleanPoints (src/SurfelMapping.cpp:496-532) -- replicated: every rank holds the same GlobalModel, so the W*H
+//      conflict cap and the id-0 rule need no exchange, and the work runs on `global`'s own stream, next to the camera's frames.
+// The camera's own slice is not touched (its fusion goes on as if alone); what an older surfel of it becomes later -- fused
+// updates, its own culls -- reaches `global` only through the views' conflict tests.  sm_rig_consolidate above is the exact
+// end-of-run union; this is the incremental model, defined by the same reference operations (tests/test_rig.py states it on
+// oracles).
+int sm_rig_consolidate_step(sm_ctx *s, const uint16_t *depth_mm, const uint8_t *semantic, const float *pose16, sm_ctx *global,
+                            uint32_t *new_surfels, uint32_t *global_count)
+{
+    if (!s || !depth_mm || !semantic || !pose16 || !global || !s->rig_on) { g_err = "sm_rig_consolidate_step: bad argument (sm_rig_configure first)"; return SM_E_ARG; }
+    HIPCK(hipSetDevice(s->cfg.device));
+    if (hip_runtime_conflict("sm_rig_consolidate_step")) return SM_E_HIP;
+    const int W = s->ss_world, r = s->ss_rank;
+    const size_t P = (size_t)s->P;
+    const size_t off_sem = 2 * P, off_pose = (3 * P + 7) / 8 * 8, row = off_pose + 64;
+    uint8_t *d_views = nullptr;
+    float *d_lists = nullptr;
+    uint32_t *d_first = nullptr;
+    RigXchg x(s, W, r);
+    auto done = [&](int code) { (void)hipFree(d_views); (void)hipFree(d_lists); (void)hipFree(d_first); (void)hipFree(x.d_cnt); return code; };
+    HIPCK(hipMalloc((void **)&x.d_cnt, 32 * (size_t)W));
+    // ---- local: compact (slots become positions), find the first surfel newer than the previous step, stage the view
+    int st = ensure_compact(s);
+    if (!st) st = pull_state(s);
+    uint32_t cnt = 0, first = 0;
+    if (!st) {
+        cnt = s->h_state->count;
+        first = cnt;
+        if (hipMalloc((void **)&d_first, 4) != hipSuccess || hipMemsetAsync(d_first, 0xFF, 4, s->stream) != hipSuccess) st = SM_E_HIP;
+        if (!st && cnt) {
+            hipLaunchKernelGGL(k_first_newer, dim3(std::min<uint32_t>((cnt + 255u) / 256u, 1024u)), dim3(256), 0, s->stream, s->M, s->d_state, s->rig_last_time, d_first);
+            uint32_t f = 0xFFFFFFFFu;
+            if (hipGetLastError() != hipSuccess || hipMemcpyAsync(&f, d_first, 4, hipMemcpyDeviceToHost, s->stream) != hipSuccess ||
+                hipStreamSynchronize(s->stream) != hipSuccess) st = SM_E_HIP;
+            else first = std::min(f, cnt);
+        }
+    }
+    const uint32_t n_new = st ? 0u : cnt - first;
+    if (!st && hipMalloc((void **)&d_views, row * (size_t)W) != hipSuccess) { g_err = "sm_rig_consolidate_step: out of device memory for the views"; st = SM_E_HIP; }
+    if (!st && (hipMemsetAsync(d_views + row * r, 0, row, s->stream) != hipSuccess ||
+                hipMemcpyAsync(d_views + row * r, depth_mm, 2 * P, hipMemcpyHostToDevice, s->stream) != hipSuccess ||
+                hipMemcpyAsync(d_views + row * r + off_sem, semantic, P, hipMemcpyHostToDevice, s->stream) != hipSuccess ||
+                hipMemcpyAsync(d_views + row * r + off_pose, pose16, 64, hipMemcpyHostToDevice, s->stream) != hipSuccess)) st = SM_E_HIP;
+    int rc = x.run(n_new, 0ull, st);
+    if (rc) return done(rc);
+    // ---- 1. the new-surfel lists, all-gathered (padded to the longest) and appended to `global` in rank order
+    unsigned long long T = 0, maxn = 0;
+    std::vector<unsigned long long> nn((size_t)W);
+    for (int q = 0; q < W; ++q) { nn[(size_t)q] = x.count(q); T += nn[(size_t)q]; maxn = std::max(maxn, nn[(size_t)q]); }
+    if (new_surfels) *new_surfels = (uint32_t)T;
+    st = SM_OK;
+    if (T && hipMalloc((void **)&d_lists, (size_t)maxn * 48 * (size_t)W) != hipSuccess) { g_err = "sm_rig_consolidate_step: out of device memory for the lists"; st = SM_E_HIP; }
+    if ((rc = x.run(n_new, 0ull, st))) return done(rc);
+    if (T) {
+        if (n_new) hipLaunchKernelGGL(k_export_aos, dim3((n_new + 255) / 256), dim3(256), 0, s->stream, s->M, s->d_state, d_lists + (size_t)r * maxn * 12, first, n_new);
+        if (hipGetLastError() != hipSuccess) return done(SM_E_HIP);
+        if ((rc = ss_collective(s, d_lists + (size_t)r * maxn * 12, d_lists, (size_t)maxn * 6, SM_COLL_GATHER))) return done(rc);
+    }
+    if ((rc = ss_collective(s, d_views + row * r, d_views, row / 8, SM_COLL_GATHER))) return done(rc);
+    std::vector<float> poses((size_t)W * 16);
+    for (int v = 0; v < W; ++v)
+        if (hipMemcpyAsync(&poses[(size_t)v * 16], d_views + row * v + off_pose, 64, hipMemcpyDeviceToHost, s->stream) != hipSuccess) return done(SM_E_HIP);
+    if (hipStreamSynchronize(s->stream) != hipSuccess) return done(SM_E_HIP);
+    for (int q = 0; q < W; ++q)
+        if (nn[(size_t)q] && (rc = sm_append_model_aos_device(global, d_lists + (size_t)q * maxn * 12, (uint32_t)nn[(size_t)q]))) return done(rc);
+    // ---- 2. the union cleaned against every camera's latest view, in rank order (the same work on every rank)
+    for (int v = 0; v < W; ++v)
+        if ((rc = clean_points_device(global, reinterpret_cast<const uint16_t *>(d_views + row * v), d_views + row * v + off_sem,
+                                      &poses[(size_t)v * 16], 1))) return done(rc);
+    if (global_count) *global_count = global->counts.count;
+    s->rig_last_time = (float)(s->tick - 1);           // every surfel created so far carries a time stamp <= tick - 1
+    return done(SM_OK);
+}
 
 int sm_rig_consolidate(sm_ctx *s, const uint16_t *depth_mm, const uint8_t *semantic, const float *pose16, sm_ctx *global,
                        uint32_t *view_conflicts, uint32_t *total_out)

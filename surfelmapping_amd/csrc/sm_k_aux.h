@@ -2,6 +2,19 @@
 // Part of sm_kernels.h (included there, in order, inside namespace sm); shader citations: /root/reference/src/Shaders/<file>:<line>.
 #pragma once
 
+// first surfel (position in the compacted model) created after time stamp t0: the model is kept in creation order, so the
+// surfels a rig rank has not yet contributed to the single GlobalModel are the suffix from there on (sm_rig_consolidate_step)
+__global__ __launch_bounds__(256) void k_first_newer(Model M, const DevState *__restrict__ st, float t0, uint32_t *__restrict__ out)
+{
+    const uint32_t N = st->count;
+    const float *__restrict__ it = M.s[st->cur].init_time;
+    uint32_t best = 0xFFFFFFFFu;
+    for (uint32_t k = blockIdx.x * 256u + threadIdx.x; k < N; k += gridDim.x * 256u)
+        if (it[k] > t0) { best = k; break; }               // (k ascending per thread: its first hit is its smallest)
+    best = 0xFFFFFFFFu - wave_max_u32(0xFFFFFFFFu - best);
+    if ((threadIdx.x & 63) == 0 && best != 0xFFFFFFFFu) atomicMin(out, best);
+}
+
 // SM_CHECK_ALIVE=1 (diagnostic): the invariant every compaction relies on -- per tile, occupied slots - dead count == live bits --
 // checked after a stage; out[0] counts the tiles that violate it, out[1..4] describe the first one seen
 __global__ __launch_bounds__(256) void k_check_alive(const DevState *__restrict__ st, const uint64_t *__restrict__ alive,

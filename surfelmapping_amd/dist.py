@@ -167,6 +167,12 @@ class RigMapper:
             self.be.shard_set_collective(collective)
         self._native = True
 
+    def consolidate_step_native(self, sm_global):
+        """the incremental single GlobalModel, one step (every K frames; collective): -> (new surfels exchanged, surfels in `sm_global`)"""
+        assert getattr(self, "_native", False), "enable_native() first"
+        depth, sem, pose = self.last
+        return self.be.rig_consolidate_step(depth, sem, pose, sm_global)
+
     def consolidate_native(self, sm_global):
         """-> (surfels of the single GlobalModel, now in `sm_global`; conflicts per view); collective"""
         assert getattr(self, "_native", False), "enable_native() first"

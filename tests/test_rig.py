@@ -347,3 +347,73 @@ def test_rig_conflict_cap_is_shared_exactly_oracle_ranks():
 def test_rig_conflict_cap_is_shared_exactly_hip_contexts(native):
     from surfelmapping_amd import capi
     check_cap(run_cap_threads(3, lambda r: capi.SurfelMap(capi.make_config(**CAP_CAM, **CAP_OVER)), native), 3)
+
+
+# ---------------------------------------------------------------- the single GlobalModel DURING a run (sm_rig_consolidate_step)
+def step_definition(world, steps, n_frames):
+    """the incremental GlobalModel by its definition, on oracles: at every step the ranks' surfels created since the previous
+    step (still alive, creation order) are appended in rank order (GlobalModel::concatenate), then the model is cleaned against
+    every camera's latest view in rank order (SurfelMapping::cleanPoints)"""
+    ranks = [ol.Oracle(ol.make_config(**CAM, **OVER)) for _ in range(world)]
+    seqs = [rank_stream(r, world, CAM, n_frames) for r in range(world)]
+    g = ol.Oracle(ol.make_config(**CAM, **dict(OVER, max_sqrt_vertices=int(OVER["max_sqrt_vertices"] * math.sqrt(world)) + 8)))
+    out, last_t, k0 = [], -1.0e30, 0
+    for k1 in steps:
+        lists = []
+        for r in range(world):
+            for fr in seqs[r][k0:k1]:
+                ranks[r].process_frame(*fr)
+            m = ranks[r].download_model()
+            lists.append(m[m[:, 6] > last_t])
+        g.upload_model(np.concatenate([g.download_model()] + lists, axis=0))
+        for r in range(world):
+            g.clean_points(*seqs[r][k1 - 1][1:])
+        out.append((g.download_model(), sum(x.shape[0] for x in lists)))
+        last_t, k0 = float(k1 - 1), k1          # frame k carries the time stamp k: everything created so far is <= k1 - 1
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3])
+def test_rig_incremental_global_model_equals_the_definition(world):
+    from surfelmapping_amd import capi
+    steps, n_frames = (3, 5, 7), 7
+    ref = step_definition(world, steps, n_frames)
+    assert ref[-1][0].shape[0] > 5000 and all(n > 500 for _, n in ref)
+    group = sharded.ThreadGroup(world)
+    out, err = [None] * world, []
+
+    def work(r):
+        try:
+            sm = capi.SurfelMap(capi.make_config(**CAM, **OVER))
+            glob = capi.SurfelMap(capi.make_config(**CAM, **dict(OVER, max_sqrt_vertices=int(OVER["max_sqrt_vertices"] * math.sqrt(world)) + 8)))
+            mp = smd.RigMapper(sm, sharded.ThreadComm(group, r), CAM["width"] * CAM["height"])
+            mp.enable_native(sharded.ThreadCollective(group, r, sm) if world > 1 else None)
+            seq = rank_stream(r, world, CAM, n_frames)
+            got, k0 = [], 0
+            for k1 in steps:
+                for fr in seq[k0:k1]:
+                    mp.process_frame(*fr)
+                new, tot = mp.consolidate_step_native(glob)
+                got.append((glob.download_model(), new, tot))
+                k0 = k1
+            own = sm.download_model()
+            out[r] = (got, own)
+        except BaseException as e:
+            err.append(e)
+            group.barrier.abort()
+
+    ts = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    [t.start() for t in ts]
+    [t.join(600) for t in ts]
+    if err:
+        raise err[0]
+    for r in range(world):
+        for k, ((model, new, tot), (want, want_new)) in enumerate(zip(out[r][0], ref)):
+            assert new == want_new and tot == want.shape[0], (r, k, new, want_new, tot, want.shape)
+            assert np.array_equal(model.view(np.uint32), want.view(np.uint32)), f"rank {r} step {k}"
+        # the camera's own model is what it would be alone
+        o = ol.Oracle(ol.make_config(**CAM, **OVER))
+        for fr in rank_stream(r, world, CAM, n_frames):
+            o.process_frame(*fr)
+        assert np.array_equal(out[r][1].view(np.uint32), o.download_model().view(np.uint32))
