@@ -305,6 +305,7 @@ struct sm_ctx {
     unsigned long long *h_stat = nullptr, *d_stat = nullptr;   // pinned, device-written: frames<<32 | occupied slots
     uint32_t *d_tb = nullptr;          // per-tile bounds (8 words per tile)
     uint8_t *d_tile_flags = nullptr;   // per-tile skip flags of the current frame
+    uint8_t *d_tile_flags_nx = nullptr; uint4 *d_wave_cnt_nx = nullptr; uint2 *d_prep_part_nx = nullptr;   // the other frame's (two-launch frame: its publisher runs next to this frame's flag workgroups)
     uint32_t *d_conf_part = nullptr;   // per-workgroup partial counters (instead of same-address atomics)
     uint2 *d_compact_part = nullptr;
     uint4 *d_lazy_part = nullptr;      // partials of k_cull_lazy_frame / k_surfel_pass (visible, splat-skipped, killed, conflict-skipped)
@@ -326,14 +327,16 @@ struct sm_ctx {
     int fix_grid = 128;
     // direct append (k_associate_direct): candidate counts per association block / per group, group prefixes
     uint32_t *d_blk_cand = nullptr, *d_grp_cand = nullptr;
-    uint32_t *d_frame_sub = nullptr;   // 4 x 64 sub-counters: visible, killed (k_surfel_pass), new, fused (k_associate_direct)
+    uint32_t *d_frame_sub = nullptr;   // 2 x 64 sub-counters: visible, killed (k_surfel_pass)
+    uint32_t *d_nf_sub = nullptr, *d_nf_sub_nx = nullptr;   // 2 x 64 each: new, fused (k_associate_direct) of this / the other frame
+    uint32_t *nf_last = nullptr;       // the set the last direct association counted into (its statistics may still be pending)
     uint32_t n_grp = 0, cand_group = 16;
     bool pend_finalize = false;        // the last frame's statistics are completed by the next k_pass_fixup or by k_frame_finalize
     int fix_set = 0;                   // k_pass_fixup's partials alternate between two sets (the previous frame's are read one frame later)
     unsigned long long *d_pass_trace = nullptr;   // SM_PASS_TRACE=<file prefix>: per-workgroup time stamps of the last k_surfel_pass launch, dumped by sm_destroy
     int pass_trace_grid = 0;
     unsigned long long *d_ap_trace = nullptr;     // the same for the last k_assoc_prep launch: (entry, exit) per workgroup
-    int ap_trace_n[3] = {0, 0, 0};                // its association / tile-flag / image workgroups (dispatch order)
+    int ap_trace_n[4] = {0, 0, 0, 0};             // its association / tile-flag / image workgroups (dispatch order); fixup workgroups ahead of them
     uint32_t *d_conf_sub = nullptr;    // 2 x 64 conflict sub-counters (one set per frame parity: zeroed by that frame's k_prep)
     int conf_sub_set = 0;
     uint32_t n_conf_part = 0, n_compact_part = 0;
@@ -363,6 +366,12 @@ struct sm_ctx {
     bool assoc_pending = false;
     AssocArgs assoc_args{};            // the held-back association (its FrameParams and that frame's planes)
     bool merge_assoc = false;          // set by enqueue_frame: the k_prep launch of this call carries assoc_args
+    // two-launch frame: the fixup step (publisher, cap repair) of a frame whose association is held back rides on the same
+    // launch as that association; the candidate count moved into the pass's launch
+    bool two_launch = false;           // this context uses it (defer_ok, SM_TWO_LAUNCH != 0)
+    bool fix_pending = false;          // the last frame's fixup has not run yet
+    FixArgs fix_args{};
+    static constexpr uint32_t N_CREW = 32;
     bool ss_settle_pending = false;    // the last sharded frame's k_shard_settle work rides on the next k_prep (or runs stand-alone first)
     ShardSettle ss_settle{};
     int n_pix_blocks = 0;
@@ -443,6 +452,7 @@ FrameParams make_params(const sm_ctx *s, const float *pose)
     fp.use_bounds = c.disable_tile_bounds ? 0 : 1;
     fp.compact_now = 1;                     // the per-pass entry points compact at every cull
     fp.maintenance = 0;
+    fp.par = s->plane_set;
     return fp;
 }
 
@@ -483,7 +493,7 @@ int finalize_if_pending(sm_ctx *s)
     }
     if (!s->pend_finalize) return SM_OK;
     s->pend_finalize = false;
-    hipLaunchKernelGGL(k_frame_finalize, dim3(1), dim3(256), 0, s->stream, s->d_state, s->d_frame_sub,
+    hipLaunchKernelGGL(k_frame_finalize, dim3(1), dim3(256), 0, s->stream, s->d_state, s->nf_last ? s->nf_last : s->d_nf_sub,
                        s->d_fix_part + (size_t)s->fix_set * MAX_GRID, s->n_fix_part, s->d_log);
     HIPCK(hipGetLastError());
     return SM_OK;
@@ -565,6 +575,19 @@ int launch_prep(sm_ctx *s, const uint8_t *rgb, const uint16_t *raw, const uint8_
             if (carry) { tp.grp_cand = s->assoc_args.grp_cand; tp.n_grp = s->assoc_args.n_grp; tp.prev_time = s->assoc_args.fp.time; }
             s->n_prep_blocks = tp.nfb;
         }
+        // two-launch frame: the held-back association's frame has not had its fixup step yet -- its publisher and repair crew
+        // open this launch, the association and the flag workgroups check for themselves whether they have to wait for them
+        FixArgs fx;
+        memset(&fx, 0, sizeof fx);
+        uint32_t n_fix = 0;
+        s->assoc_args.slow_conf_sub = nullptr; s->assoc_args.slow_need = 0u;
+        if (carry && s->fix_pending) {
+            s->fix_pending = false;
+            fx = s->fix_args;
+            n_fix = 1u + fx.n_crew;
+            s->assoc_args.slow_conf_sub = fx.conf_sub; s->assoc_args.slow_need = n_fix;
+            if (tp.nfb) { tp.slow_conf_sub = fx.conf_sub; tp.slow_cap = s->assoc_args.fp.conflict_cap; tp.slow_need = n_fix; tp.slow_par = s->assoc_args.fp.par; }
+        }
         PrepArgs pa;
         pa.rgb = rgb; pa.depth_raw = raw; pa.sem = sem; pa.depth_f32 = dm; pa.depthT = s->d_depthT; pa.rgbsT = s->d_rgbsT;
         pa.keyT = clear_keys ? s->d_keyT : nullptr; pa.dcT = s->d_dcT;
@@ -574,10 +597,10 @@ int launch_prep(sm_ctx *s, const uint8_t *rgb, const uint16_t *raw, const uint8_
         memset(&ca, 0, sizeof ca);
         uint32_t n_img = (uint32_t)tiles;
         if (chain) { ca = *chain; n_img = (uint32_t)(((s->W + CH_TX - 1) / CH_TX) * ((s->H + CH_TY - 1) / CH_TY)); }
-        if (s->d_ap_trace) { s->ap_trace_n[0] = (int)n_assoc; s->ap_trace_n[1] = (int)tp.nfb; s->ap_trace_n[2] = (int)n_img; }    // (chain: dispatched image | association | flags)
-        const dim3 grid(tp.nfb + n_assoc + n_img);
-        if (chain) hipLaunchKernelGGL((k_assoc_prep<true>), grid, dim3(PIX_BLOCK), 0, s->stream, s->assoc_args, pa, fp, tp, n_assoc, n_img, ca, s->d_ap_trace);
-        else hipLaunchKernelGGL((k_assoc_prep<false>), grid, dim3(PIX_BLOCK), 0, s->stream, s->assoc_args, pa, fp, tp, n_assoc, n_img, ca, s->d_ap_trace);
+        if (s->d_ap_trace) { s->ap_trace_n[0] = (int)n_assoc; s->ap_trace_n[1] = (int)tp.nfb; s->ap_trace_n[2] = (int)n_img; s->ap_trace_n[3] = (int)n_fix; }    // (chain: dispatched image | association | flags; the fixup workgroups before them)
+        const dim3 grid(n_fix + tp.nfb + n_assoc + n_img);
+        if (chain) hipLaunchKernelGGL((k_assoc_prep<true>), grid, dim3(PIX_BLOCK), 0, s->stream, s->assoc_args, pa, fp, tp, n_assoc, n_img, ca, fx, n_fix, s->d_ap_trace);
+        else hipLaunchKernelGGL((k_assoc_prep<false>), grid, dim3(PIX_BLOCK), 0, s->stream, s->assoc_args, pa, fp, tp, n_assoc, n_img, ca, fx, n_fix, s->d_ap_trace);
         HIPCK(hipGetLastError());
         return SM_OK;
     }
@@ -643,6 +666,9 @@ int launch_conflict(sm_ctx *s, const FrameParams &fp, bool timed = false)
 int launch_surfel_pass(sm_ctx *s, const FrameParams &fp, bool timed, bool direct)
 {
     if (s->n_prep_blocks == 0) { g_err = "internal: one-pass frame without tile flags from the preparation launch"; return SM_E_ARG; }
+    // two-launch frame: the association will be held back, and the fixup step with it (launch_prep carries both); the candidate
+    // pixels are counted by extra workgroups of the pass's own launch
+    const bool two = s->two_launch && s->defer_ok && timed && direct;
     // Grid: up to 2 048 workgroups while the model is small (most tiles are skipped by their flags; a wide grid spreads the few
     // hundred tiles with work), but no more than are RESIDENT once every workgroup has many tiles with work (>= 4 per
     // workgroup: beyond ~8 M slots) -- the surplus would start when the first ones finish and run a second, thin wave
@@ -650,7 +676,8 @@ int launch_surfel_pass(sm_ctx *s, const FrameParams &fp, bool timed, bool direct
     const uint64_t tiles_b = ((uint64_t)s->count_bound + TILE - 1) / TILE;
     const int grid = tiles_b > (uint64_t)4 * MAX_GRID ? std::min(grid_surfels(s), s->pass_grid) : grid_surfels(s);
     // fixup workers: the cap repair strides over the tiles; with direct append they first count the frame's candidate pixels, one group each
-    const int fgrid = direct ? std::max(std::min(grid, s->fix_grid), (int)std::min<uint32_t>(s->n_grp, MAX_GRID)) : std::min(grid, s->fix_grid);
+    const int fgrid = two ? (int)sm_ctx::N_CREW
+                    : direct ? std::max(std::min(grid, s->fix_grid), (int)std::min<uint32_t>(s->n_grp, MAX_GRID)) : std::min(grid, s->fix_grid);
     const uint32_t n_fix_prev = s->n_fix_part;
     const uint2 *fix_prev = s->d_fix_part + (size_t)s->fix_set * MAX_GRID;
     s->fix_set ^= 1;
@@ -663,25 +690,41 @@ int launch_surfel_pass(sm_ctx *s, const FrameParams &fp, bool timed, bool direct
     uint32_t *sub = s->d_conf_sub + SUB_SET * s->conf_sub_set;
     const uint32_t tile_bound = (uint32_t)std::max<uint64_t>(((uint64_t)s->count_bound + TILE - 1) / TILE, 1);
     if (s->d_pass_trace) s->pass_trace_grid = grid;
-    hipLaunchKernelGGL(k_surfel_pass, dim3(grid), dim3(256), 0, s->stream, s->M, s->d_state, fp, s->d_dcT, s->d_cm, s->d_dm /* km */,
+    CandArgs ca;
+    memset(&ca, 0, sizeof ca);
+    ca.n_pass = (uint32_t)grid;
+    if (two) {
+        ca.n_grp = s->n_grp; ca.cg = s->cand_group; ca.n_pix_blocks = s->n_pix_blocks;
+        ca.depthT = s->d_depthT; ca.xs = s->d_xs; ca.ys = s->d_ys; ca.blk_cand = s->d_blk_cand; ca.grp_cand = s->d_grp_cand;
+    }
+    hipLaunchKernelGGL(k_surfel_pass, dim3(grid + (two ? (int)s->n_grp : 0)), dim3(256), 0, s->stream, s->M, s->d_state, fp, s->d_dcT, s->d_cm, s->d_dm /* km */,
                        s->d_wave_cnt, s->d_tb, s->d_tile_flags, s->d_lazy_part, s->d_alive, s->d_tile_dead, sub, s->d_keyT, s->d_undo, tile_bound,
-                       s->d_frame_sub, s->d_pass_trace);
+                       s->d_frame_sub, ca, s->d_pass_trace);
     HIPCK(hipGetLastError());
     if (mark(s, 2, timed) || mark(s, 3, timed)) return SM_E_HIP;
-    DirectArgs da;
-    memset(&da, 0, sizeof da);
-    da.on = direct ? 1 : 0;
+    FixArgs x;
+    memset(&x, 0, sizeof x);
+    DirectArgs &da = x.da;
+    da.on = direct ? (two ? 2 : 1) : 0;
     da.blk_cand = s->d_blk_cand; da.grp_cand = s->d_grp_cand; da.n_grp = s->n_grp; da.cg = s->cand_group; da.n_pix_blocks = s->n_pix_blocks;
     da.depthT = s->d_depthT; da.xs = s->d_xs; da.ys = s->d_ys;
     da.frame_sub = s->d_frame_sub;
+    // the previous frame's new / fused counters: the other set where the sets alternate (its association may run next to this publisher)
+    da.nf_prev = s->defer_ok ? s->d_nf_sub_nx : s->d_nf_sub;
     // (the previous frame's fixup partials: only if it appended directly and nothing has completed its statistics since)
     da.fix_prev = fix_prev; da.n_fix_prev = s->pend_finalize ? n_fix_prev : 0u;
     da.log = s->d_log;
     s->pend_finalize = false;            // the fixup's publisher completes the previous frame's statistics first
-    hipLaunchKernelGGL(k_pass_fixup, dim3(fgrid + 1), dim3(256), 0, s->stream, s->M, s->d_state, fp, s->d_cm, s->d_dm /* km */, s->d_wave_cnt,
-                       s->d_tile_flags, s->d_lazy_part, (uint32_t)grid, fix_cur, s->d_alive, s->d_tile_dead, sub, s->d_keyT, s->d_undo,
-                       s->d_stat, s->d_prep_part, s->n_prep_blocks, da, s->d_tb);
-    HIPCK(hipGetLastError());
+    x.cm = s->d_cm; x.km = s->d_dm; x.wave_cnt = s->d_wave_cnt; x.tile_flags = s->d_tile_flags; x.part = s->d_lazy_part; x.n_part = (uint32_t)grid;
+    x.fix_part = fix_cur; x.alive = s->d_alive; x.tile_dead = s->d_tile_dead; x.conf_sub = sub; x.keyT = s->d_keyT; x.undo = s->d_undo;
+    x.host_stat = s->d_stat; x.prep_part = s->d_prep_part; x.n_prep = s->n_prep_blocks; x.tb = s->d_tb; x.n_crew = (uint32_t)fgrid;
+    if (two) {
+        s->fix_args = x;
+        s->fix_pending = true;
+    } else {
+        hipLaunchKernelGGL(k_pass_fixup, dim3(fgrid + 1), dim3(256), 0, s->stream, s->M, s->d_state, fp, x);
+        HIPCK(hipGetLastError());
+    }
     if (mark(s, 4, timed)) return SM_E_HIP;
     check_alive(s, 1u + 16u * (uint32_t)(s->tick & 0xFFFF));
     return SM_OK;
@@ -691,8 +734,9 @@ void fill_assoc_args(const sm_ctx *s, const FrameParams &fp, AssocArgs &a)
 {
     a.M = s->M; a.st = s->d_state; a.fp = fp;
     a.depthT = s->d_depthT; a.rgbsT = s->d_rgbsT; a.keyT = s->d_keyT; a.xs = s->d_xs; a.ys = s->d_ys;
-    a.blk_cand = s->d_blk_cand; a.grp_cand = s->d_grp_cand; a.frame_sub = s->d_frame_sub; a.tb = s->d_tb;
+    a.blk_cand = s->d_blk_cand; a.grp_cand = s->d_grp_cand; a.nf = s->d_nf_sub; a.tb = s->d_tb;
     a.alive = s->d_alive; a.tile_dead = s->d_tile_dead; a.n_grp = s->n_grp; a.cg = s->cand_group; a.host_stat = s->d_stat;
+    a.slow_conf_sub = nullptr; a.slow_need = 0u;
 }
 
 // association + in-place fuse + direct append (the frame's last kernel; its statistics are completed later)
@@ -703,6 +747,7 @@ int launch_associate_direct(sm_ctx *s, const FrameParams &fp, bool timed)
     AssocArgs a;
     fill_assoc_args(s, fp, a);
     if (s->ev_ok && timed) s->ev_deferred[s->ev_frames % EV_RING] = s->defer_ok;
+    s->nf_last = s->d_nf_sub;
     if (s->defer_ok && timed) {
         // asynchronous plain stream: hold the association back; the next frame's k_prep launch carries it (k_assoc_prep),
         // anything else that needs its results launches it first (flush_assoc, reached through finalize_if_pending)
@@ -725,6 +770,12 @@ int flush_assoc(sm_ctx *s)
 {
     if (!s->assoc_pending) return SM_OK;
     s->assoc_pending = false;
+    if (s->fix_pending) {                 // two-launch frame: that frame's fixup step has not run either -- in a launch of its own, first
+        s->fix_pending = false;
+        hipLaunchKernelGGL(k_pass_fixup, dim3(s->fix_args.n_crew + 1), dim3(256), 0, s->stream, s->M, s->d_state, s->assoc_args.fp, s->fix_args);
+        HIPCK(hipGetLastError());
+    }
+    s->assoc_args.slow_conf_sub = nullptr; s->assoc_args.slow_need = 0u;
     ShardArgs sh;
     memset(&sh, 0, sizeof sh);
     hipLaunchKernelGGL((k_associate_direct<false>), dim3(assoc_wgs(s)), dim3(PIX_BLOCK), 0, s->stream, s->assoc_args, sh);
@@ -950,10 +1001,15 @@ int begin_frame(sm_ctx *s, const uint8_t *d_rgb, const uint16_t *d_raw, const ui
     // sets, so that the pre-processing of frame f+1 never touches what frame f still reads
     s->plane_set ^= 1;
     s->conf_sub_set = s->plane_set;
+    fp.par = s->plane_set;
     if (s->defer_ok) {
         std::swap(s->d_depthT, s->d_depthT_nx); std::swap(s->d_rgbsT, s->d_rgbsT_nx);
         std::swap(s->d_dcT, s->d_dcT_nx);
         if (will_splat) std::swap(s->d_keyT, s->d_keyT_nx);
+        // per-frame scratch the previous frame's publisher / repair crew may still read while this frame's flag workgroups and
+        // association write theirs (two-launch frame)
+        std::swap(s->d_tile_flags, s->d_tile_flags_nx); std::swap(s->d_wave_cnt, s->d_wave_cnt_nx);
+        std::swap(s->d_prep_part, s->d_prep_part_nx); std::swap(s->d_nf_sub, s->d_nf_sub_nx);
     }
     // metriciseDepth + filterDepth + removeMovings (src/SurfelMapping.cpp:136-139,156,254-365): with preprocess = 1 the whole
     // chain is one stage of the preparation launch (prep_chain_block); the reference frame stops before removeMovings
@@ -1025,7 +1081,9 @@ int enqueue_frame(sm_ctx *s, const uint8_t *d_rgb, const uint16_t *d_raw, const 
     s->want_list = fusing && !compact_now;
     // a held-back association rides on this frame's k_prep launch if this is again a fusing frame; anything else (the frame
     // after reset, ...) needs its results first
-    s->merge_assoc = s->assoc_pending && fusing && s->defer_ok;       // (a compacting frame too: its k_prep launch has no tile flags to make)
+    // (a compacting frame too: its k_prep launch has no tile flags to make -- unless the fixup step is pending as well: the doubled
+    //  words of DevState it leaves set are cleared by the NEXT pass's launch, which a compacting frame does not have)
+    s->merge_assoc = s->assoc_pending && fusing && s->defer_ok && !(s->fix_pending && compact_now);
     int rc = SM_OK;
     if (s->assoc_pending && !s->merge_assoc && (rc = flush_assoc(s))) return rc;
     rc = begin_frame(s, d_rgb, d_raw, d_sem, pose, &fp);
@@ -1192,7 +1250,15 @@ sm_ctx *sm_create(const sm_config *c)
     if (const char *e = std::getenv("SM_CAND_GROUP")) { const int v = std::atoi(e); if (v == 4 || v == 8 || v == 16) s->cand_group = (uint32_t)v; }
     s->n_grp = (uint32_t)((s->n_pix_blocks + s->cand_group - 1) / s->cand_group);
     ok = ok && dalloc(&s->d_blk_cand, (size_t)s->n_grp * CAND_GROUP_MAX) == SM_OK && dalloc(&s->d_grp_cand, (size_t)s->n_grp) == SM_OK &&
-         dalloc(&s->d_frame_sub, (size_t)4 * SUB_SET) == SM_OK && hipMemset(s->d_frame_sub, 0, (size_t)4 * SUB_SET * 4) == hipSuccess;
+         dalloc(&s->d_frame_sub, (size_t)6 * SUB_SET) == SM_OK && hipMemset(s->d_frame_sub, 0, (size_t)6 * SUB_SET * 4) == hipSuccess;
+    s->d_nf_sub = s->d_frame_sub + 2 * SUB_SET; s->d_nf_sub_nx = s->d_frame_sub + 4 * SUB_SET;
+    if (s->defer_ok)
+        ok = ok && dalloc(&s->d_tile_flags_nx, (size_t)s->tb_tiles) == SM_OK && hipMemset(s->d_tile_flags_nx, 0, s->tb_tiles) == hipSuccess &&
+             dalloc(&s->d_wave_cnt_nx, ntiles) == SM_OK && dalloc(&s->d_prep_part_nx, (size_t)256) == SM_OK;
+    {
+        const char *e = std::getenv("SM_TWO_LAUNCH");                     // "0": the fixup step keeps its own launch (three launches per frame)
+        s->two_launch = s->defer_ok && !(e && e[0] == '0');
+    }
     if (!ok) { if (g_err.empty()) g_err = "sm_create: allocation failed"; sm_destroy(s); return nullptr; }
 
     // pixel-centre coordinates exactly as data.vert sees them:
@@ -1339,6 +1405,7 @@ void sm_destroy(sm_ctx *s)
     (void)hipFree(s->d_rgb); (void)hipFree(s->d_sem); (void)hipFree(s->d_depth_raw); (void)hipFree(s->d_depth_f32);
     (void)hipFree(s->d_xs); (void)hipFree(s->d_ys);
     (void)hipFree(s->d_cm); (void)hipFree(s->d_dm); (void)hipFree(s->d_zm); (void)hipFree(s->d_alive); (void)hipFree(s->d_tile_dead);
+    (void)hipFree(s->d_tile_flags_nx); (void)hipFree(s->d_wave_cnt_nx); (void)hipFree(s->d_prep_part_nx);
     (void)hipFree(s->d_tile_cnt); (void)hipFree(s->d_tile_allow); (void)hipFree(s->d_tile_keep); (void)hipFree(s->d_tile_flag); (void)hipFree(s->d_group_tot); (void)hipFree(s->d_group_base); (void)hipFree(s->d_tb); (void)hipFree(s->d_tile_flags); (void)hipFree(s->d_conf_part); (void)hipFree(s->d_compact_part); (void)hipFree(s->d_lazy_part); (void)hipFree(s->d_conf_sub); (void)hipFree(s->d_fix_part); (void)hipFree(s->d_blk_cand); (void)hipFree(s->d_grp_cand); (void)hipFree(s->d_frame_sub); (void)hipFree(s->d_wave_cnt); (void)hipFree(s->d_undo); (void)hipFree(s->d_prep_part);
     (void)hipFree(s->d_validmask); (void)hipFree(s->d_fusedmask); (void)hipFree(s->d_blk_cnt);
     (void)hipFree(s->d_chk); (void)hipFree(s->d_galive); (void)hipFree(s->d_new_alive); (void)hipFree(s->d_gmask); (void)hipFree(s->d_ss_info); (void)hipFree(s->d_capx);
@@ -2337,7 +2404,7 @@ int sm_shard_frame_device(sm_ctx *s, const uint8_t *d_rgb, const uint16_t *d_dep
     // only needed by the next frame's surfel pass: it rides on that frame's k_prep (finalize_if_pending runs it earlier if asked)
     ShardSettle &ss = s->ss_settle;
     ss.n = (uint32_t)s->n_pix_blocks; ss.st = s->d_state; ss.validmask = s->d_validmask; ss.ownmask = s->d_fusedmask; ss.gmask = s->d_gmask;
-    ss.nwords = sh.nwords; ss.blk_cand = s->d_blk_cand; ss.grp_cand = s->d_grp_cand; ss.frame_sub = s->d_frame_sub; ss.alive = s->d_alive;
+    ss.nwords = sh.nwords; ss.blk_cand = s->d_blk_cand; ss.grp_cand = s->d_grp_cand; ss.nf = s->d_nf_sub; ss.alive = s->d_alive;
     ss.tile_dead = s->d_tile_dead; ss.owner = sh.owner; ss.cap_pixels = s->cfg.conflict_cap ? (uint32_t)s->P : 0xFFFFFFFFu; ss.max_vertices = s->cap; ss.cg = s->cand_group;
     s->ss_settle_pending = true;
     if ((rc = mark(s, 6, true)) || (rc = mark(s, 7, true))) return rc;

@@ -64,7 +64,8 @@ struct DevState {
     uint32_t compact_ticket;  // work queue of k_compact: next moving tile (relative to first_moving) to hand out
     uint32_t stat_frames;     // frames whose append has completed (tag of the host-visible slot statistic)
     uint32_t first_live;      // slot of the first live surfel = the reference's surfel id 0 (conflict.geom:15, data.vert:142)
-    uint32_t fl_dirty;        // k_surfel_pass saw that surfel die: k_pass_fixup looks for its successor
+    uint32_t fl_dirty2[2];    // k_surfel_pass saw that surfel die (word of the frame's parity, FrameParams::par): the publisher looks for its successor
+    uint32_t slow_done[2];    // two-launch frame, rare path (the conflict cap binds / "id 0" died): publisher + repair crew workgroups that are through (by frame parity)
     // ---- direct append (k_associate_direct): the frame's statistics are completed one kernel later
     uint32_t pend;            // 1: the last frame's new / fused counts, dead-slot total and log entry are still to be completed
                               //    (by the next frame's k_pass_fixup, or by k_frame_finalize before anything else reads them)
@@ -105,6 +106,7 @@ struct FrameParams {
     int compact_tickets;      // 1: k_compact hands its moving tiles out in order from a ticket counter (no co-residency needed)
     int no_exempt;            // 1: no surfel is exempt from the conflict test (a rig slice that does not hold the global surfel 0)
     int shard_slots;          // 1: slot-addressed sharding of one stream: ids are global slot numbers on every rank
+    int par;                  // frame parity (0 / 1): which of the doubled per-frame words of DevState this frame uses
 };
 
 __device__ __forceinline__ float min_glsl(float a, float b) { return (b < a) ? b : a; }
@@ -295,6 +297,26 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
     v += dpp_take<0x143, 0xC>(v);
     return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
+
+// ---- two-launch frame (sm_k_pass.h, "Two homes"): the rare path's test and wait
+// does the frame need its publisher / repair before anybody may use the pass's results?  (wave-uniform; one load per lane)
+__device__ __forceinline__ bool slow_frame(const DevState *__restrict__ st, const uint32_t *__restrict__ conf_sub, uint32_t cap, int par, int lane)
+{
+    const uint32_t ctotal = wave_sum_u32(conf_sub[lane * SUB_STRIDE]);
+    return ctotal > cap || st->fl_dirty2[par] != 0u;
+}
+
+// ... and the wait of that rare path: publisher + crew are the first workgroups of the launch (dispatched first, waiting for
+// nobody), so this terminates whatever is resident; bounded all the same (SM_E_STALL instead of a hang)
+__device__ __forceinline__ void wait_slow_frame(DevState *__restrict__ st, int par, uint32_t need)
+{
+    uint32_t spins = 0;
+    while (__hip_atomic_load(&st->slow_done[par], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < need) {
+        __builtin_amdgcn_s_sleep(8);
+        if (++spins > (1u << 22)) { st->error = -6; break; }
+    }
+}
+
 
 // expand the bounds of the tiles touched by this wave: each active lane contributes one surfel
 // (position, time, "bad") to tile `tile`; lanes are grouped by tile with ballots, reduced with

@@ -24,9 +24,30 @@ __device__ __forceinline__ float3 get_vertex(float z, float x, float y, const Fr
     return r;
 }
 
+// What the association of pixel q reads from the frame's planes and the key map, loaded by the caller ahead of a decision it
+// has to take first (two-launch frame: associate_direct_block)
+struct PixelLoads { float z, zl, zu, zr, zd; uint32_t c; uint64_t key; };
+
+__device__ __forceinline__ PixelLoads load_pixel(int q, int i, int j, const FrameParams &fp, const float *__restrict__ depthT,
+                                                 const uint32_t *__restrict__ rgbsT, const uint64_t *__restrict__ keyT)
+{
+    const int H = fp.H, W = fp.W;
+    PixelLoads r;
+    q = min(q, fp.P - 1);
+    r.key = keyT[q];
+    r.z = depthT[q];
+    r.zl = depthT[i > 0 ? q - H : q];
+    r.zu = depthT[j > 0 ? q - 1 : q];
+    r.zr = depthT[i < W - 1 && q + H < fp.P ? q + H : q];
+    r.zd = depthT[j < H - 1 && q + 1 < fp.P ? q + 1 : q];
+    r.c = rgbsT[q];
+    return r;
+}
+
 __device__ __forceinline__ bool local_surfel(int q, const FrameParams &fp, const float *__restrict__ depthT,
                                              const uint32_t *__restrict__ rgbsT, const float *__restrict__ xs,
-                                             const float *__restrict__ ys, LocalSurfel &L, int qi = -1, int qj = 0)
+                                             const float *__restrict__ ys, LocalSurfel &L, int qi = -1, int qj = 0,
+                                             const PixelLoads *pre = nullptr)
 {
     const int H = fp.H, W = fp.W;
     const int i = qi >= 0 ? qi : q / H, j = qi >= 0 ? qj : q - i * H;     // (qi, qj): the caller knows the column / row of q already
@@ -34,12 +55,12 @@ __device__ __forceinline__ bool local_surfel(int q, const FrameParams &fp, const
     // follow the association tables in the same arrays at offsets W and H
     const float x = fp.init_mode ? xs[W + i] : xs[i], y = fp.init_mode ? ys[H + j] : ys[j];
     const float inv_fx = fp.init_mode ? fp.inv_fx_fb : fp.inv_fx, inv_fy = fp.init_mode ? fp.inv_fy_fb : fp.inv_fy;
-    const float z = depthT[q];
+    const float z = pre ? pre->z : depthT[q];
     // clamp-to-edge neighbours: at the border the neighbour depth is the pixel's own (A1)
-    const float zl = depthT[i > 0 ? q - H : q];
-    const float zu = depthT[j > 0 ? q - 1 : q];
-    const float zr = depthT[i < W - 1 ? q + H : q];
-    const float zd = depthT[j < H - 1 ? q + 1 : q];
+    const float zl = pre ? pre->zl : depthT[i > 0 ? q - H : q];
+    const float zu = pre ? pre->zu : depthT[j > 0 ? q - 1 : q];
+    const float zr = pre ? pre->zr : depthT[i < W - 1 ? q + H : q];
+    const float zd = pre ? pre->zd : depthT[j < H - 1 ? q + 1 : q];
     if (fp.init_mode) {
         // surfel_feedback.vert:80-92: 0 < z < maxDepth and the checkerboard; no neighbour test
         if (!(z > 0.0f && z < fp.max_depth)) return false;
@@ -61,7 +82,7 @@ __device__ __forceinline__ bool local_surfel(int q, const FrameParams &fp, const
     const float3 del_x = make_float3(xb.x - xf.x, xb.y - xf.y, xb.z - xf.z);
     const float3 del_y = make_float3(yb.x - yf.x, yb.y - yf.y, yb.z - yf.z);
     L.nrm = normalize3(cross3(del_x, del_y));
-    const uint32_t c = rgbsT[q];
+    const uint32_t c = pre ? pre->c : rgbsT[q];
     L.cr = (float)((c >> 16) & 0xFFu) / 255.0f;     // GL_RGB32F upload of u8 (A1)
     L.cg = (float)((c >> 8) & 0xFFu) / 255.0f;
     L.cb = (float)(c & 0xFFu) / 255.0f;
@@ -154,15 +175,16 @@ __device__ __forceinline__ void associate_pixel(int q, const SurfelSet &cur, con
                                                 bool &is_fused, uint32_t *__restrict__ tb, uint32_t first_live,
                                                 const uint64_t *__restrict__ own_alive = nullptr /* slot-addressed sharding: this rank's alive bits */,
                                                 FuseMove *mv = nullptr /* given: the caller grows the tile boxes (fuse_bounds_block) */,
-                                                int qi = -1, int qj = 0 /* column / row of q, if the caller has them */)
+                                                int qi = -1, int qj = 0 /* column / row of q, if the caller has them */,
+                                                const PixelLoads *pre = nullptr /* the pixel's plane / key-map words, if the caller loaded them */)
 {
     is_valid = false;
     is_fused = false;
     uint32_t f_id = 0;                        // the surfel this lane fused into, and where it moved
     float f_x = 0.f, f_y = 0.f, f_z = 0.f;
     // (the key does not depend on the pixel's own surfel: its load is issued with the stencil's, not after the arithmetic)
-    const uint64_t key_q = fp.init_mode ? KEY_EMPTY : keyT[min(q, fp.P - 1)];
-    if (q < fp.P && local_surfel(q, fp, depthT, rgbsT, xs, ys, L, qi, qj)) {
+    const uint64_t key_q = fp.init_mode ? KEY_EMPTY : pre ? pre->key : keyT[min(q, fp.P - 1)];
+    if (q < fp.P && local_surfel(q, fp, depthT, rgbsT, xs, ys, L, qi, qj, pre)) {
         is_valid = true;
         const uint64_t key = key_q;
         const int32_t gid = (int32_t)(uint32_t)(key & 0xFFFFFFFFull);
@@ -317,8 +339,12 @@ struct AssocArgs {
     Model M; DevState *st; FrameParams fp;
     const float *depthT; const uint32_t *rgbsT; const uint64_t *keyT; const float *xs, *ys;
     const uint32_t *blk_cand /* candidate pixels per block ... */, *grp_cand /* ... and per group of CAND_GROUP blocks */;
-    uint32_t *frame_sub /* sets 2, 3: new, fused -- 64 sub-counters each */, *tb;
+    uint32_t *nf /* new, fused: 64 sub-counters each */, *tb;
     uint64_t *alive; uint32_t *tile_dead; uint32_t n_grp, cg; unsigned long long *host_stat;
+    // two-launch frame: the frame's publisher / repair crew run in the SAME launch (fixup_merged_block); on the rare frames where
+    // they change anything the association waits for them first
+    const uint32_t *slow_conf_sub;   // the frame's conflict sub-counters, or null: the fixup ran in a launch of its own
+    uint32_t slow_need;              // workgroups to wait for (publisher + crew)
 };
 
 // bit i of x -> bit 2 i (Morton spread)
@@ -367,13 +393,17 @@ __device__ __forceinline__ void associate_direct_block(const AssocArgs &a, const
     const float *__restrict__ depthT = a.depthT; const uint32_t *__restrict__ rgbsT = a.rgbsT; const uint64_t *__restrict__ keyT = a.keyT;
     const float *__restrict__ xs = a.xs, *__restrict__ ys = a.ys;
     const uint32_t *__restrict__ blk_cand = a.blk_cand, *__restrict__ grp_cand = a.grp_cand;
-    uint32_t *__restrict__ frame_sub = a.frame_sub, *__restrict__ tb = a.tb;
+    uint32_t *__restrict__ nf_sub = a.nf, *__restrict__ tb = a.tb;
     uint64_t *__restrict__ alive = a.alive; uint32_t *__restrict__ tile_dead = a.tile_dead;
     const uint32_t n_grp = a.n_grp; unsigned long long *__restrict__ host_stat = a.host_stat;
     __shared__ uint32_t s_v[4], s_n[4], s_f[4];
     __shared__ uint32_t s_hole[12], s_dead[2];          // empty slots of this block: 6 alive words (lo, hi), 2 tiles
     __shared__ uint32_t s_tag[FB_SLOTS], s_box[FB_SLOTS * 8];
+    __shared__ uint32_t s_slow;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // two-launch frame: the frame's conflict total, for the one decision below (wave 0 only; first load of the workgroup)
+    uint32_t gate_cs = 0, gate_dirty = 0;
+    if (!SHARD && a.slow_conf_sub && wave == 0) { gate_cs = a.slow_conf_sub[lane * SUB_STRIDE]; gate_dirty = st->fl_dirty2[fp.par]; }
     if (threadIdx.x < 12) s_hole[threadIdx.x] = 0u;
     if (threadIdx.x < 2) s_dead[threadIdx.x] = 0u;
     // candidates before this block = the groups before its group + the blocks of its group before it: a few loads per lane,
@@ -389,8 +419,28 @@ __device__ __forceinline__ void associate_direct_block(const AssocArgs &a, const
     bool is_valid, is_fused;
     LocalSurfel L;
     FuseMove mv;
-    associate_pixel(q, cur, fp, depthT, rgbsT, keyT, xs, ys, L, is_valid, is_fused, tb, st->first_live,
-                    SHARD ? alive : nullptr, &mv, qi, qj);
+    // The pixel's loads go out with the ones above, BEFORE the one decision of the two-launch frame: did the pass leave work for
+    // the publisher / the repair crew of this very launch (the conflict cap binds, "id 0" died)?  One more load per lane and a
+    // wave reduction; on such a frame the wave waits for them and takes the words they may have changed again.
+    PixelLoads pl = load_pixel(q, qi, qj, fp, depthT, rgbsT, keyT);
+    uint32_t first_live = st->first_live;
+    if (!SHARD && a.slow_conf_sub) {                    // workgroup-uniform
+        // Wave 0 takes the decision for the workgroup (its sub-counter load went out first, see the top); the others meet it at a
+        // bare s_barrier -- no fence, so that nobody's loads above have to land first -- and read the verdict from LDS.  (Every
+        // wave reading the 64 sub-counter lines for itself cost the launch 1 us at 1242x375 and 5 us at 1920x1080.)
+        if (wave == 0) {
+            const bool slow = (wave_sum_u32(gate_cs) > fp.conflict_cap) | (gate_dirty != 0u);
+            if (lane == 0) s_slow = slow ? 1u : 0u;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (s_slow) {
+            wait_slow_frame(st, fp.par, a.slow_need);
+            pl.key = __hip_atomic_load(&keyT[min(q, fp.P - 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            first_live = __hip_atomic_load(&st->first_live, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    associate_pixel(q, cur, fp, depthT, rgbsT, keyT, xs, ys, L, is_valid, is_fused, tb, first_live,
+                    SHARD ? alive : nullptr, &mv, qi, qj, &pl);
     const uint64_t vw = __ballot(is_valid), fw = __ballot(is_fused);
     if (lane == 0) { s_v[wave] = (uint32_t)__popcll(vw); s_n[wave] = (uint32_t)__popcll(vw & ~fw); s_f[wave] = (uint32_t)__popcll(fw); }
     if (SHARD) {
@@ -432,8 +482,8 @@ __device__ __forceinline__ void associate_direct_block(const AssocArgs &a, const
     }
     if (!SHARD && threadIdx.x == 0) {                    // (sharded: k_shard_settle counts, from the masks of all ranks)
         const uint32_t nn = s_n[0] + s_n[1] + s_n[2] + s_n[3], nf = s_f[0] + s_f[1] + s_f[2] + s_f[3];
-        if (nn) atomicAdd(&frame_sub[2 * SUB_SET + (wg & 63u) * SUB_STRIDE], nn);
-        if (nf) atomicAdd(&frame_sub[3 * SUB_SET + (wg & 63u) * SUB_STRIDE], nf);
+        if (nn) atomicAdd(&nf_sub[(wg & 63u) * SUB_STRIDE], nn);
+        if (nf) atomicAdd(&nf_sub[SUB_SET + (wg & 63u) * SUB_STRIDE], nf);
     }
     fuse_bounds_block(tb, is_fused, mv, s_f[0] + s_f[1] + s_f[2] + s_f[3], s_tag, s_box);
     uint32_t rank = (uint32_t)__popcll(vw & ((1ull << lane) - 1ull));
@@ -486,36 +536,41 @@ __global__ __launch_bounds__(PIX_BLOCK) void k_associate_direct(AssocArgs a, Sha
 // ---------------------------------------------------------------------------------------------
 template <bool CHAIN>
 __global__ __launch_bounds__(PIX_BLOCK) void k_assoc_prep(AssocArgs a, PrepArgs p, FrameParams fp_new, TilePrep tp, uint32_t n_assoc,
-                                                          uint32_t n_img, ChainArgs ch, unsigned long long *__restrict__ trace = nullptr /* SM_PASS_TRACE */)
+                                                          uint32_t n_img, ChainArgs ch, FixArgs fx, uint32_t n_fix /* 0, or 1 + fx.n_crew */,
+                                                          unsigned long long *__restrict__ trace = nullptr /* SM_PASS_TRACE */)
 {
     struct Stamp {              // entry / exit time of every workgroup (thread 0), for tools/pass_trace.py
         unsigned long long *t; unsigned long long t0;
         __device__ Stamp(unsigned long long *tr) : t(tr), t0(tr ? wall_clock64() : 0ull) {}
         __device__ ~Stamp() { if (t && threadIdx.x == 0 && blockIdx.x < 65536u) { t[(size_t)blockIdx.x * 2] = t0; t[(size_t)blockIdx.x * 2 + 1] = wall_clock64(); } }   // (the buffer holds 65 536 records)
     } stamp(trace);
+    // Two-launch frame: the publisher and the repair crew of the frame whose association this launch carries come FIRST in
+    // dispatch order -- on the rare frames where the others wait for them they are in the chip whatever else is resident.
+    if (blockIdx.x < n_fix) { fixup_merged_block(a.M, a.st, a.fp, fx, blockIdx.x); return; }      // workgroup-uniform
+    const uint32_t bx = blockIdx.x - n_fix;
     // Dispatch order.  Without the chain: the association first -- all ~1 500 workgroups are in the chip within 0.3 us and their
     // loads are one burst served roughly in dispatch order; the association is the part with two or three DEPENDENT round trips,
     // the image tiles have one.  With the chain (CHAIN): the chain tiles first -- they are the long workgroups of the launch (169
     // taps per pixel), the association fills the chip around them.
     __shared__ __align__(16) unsigned char s_chain[CHAIN ? CHAIN_LDS_BYTES : 16];
     if (CHAIN) {
-        if (blockIdx.x < n_img) { prep_chain_block(p, ch, fp_new, blockIdx.x, s_chain); return; }      // workgroup-uniform
-        const uint32_t b = blockIdx.x - n_img;
-        if (b >= n_assoc) { tile_prep_block(fp_new, tp, n_img + n_assoc); return; }
+        if (bx < n_img) { prep_chain_block(p, ch, fp_new, bx, s_chain); return; }      // workgroup-uniform
+        const uint32_t b = bx - n_img;
+        if (b >= n_assoc) { tile_prep_block(fp_new, tp, n_fix + n_img + n_assoc); return; }
         ShardArgs none;
         none.validmask = nullptr; none.ownmask = nullptr; none.gmask = nullptr; none.nwords = 0u; none.owner = 1;
         associate_direct_block<false>(a, none, b);
         return;
     }
-    if (blockIdx.x >= n_assoc) {                                                                  // workgroup-uniform
-        const uint32_t b = blockIdx.x - n_assoc;
-        if (b < tp.nfb) { tile_prep_block(fp_new, tp, n_assoc); return; }
+    if (bx >= n_assoc) {                                                                  // workgroup-uniform
+        const uint32_t b = bx - n_assoc;
+        if (b < tp.nfb) { tile_prep_block(fp_new, tp, n_fix + n_assoc); return; }
         prep_image_block<PIX_BLOCK>(p, fp_new, b - tp.nfb);
         return;
     }
     ShardArgs none;
     none.validmask = nullptr; none.ownmask = nullptr; none.gmask = nullptr; none.nwords = 0u; none.owner = 1;
-    associate_direct_block<false>(a, none, blockIdx.x);
+    associate_direct_block<false>(a, none, bx);
 }
 
 // p11 concatenate (unstable.vert:13-34 + glCopyBufferSubData src/GlobalModel.cpp:627) on the frames that compact, after k_associate:

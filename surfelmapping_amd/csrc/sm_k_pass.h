@@ -72,6 +72,47 @@ __device__ __forceinline__ void cand_count_block(uint32_t cg, const FrameParams 
     }
 }
 
+// The same counts from inside k_surfel_pass's launch (two-launch frame): a few extra workgroups behind the ones
+// that own tiles -- they start as soon as the first of those leave the chip.  Four blocks per round whatever the group size, so
+// that the pass's register allocation is not touched (cand_count_block<16> holds 80 loads in flight: 149 VGPRs).
+struct CandArgs {
+    uint32_t n_pass;                     // workgroups of the launch that own tiles; the ones behind them count candidates (0 groups: none)
+    uint32_t n_grp, cg;                  // candidate groups; association blocks per group (4, 8 or 16)
+    int n_pix_blocks;
+    const float *depthT, *xs, *ys;
+    uint32_t *blk_cand, *grp_cand;
+};
+
+__device__ __forceinline__ void cand_count_group_lean(uint32_t g, const CandArgs &ca, const FrameParams &fp, uint32_t *s_w /* 16 words of LDS */)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t gsum = 0;
+#pragma unroll 1
+    for (uint32_t r = 0; r < ca.cg; r += 4u) {                           // workgroup-uniform
+        bool c[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int q = (int)((g * ca.cg + r + (uint32_t)k) * (uint32_t)PIX_BLOCK + threadIdx.x);
+            c[k] = candidate_pixel(min(q, fp.P - 1), fp, ca.depthT, ca.xs, ca.ys) & (q < fp.P);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint64_t m = __ballot(c[k]);
+            if (lane == 0) s_w[k * 4 + wave] = (uint32_t)__popcll(m);
+        }
+        __syncthreads();
+        if (wave == 0) {
+            uint32_t v = 0;
+            const int b = (int)(g * ca.cg + r) + lane;
+            if (lane < 4) v = s_w[lane * 4] + s_w[lane * 4 + 1] + s_w[lane * 4 + 2] + s_w[lane * 4 + 3];
+            if (lane < 4 && b < ca.n_pix_blocks) ca.blk_cand[b] = v;
+            gsum += wave_sum_u32(v);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) ca.grp_cand[g] = gsum;
+}
+
 struct PassAcc { uint32_t vis, killed, nconf; };
 
 // ---------------------------------------------------------------------------------------------
@@ -177,7 +218,7 @@ __device__ __forceinline__ void pass_flush(const SurfelSet &set, DevState *__res
             if (conf[r] && dies && !dead) atomicOr(&L.km[bi[r]][wi], bit);
             if (has[r] && !kp[r]) {
                 atomicOr(&L.gone[bi[r]][wi], bit);
-                if (k[r] == exempt) st->fl_dirty = 1u;               // "id 0" died: the fixup searches its successor
+                if (k[r] == exempt) st->fl_dirty2[fp.par] = 1u;      // "id 0" died: the publisher searches its successor
             }
         }
 #pragma unroll
@@ -332,8 +373,23 @@ __global__ __launch_bounds__(256) void k_surfel_pass(Model M, DevState *__restri
                                                      float *__restrict__ undo,
                                                      uint32_t tile_bound /* host upper bound of the number of tiles (>= 1) */,
                                                      uint32_t *__restrict__ frame_sub /* sets 0, 1: visible, killed -- sub-counters like conf_sub */,
+                                                     CandArgs ca /* two-launch frame: the workgroups from ca.n_pass on count the frame's candidate pixels */,
                                                      unsigned long long *__restrict__ trace = nullptr /* SM_PASS_TRACE: 8 words per workgroup */)
 {
+    if (blockIdx.x >= ca.n_pass) {                      // workgroup-uniform
+        __shared__ uint32_t s_cw[16];
+        const uint32_t g = blockIdx.x - ca.n_pass;
+        if (g == 0u && threadIdx.x == 0u) {
+            // nothing of this launch moves the slot count: the association that follows appends from here.  (k_pass_fixup's
+            // publisher wrote this word; in the two-launch frame it runs NEXT to that association and leaves it alone.)  The
+            // doubled words of the other parity are the previous frame's: everybody who read them is through.
+            st->offset = st->count;
+            st->fl_dirty2[fp.par ^ 1] = 0u;
+            st->slow_done[fp.par ^ 1] = 0u;
+        }
+        cand_count_group_lean(g, ca, fp, s_cw);
+        return;
+    }
     // (stamps go straight to memory: kept in registers until the exit they cost the kernel 30 more spilled scalars)
     unsigned long long *const tr = trace ? trace + (size_t)blockIdx.x * 8 : nullptr;
     if (tr && threadIdx.x == 0) { tr[0] = wall_clock64(); tr[1] = 0ull; tr[2] = 0ull; tr[4] = ~0ull; tr[5] = 0ull; }
@@ -342,7 +398,7 @@ __global__ __launch_bounds__(256) void k_surfel_pass(Model M, DevState *__restri
     // newest tiles -- the surfels the camera is looking at, i.e. the tiles with all the work -- are the highest ones, so the
     // mapping is reversed: block 0 takes the highest tile of the grid, and a workgroup with several tiles starts with its
     // highest (the flags of its first 64 tiles sit one per lane whatever the order).
-    const uint32_t tile_grid = gridDim.x, bid = gridDim.x - 1u - blockIdx.x;
+    const uint32_t tile_grid = ca.n_pass, bid = ca.n_pass - 1u - blockIdx.x;
     __shared__ uint32_t s_a[4], s_b[4], s_c[4];
     __shared__ PassLds s_pass;
     const int lane = threadIdx.x & 63;
@@ -427,12 +483,13 @@ __device__ __forceinline__ uint64_t ineffective_conflicts(uint64_t c, uint32_t b
 
 // Arguments of the direct-append frame form (k_associate_direct), handed to k_pass_fixup's publisher
 struct DirectArgs {
-    int on;                              // 1: this frame appends directly (k_associate_direct follows; no k_append_scan)
+    int on;                              // 1: this frame appends directly (k_associate_direct follows; no k_append_scan); 2: ... and its candidate pixels were counted by the pass's launch
     uint32_t *blk_cand, *grp_cand;       // out: candidate pixels per association block / per group of CAND_GROUP blocks (this frame)
     uint32_t n_grp, cg;                  // groups; association blocks per group (4, 8 or 16)
     int n_pix_blocks;
     const float *depthT, *xs, *ys;
-    uint32_t *frame_sub;                 // 4 x 64 sub-counters: visible, killed (this frame's pass); new, fused (the PREVIOUS frame's association)
+    uint32_t *frame_sub;                 // 2 x 64 sub-counters: visible, killed (this frame's pass)
+    uint32_t *nf_prev;                   // 2 x 64 sub-counters: new, fused of the PREVIOUS frame's association (the sets alternate where that association runs next to this publisher)
     const uint2 *fix_prev;               // the previous frame's k_pass_fixup partials (read if its conflict cap bound)
     uint32_t n_fix_prev;
     FrameLog *log;
@@ -447,7 +504,7 @@ __device__ __forceinline__ void finalize_write(DevState *__restrict__ st, FrameL
 // Completes the statistics of a direct-append frame once its association has finished: new / fused totals from the
 // per-block counts, the fixup's corrections if the conflict cap bound, the dead-slot total (culled + fused candidates'
 // empty slots), the frame-log entry.  Executed by one 256-thread workgroup; no-op unless DevState::pend is set.
-__device__ __forceinline__ void finalize_frame(DevState *__restrict__ st, uint32_t *__restrict__ frame_sub,
+__device__ __forceinline__ void finalize_frame(DevState *__restrict__ st, uint32_t *__restrict__ nf /* that frame's new / fused sub-counter sets */,
                                                const uint2 *__restrict__ fix_prev, uint32_t n_fix_prev, FrameLog *__restrict__ log,
                                                uint32_t *s_red /* 16 words of LDS */)
 {
@@ -455,7 +512,7 @@ __device__ __forceinline__ void finalize_frame(DevState *__restrict__ st, uint32
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t un = 0, fu = 0, va = 0, rs = 0;
     if (wave == 0) {
-        uint32_t *a = frame_sub + 2 * SUB_SET + lane * SUB_STRIDE, *b = frame_sub + 3 * SUB_SET + lane * SUB_STRIDE;
+        uint32_t *a = nf + lane * SUB_STRIDE, *b = nf + SUB_SET + lane * SUB_STRIDE;
         un = *a; fu = *b; *a = 0u; *b = 0u;
     }
     if (st->cap_binds)
@@ -503,162 +560,188 @@ __device__ __forceinline__ void finalize_write(DevState *__restrict__ st, FrameL
     st->pend = 0u;
 }
 
-__global__ __launch_bounds__(256) void k_frame_finalize(DevState *__restrict__ st, uint32_t *__restrict__ frame_sub,
+__global__ __launch_bounds__(256) void k_frame_finalize(DevState *__restrict__ st, uint32_t *__restrict__ nf,
                                                         const uint2 *__restrict__ fix_prev, uint32_t n_fix_prev, FrameLog *__restrict__ log)
 {
     __shared__ uint32_t s_red[16];
-    finalize_frame(st, frame_sub, fix_prev, n_fix_prev, log, s_red);
+    finalize_frame(st, nf, fix_prev, n_fix_prev, log, s_red);
 }
 
 // ---------------------------------------------------------------------------------------------
-// After k_surfel_pass: workgroup 0 publishes DevState (as k_cull_lazy_frame's publisher does); the other workgroups
-// return at once unless the conflict cap binds (total > W*H: src/GlobalModel.cpp:54-57).  Then they take
-// back every conflict beyond the first `cap` in slot order: a surfel the pass killed because of such a conflict is
-// resurrected (alive bit, dead count, splat), a surviving one gets its confidence back from the undo plane.
-// Conflict ordinals come from prefix sums of the per-quarter-tile counts.
+// After k_surfel_pass: one workgroup publishes DevState (fixup_publisher); the others return at once unless the conflict cap
+// binds (total > W*H: src/GlobalModel.cpp:54-57).  Then they take back every conflict beyond the first `cap`
+// in slot order (fixup_repair): a surfel the pass killed because of such a conflict is resurrected (alive bit, dead count,
+// splat), a surviving one gets its confidence back from the undo plane.  Conflict ordinals come from prefix sums of the
+// per-quarter-tile counts.
+//
+// Two homes.  k_pass_fixup: a launch of its own between the pass and the association (frames whose caller waits, sharded
+// streams, a held-back association that is flushed).  MERGED: the first workgroups of the NEXT frame's preparation launch
+// (k_assoc_prep), next to the association they used to precede -- the two-launch frame.  There the publisher only
+// completes statistics unless the cap binds or the "id 0" surfel died; every association / tile-flag workgroup of that launch
+// tells the two cases apart for itself (slow_frame) and waits for the publisher and the repair crew only then (wait_slow_frame).
+// What a MERGED publisher must not touch, because workgroups of its own launch read or write it: count (the association's first
+// workgroup publishes the new one; N is taken from `offset`, which the pass's launch set), offset, first_live unless it changes,
+// the dirty word (cleared one launch later), the host statistic.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_pass_fixup(Model M, DevState *__restrict__ st, FrameParams fp,
-                                                    const uint64_t *__restrict__ cm, const uint64_t *__restrict__ km,
-                                                    const uint4 *__restrict__ wave_cnt, const uint8_t *__restrict__ tile_flags,
-                                                    const uint4 *__restrict__ part, uint32_t n_part,
-                                                    uint2 *__restrict__ fix_part /* [workers] (visible added, resurrected) */,
-                                                    uint64_t *__restrict__ alive, uint32_t *__restrict__ tile_dead,
-                                                    const uint32_t *__restrict__ conf_sub, uint64_t *__restrict__ keyT,
-                                                    const float *__restrict__ undo, unsigned long long *__restrict__ host_stat,
-                                                    const uint2 *__restrict__ prep_part, uint32_t n_prep /* k_prep's skip statistics (it evaluated the tile flags), or 0 */,
-                                                    DirectArgs da, uint32_t *__restrict__ tb /* tile bounds: a tile drawn only through a resurrected surfel gets the frame's time stamp too */)
+struct FixArgs {
+    const uint64_t *cm, *km;
+    const uint4 *wave_cnt;
+    const uint8_t *tile_flags;
+    const uint4 *part; uint32_t n_part;
+    uint2 *fix_part;                     // [workers] (visible added, resurrected)
+    uint64_t *alive; uint32_t *tile_dead;
+    const uint32_t *conf_sub;            // the frame's 64 conflict sub-counters
+    uint64_t *keyT;
+    const float *undo;
+    unsigned long long *host_stat;
+    const uint2 *prep_part; uint32_t n_prep;     // the preparation launch's skip statistics (it evaluated the tile flags), or 0
+    DirectArgs da;
+    uint32_t *tb;                        // tile bounds: a tile drawn only through a resurrected surfel gets the frame's time stamp too
+    uint32_t n_crew;                     // MERGED: workgroups behind the publisher that repair (0: the launch carries no fixup)
+};
+
+template <bool MERGED>
+__device__ __forceinline__ void fixup_publisher(DevState *__restrict__ st, const FrameParams &fp, const FixArgs &x, uint32_t ctotal)
 {
-    __shared__ uint32_t s_a[4], s_b[4], s_c[4];
+    __shared__ uint32_t s_c[4];
     __shared__ uint32_t s_fl;
     __shared__ uint32_t s_red9[9][4];
+    const DirectArgs &da = x.da;
+    const uint64_t *__restrict__ cm = x.cm, *__restrict__ km = x.km;
+    const uint4 *__restrict__ wave_cnt = x.wave_cnt;
+    const uint64_t *__restrict__ alive = x.alive;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t nwg = gridDim.x - 1u;               // workers; workgroup 0 (dispatched first) publishes
-    const uint32_t ctotal = wave_sum_u32(conf_sub[lane * SUB_STRIDE]);
     const uint32_t cap = fp.conflict_cap;
     const bool cap_binds = ctotal > cap;
-    const uint32_t N = st->count;                      // occupied slots: unchanged by a cull that only marks the dead
+    const uint32_t N = MERGED ? st->offset : st->count;   // occupied slots: unchanged by a cull that only marks the dead
     const uint32_t ntiles = (N + TILE - 1) / TILE;
-    if (blockIdx.x == 0u) {
-        // ---- every load the publisher needs, issued together (each dependent round trip costs ~1 us on this single workgroup)
-        const uint32_t pend = st->pend, cap_prev = st->cap_binds, g_in = st->garbage, old_first = st->first_live;
-        const bool dirty = st->fl_dirty != 0u;
-        PendFields pf;
-        pf.cull_n = st->cull_n; pf.garbage_prev = st->garbage_prev; pf.n_kill = st->n_kill; pf.visible = st->visible_count;
-        pf.conflict = st->conflict_count; pf.n_static = st->n_static; pf.conf_skipped = st->n_conf_skipped;
-        pf.splat_skipped = st->n_splat_skipped; pf.tick = st->pend_tick; pf.frames_logged = st->frames_logged;
-        uint32_t red[9] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};  // new, fused, vis+, resurrected (previous frame) | conf-skip, splat-skip, visible, killed | candidates
-        // the sums the pass / the previous association left in 64 sub-counters each (one load per lane; consumed: zeroed)
-        if (wave == 0) {
-            uint32_t *c = da.frame_sub + lane * SUB_STRIDE;
-            red[6] = c[0]; red[7] = c[SUB_SET]; red[0] = c[2 * SUB_SET]; red[1] = c[3 * SUB_SET];
-            c[0] = 0u; c[SUB_SET] = 0u; c[2 * SUB_SET] = 0u; c[3 * SUB_SET] = 0u;
-        }
-        // (the fixup partials of the previous frame are only meaningful if its conflict cap bound: masked after the
-        //  reduction, so that no load waits for DevState)
-        for (uint32_t b = threadIdx.x; b < da.n_fix_prev; b += 256u) { const uint2 c = da.fix_prev[b]; red[2] += c.x; red[3] += c.y; }
-        if (n_prep) for (uint32_t b = threadIdx.x; b < n_prep; b += 256u) { const uint2 c = prep_part[b]; red[4] += c.x; red[5] += c.y; }
-        else for (uint32_t b = threadIdx.x; b < n_part; b += 256u) { const uint4 c = part[b]; red[4] += c.w; red[5] += c.y; }
-        // ---- one round of reductions
-#pragma unroll
-        for (int x = 0; x < 9; ++x) red[x] = wave_sum_u32(red[x]);
-        if (lane == 0) {
-#pragma unroll
-            for (int x = 0; x < 9; ++x) s_red9[x][wave] = red[x];
-        }
-        if (threadIdx.x == 0) s_fl = 0xFFFFFFFFu;
-        __syncthreads();
-        uint32_t tot[9];
-#pragma unroll
-        for (int x = 0; x < 9; ++x) tot[x] = s_red9[x][0] + s_red9[x][1] + s_red9[x][2] + s_red9[x][3];
-        if (!cap_prev || !pend) { tot[2] = 0u; tot[3] = 0u; }
-        // the previous frame appended directly: its statistics (incl. the dead-slot total used below) are completed first
-        uint32_t g0 = g_in;
-        if (pend) {
-            g0 = pf.garbage_prev + (pf.n_kill - tot[3]) + tot[1];
-            if (threadIdx.x == 0) finalize_write(st, da.log, pf, tot[0], tot[1], tot[2], tot[3]);
-        }
-        const uint32_t cskip_tot = tot[4], sskip_tot = tot[5], vis_tot = tot[6], kill_tot = tot[7];
-        uint32_t first_live = old_first;
-        if (dirty) {
-            // The surfel that was id 0 died in the pass (conf <= 0: only an uploaded model holds such surfels).  Its
-            // successor is the first slot that is alive after the fixup: alive now, or killed by a conflict beyond the cap.
-            first_live = N;
-            const uint32_t t0 = min(old_first, N ? N - 1u : 0u) / TILE;
-            uint32_t before = 0;                       // conflicts in the tiles below the one being searched
-            if (cap_binds) {
-                uint32_t p = 0;
-                for (uint32_t t = threadIdx.x; t < t0; t += 256u) { const uint4 c = wave_cnt[t]; p += c.x + c.y + c.z + c.w; }
-                p = wave_sum_u32(p);
-                if (lane == 0) s_c[wave] = p;
-                __syncthreads();
-                before = s_c[0] + s_c[1] + s_c[2] + s_c[3];
-                __syncthreads();
-            }
-            for (uint32_t t = t0; t < ntiles && N; ++t) {                 // one tile per round, 16 words on 16 threads
-                const uint4 c4 = wave_cnt[t];
-                if (threadIdx.x < TILE_WORDS) {
-                    const uint32_t word = t * TILE_WORDS + threadIdx.x;
-                    const uint64_t base = (uint64_t)word * 64u;
-                    if (base < N) {
-                        const uint64_t rem = (uint64_t)N - base;
-                        const uint64_t range = rem >= 64 ? ~0ull : ((1ull << rem) - 1ull);
-                        uint64_t live = alive[word] & range;
-                        if (cap_binds && (c4.x | c4.y | c4.z | c4.w)) {
-                            uint32_t pre = before;
-                            for (uint32_t x = t * TILE_WORDS; x < word; ++x) pre += (uint32_t)__popcll(cm[x]);
-                            live |= km[word] & ineffective_conflicts(cm[word], pre, cap) & range;
-                        }
-                        if (word == old_first / 64u) live &= ~((2ull << (old_first % 64u)) - 1ull);     // strictly after the old one
-                        if (live) atomicMin(&s_fl, word * 64u + (uint32_t)(__ffsll((long long)live) - 1));
-                    }
-                }
-                __syncthreads();
-                const uint32_t found = s_fl;
-                __syncthreads();
-                if (found != 0xFFFFFFFFu) { first_live = found; break; }
-                before += c4.x + c4.y + c4.z + c4.w;
-            }
-        }
-        if (threadIdx.x == 0) {
-            st->n_conf_skipped = cskip_tot;
-            st->n_splat_skipped = sskip_tot;
-            st->n_static = N;
-            st->conflict_count = min(ctotal, cap);
-            if (fp.splat_follows) st->visible_count = 0;
-            st->cull_n = N;
-            st->cull_src = st->cur;
-            st->cull_dst = st->cur;
-            st->garbage_prev = g0;
-            st->cap_binds = cap_binds ? 1u : 0u;
-            st->do_compact = 0u;
-            st->first_live = first_live;
-            st->fl_dirty = 0u;
-            st->offset = N;                             // the dead keep their slots until the next compaction
-            st->holes_last = 0u;
-            if (da.on) {
-                // provisional totals of the pass (k_associate_direct's first block publishes the new count; the statistics
-                // are completed by finalize_frame / finalize_write once the association is through)
-                st->visible_count = vis_tot;
-                st->n_kill = kill_tot;
-                st->pend = 1u;
-                st->pend_tick = (uint32_t)fp.time;
-            }
-            if (host_stat)
-                __hip_atomic_store(host_stat, ((unsigned long long)st->stat_frames << 32) | (unsigned long long)N, __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-        return;
+    // ---- every load the publisher needs, issued together (each dependent round trip costs ~1 us on this single workgroup)
+    const uint32_t pend = st->pend, cap_prev = st->cap_binds, g_in = st->garbage, old_first = st->first_live;
+    const bool dirty = st->fl_dirty2[fp.par] != 0u;
+    PendFields pf;
+    pf.cull_n = st->cull_n; pf.garbage_prev = st->garbage_prev; pf.n_kill = st->n_kill; pf.visible = st->visible_count;
+    pf.conflict = st->conflict_count; pf.n_static = st->n_static; pf.conf_skipped = st->n_conf_skipped;
+    pf.splat_skipped = st->n_splat_skipped; pf.tick = st->pend_tick; pf.frames_logged = st->frames_logged;
+    uint32_t red[9] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};  // new, fused, vis+, resurrected (previous frame) | conf-skip, splat-skip, visible, killed | candidates
+    // the sums the pass / the previous association left in 64 sub-counters each (one load per lane; consumed: zeroed)
+    if (wave == 0) {
+        uint32_t *c = da.frame_sub + lane * SUB_STRIDE, *n = da.nf_prev + lane * SUB_STRIDE;
+        red[6] = c[0]; red[7] = c[SUB_SET]; red[0] = n[0]; red[1] = n[SUB_SET];
+        c[0] = 0u; c[SUB_SET] = 0u; n[0] = 0u; n[SUB_SET] = 0u;
     }
-    const uint32_t wi = blockIdx.x - 1u;
-    // ---- direct append: the candidate pixels of the frame, per association block and per group (workgroup-uniform loop)
-    if (da.on)
-        for (uint32_t g = wi; g < da.n_grp; g += nwg) {          // (da.cg is uniform)
-            if (da.cg == 4u) cand_count_block<4>(g, fp, da.depthT, da.xs, da.ys, da.n_pix_blocks, da.blk_cand, da.grp_cand);
-            else if (da.cg == 8u) cand_count_block<8>(g, fp, da.depthT, da.xs, da.ys, da.n_pix_blocks, da.blk_cand, da.grp_cand);
-            else cand_count_block<16>(g, fp, da.depthT, da.xs, da.ys, da.n_pix_blocks, da.blk_cand, da.grp_cand);
+    // (the fixup partials of the previous frame are only meaningful if its conflict cap bound: masked after the
+    //  reduction, so that no load waits for DevState)
+    for (uint32_t b = threadIdx.x; b < da.n_fix_prev; b += 256u) { const uint2 c = da.fix_prev[b]; red[2] += c.x; red[3] += c.y; }
+    if (x.n_prep) for (uint32_t b = threadIdx.x; b < x.n_prep; b += 256u) { const uint2 c = x.prep_part[b]; red[4] += c.x; red[5] += c.y; }
+    else for (uint32_t b = threadIdx.x; b < x.n_part; b += 256u) { const uint4 c = x.part[b]; red[4] += c.w; red[5] += c.y; }
+    // ---- one round of reductions
+#pragma unroll
+    for (int i = 0; i < 9; ++i) red[i] = wave_sum_u32(red[i]);
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) s_red9[i][wave] = red[i];
+    }
+    if (threadIdx.x == 0) s_fl = 0xFFFFFFFFu;
+    __syncthreads();
+    uint32_t tot[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) tot[i] = s_red9[i][0] + s_red9[i][1] + s_red9[i][2] + s_red9[i][3];
+    if (!cap_prev || !pend) { tot[2] = 0u; tot[3] = 0u; }
+    // the previous frame appended directly: its statistics (incl. the dead-slot total used below) are completed first
+    uint32_t g0 = g_in;
+    if (pend) {
+        g0 = pf.garbage_prev + (pf.n_kill - tot[3]) + tot[1];
+        if (threadIdx.x == 0) finalize_write(st, da.log, pf, tot[0], tot[1], tot[2], tot[3]);
+    }
+    const uint32_t cskip_tot = tot[4], sskip_tot = tot[5], vis_tot = tot[6], kill_tot = tot[7];
+    uint32_t first_live = old_first;
+    if (dirty) {
+        // The surfel that was id 0 died in the pass (conf <= 0: only an uploaded model holds such surfels).  Its
+        // successor is the first slot that is alive after the fixup: alive now, or killed by a conflict beyond the cap.
+        first_live = N;
+        const uint32_t t0 = min(old_first, N ? N - 1u : 0u) / TILE;
+        uint32_t before = 0;                       // conflicts in the tiles below the one being searched
+        if (cap_binds) {
+            uint32_t p = 0;
+            for (uint32_t t = threadIdx.x; t < t0; t += 256u) { const uint4 c = wave_cnt[t]; p += c.x + c.y + c.z + c.w; }
+            p = wave_sum_u32(p);
+            if (lane == 0) s_c[wave] = p;
+            __syncthreads();
+            before = s_c[0] + s_c[1] + s_c[2] + s_c[3];
+            __syncthreads();
         }
-    if (!cap_binds) return;
-    // ---- the cap binds: take the conflicts beyond the first `cap` back
+        for (uint32_t t = t0; t < ntiles && N; ++t) {                 // one tile per round, 16 words on 16 threads
+            const uint4 c4 = wave_cnt[t];
+            if (threadIdx.x < TILE_WORDS) {
+                const uint32_t word = t * TILE_WORDS + threadIdx.x;
+                const uint64_t base = (uint64_t)word * 64u;
+                if (base < N) {
+                    const uint64_t rem = (uint64_t)N - base;
+                    const uint64_t range = rem >= 64 ? ~0ull : ((1ull << rem) - 1ull);
+                    uint64_t live = alive[word] & range;
+                    if (cap_binds && (c4.x | c4.y | c4.z | c4.w)) {
+                        uint32_t pre = before;
+                        for (uint32_t w = t * TILE_WORDS; w < word; ++w) pre += (uint32_t)__popcll(cm[w]);
+                        live |= km[word] & ineffective_conflicts(cm[word], pre, cap) & range;
+                    }
+                    if (word == old_first / 64u) live &= ~((2ull << (old_first % 64u)) - 1ull);     // strictly after the old one
+                    if (live) atomicMin(&s_fl, word * 64u + (uint32_t)(__ffsll((long long)live) - 1));
+                }
+            }
+            __syncthreads();
+            const uint32_t found = s_fl;
+            __syncthreads();
+            if (found != 0xFFFFFFFFu) { first_live = found; break; }
+            before += c4.x + c4.y + c4.z + c4.w;
+        }
+    }
+    if (threadIdx.x == 0) {
+        st->n_conf_skipped = cskip_tot;
+        st->n_splat_skipped = sskip_tot;
+        st->n_static = N;
+        st->conflict_count = min(ctotal, cap);
+        if (fp.splat_follows) st->visible_count = 0;
+        st->cull_n = N;
+        st->cull_src = st->cur;
+        st->cull_dst = st->cur;
+        st->garbage_prev = g0;
+        st->cap_binds = cap_binds ? 1u : 0u;
+        st->do_compact = 0u;
+        if (!MERGED || dirty) st->first_live = first_live;
+        if (!MERGED) {
+            st->fl_dirty2[fp.par] = 0u;
+            st->offset = N;                         // the dead keep their slots until the next compaction
+        }
+        st->holes_last = 0u;
+        if (da.on) {
+            // provisional totals of the pass (k_associate_direct's first block publishes the new count; the statistics
+            // are completed by finalize_frame / finalize_write once the association is through)
+            st->visible_count = vis_tot;
+            st->n_kill = kill_tot;
+            st->pend = 1u;
+            st->pend_tick = (uint32_t)fp.time;
+        }
+        if (!MERGED && x.host_stat)
+            __hip_atomic_store(x.host_stat, ((unsigned long long)st->stat_frames << 32) | (unsigned long long)N, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_SYSTEM);
+        if (MERGED && (cap_binds || dirty)) {       // somebody waits for this
+            __hip_atomic_fetch_add(&st->slow_done[fp.par], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+// the cap binds: worker `wi` of `nwg` takes the conflicts beyond the first `cap` back in its tiles (wi, wi + nwg, ...)
+__device__ __forceinline__ void fixup_repair(const Model &M, DevState *__restrict__ st, const FrameParams &fp, const FixArgs &x,
+                                             uint32_t wi, uint32_t nwg, uint32_t N)
+{
+    __shared__ uint32_t s_a[4], s_b[4], s_c[4];
+    const uint64_t *__restrict__ cm = x.cm, *__restrict__ km = x.km;
+    const uint4 *__restrict__ wave_cnt = x.wave_cnt;
+    uint64_t *__restrict__ alive = x.alive; uint32_t *__restrict__ tile_dead = x.tile_dead;
+    uint64_t *__restrict__ keyT = x.keyT; const float *__restrict__ undo = x.undo; uint32_t *__restrict__ tb = x.tb;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t cap = fp.conflict_cap;
+    const uint32_t ntiles = (N + TILE - 1) / TILE;
     const SurfelSet set = M.s[st->cur];
     uint32_t cpre = 0;                                  // conflicts in all tiles below this workgroup's current one
     {
@@ -685,7 +768,7 @@ __global__ __launch_bounds__(256) void k_pass_fixup(Model M, DevState *__restric
             cpre += s_c[0] + s_c[1] + s_c[2] + s_c[3];
         }
         if (nconf == 0u || tile_pre + nconf <= cap) continue;              // every conflict of the tile is effective
-        const bool nosplat = (tile_flags[tile] & 2u) != 0u;
+        const bool nosplat = (x.tile_flags[tile] & 2u) != 0u;
         uint32_t wpre = tile_pre + (wave > 0 ? c4.x : 0u) + (wave > 1 ? c4.y : 0u) + (wave > 2 ? c4.z : 0u);
         uint32_t res_wave = 0, vis_tile = vis;
 #pragma unroll
@@ -715,7 +798,7 @@ __global__ __launch_bounds__(256) void k_pass_fixup(Model M, DevState *__restric
         }
         if (res_wave && lane == 0) atomicSub(&tile_dead[tile], res_wave);
         // A resurrected surfel that went into the index map can be fused by this frame's association: the tile carries the
-        // frame's time stamp like a tile k_surfel_pass drew itself (pass_quarter / pass_tile_compact: "drawn at t" bounds the
+        // frame's time stamp like a tile k_surfel_pass drew itself (pass_flush: "drawn at t" bounds the
         // last update of every surfel of the tile, and tells the next frame's tile flags which boxes may still grow)
         if (vis != vis_tile && lane == 0) atomicMax(&tb[(size_t)tile * 8 + 7], f2ord((float)fp.time));
         resurrected += res_wave;
@@ -723,7 +806,42 @@ __global__ __launch_bounds__(256) void k_pass_fixup(Model M, DevState *__restric
     __syncthreads();
     if (lane == 0) { s_a[wave] = vis; s_b[wave] = resurrected; }
     __syncthreads();
-    if (threadIdx.x == 0) fix_part[wi] = make_uint2(s_a[0] + s_a[1] + s_a[2] + s_a[3], s_b[0] + s_b[1] + s_b[2] + s_b[3]);
+    if (threadIdx.x == 0) x.fix_part[wi] = make_uint2(s_a[0] + s_a[1] + s_a[2] + s_a[3], s_b[0] + s_b[1] + s_b[2] + s_b[3]);
+}
+
+// MERGED form: block b of the 1 + n_crew fixup workgroups that open k_assoc_prep's grid
+__device__ __forceinline__ void fixup_merged_block(const Model &M, DevState *__restrict__ st, const FrameParams &fp, const FixArgs &x, uint32_t b)
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t ctotal = wave_sum_u32(x.conf_sub[lane * SUB_STRIDE]);
+    if (b == 0u) { fixup_publisher<true>(st, fp, x, ctotal); return; }
+    const bool cap_binds = ctotal > fp.conflict_cap;
+    if (!cap_binds && st->fl_dirty2[fp.par] == 0u) return;                  // (workgroup-uniform) the usual frame
+    if (cap_binds) fixup_repair(M, st, fp, x, b - 1u, x.n_crew, st->offset);
+    else if (threadIdx.x == 0) x.fix_part[b - 1u] = make_uint2(0u, 0u);
+    __threadfence();                                   // every thread's repairs, before the one count the waiters acquire
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(&st->slow_done[fp.par], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ __launch_bounds__(256) void k_pass_fixup(Model M, DevState *__restrict__ st, FrameParams fp, FixArgs x)
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t nwg = gridDim.x - 1u;               // workers; workgroup 0 (dispatched first) publishes
+    const uint32_t ctotal = wave_sum_u32(x.conf_sub[lane * SUB_STRIDE]);
+    if (blockIdx.x == 0u) { fixup_publisher<false>(st, fp, x, ctotal); return; }
+    const uint32_t wi = blockIdx.x - 1u;
+    const DirectArgs &da = x.da;
+    // ---- direct append: the candidate pixels of the frame, per association block and per group (workgroup-uniform loop)
+    if (da.on == 1)                                    // (2: the pass's launch counted them already)
+        for (uint32_t g = wi; g < da.n_grp; g += nwg) {          // (da.cg is uniform)
+            if (da.cg == 4u) cand_count_block<4>(g, fp, da.depthT, da.xs, da.ys, da.n_pix_blocks, da.blk_cand, da.grp_cand);
+            else if (da.cg == 8u) cand_count_block<8>(g, fp, da.depthT, da.xs, da.ys, da.n_pix_blocks, da.blk_cand, da.grp_cand);
+            else cand_count_block<16>(g, fp, da.depthT, da.xs, da.ys, da.n_pix_blocks, da.blk_cand, da.grp_cand);
+        }
+    if (ctotal <= fp.conflict_cap) return;
+    // ---- the cap binds: take the conflicts beyond the first `cap` back
+    fixup_repair(M, st, fp, x, wi, nwg, st->count);
 }
 
 // standalone p6 (IndexMap::predictIndices) over the current model

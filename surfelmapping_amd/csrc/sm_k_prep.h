@@ -94,6 +94,11 @@ struct TilePrep {
     const uint32_t *grp_cand; // candidate pixels of that frame per group (its new slot count = offset + their sum), or null
     uint32_t n_grp;
     int prev_time;            // that frame's time stamp
+    // ... and, in the two-launch frame, so do that frame's publisher and repair crew: on the rare frames where they change anything
+    // (slow_frame) the flag workgroups wait for them first -- a resurrected surfel may stamp a tile
+    const uint32_t *slow_conf_sub;   // that frame's conflict sub-counters, or null: nothing to wait for
+    uint32_t slow_cap, slow_need;
+    int slow_par;
 };
 
 __device__ __forceinline__ void tile_prep_block(const FrameParams &fp, const TilePrep &tp, uint32_t first_block = 0u)
@@ -105,6 +110,8 @@ __device__ __forceinline__ void tile_prep_block(const FrameParams &fp, const Til
     // offset + (its candidate pixels); tiles it can still change must not be skipped on stale bounds.  Those are the tiles
     // from the old end on (appends) and the tiles that frame drew into the index map (a fuse moves a surfel: its box may
     // grow) -- k_surfel_pass stamped exactly those with the frame's time, so "stamped last frame" means "do not skip".
+    if (tp.slow_conf_sub && slow_frame(tp.st, tp.slow_conf_sub, tp.slow_cap, tp.slow_par, lane))
+        wait_slow_frame(const_cast<DevState *>(tp.st), tp.slow_par, tp.slow_need);
     uint32_t N = tp.st->count, first_new_tile = 0xFFFFFFFFu;
     if (tp.grp_cand) {
         uint32_t d = 0;
@@ -186,7 +193,7 @@ struct ShardSettle {
     const uint64_t *validmask, *ownmask, *gmask;
     uint32_t nwords;
     const uint32_t *blk_cand, *grp_cand;
-    uint32_t *frame_sub;
+    uint32_t *nf;                     // new / fused sub-counter sets
     uint64_t *alive;
     uint32_t *tile_dead;
     int owner;
@@ -234,8 +241,8 @@ __device__ __forceinline__ void shard_settle_body(const ShardSettle &a, uint32_t
     }
     if (lane == 0 && in) {
         const uint32_t nf = (uint32_t)__popcll(gw & vw), nn = (uint32_t)__popcll(vw & ~gw);
-        if (nn) atomicAdd(&a.frame_sub[2 * SUB_SET + (word & 63u) * SUB_STRIDE], nn);
-        if (nf) atomicAdd(&a.frame_sub[3 * SUB_SET + (word & 63u) * SUB_STRIDE], nf);
+        if (nn) atomicAdd(&a.nf[(word & 63u) * SUB_STRIDE], nn);
+        if (nf) atomicAdd(&a.nf[SUB_SET + (word & 63u) * SUB_STRIDE], nf);
     }
     __syncthreads();
     const bool holes = need && s_any[sub] != 0u;                  // uniform per sub-block

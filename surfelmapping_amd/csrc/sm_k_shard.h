@@ -209,7 +209,7 @@ __global__ __launch_bounds__(1024) void k_shard_scan(DevState *__restrict__ st, 
         const uint32_t live_before_append = st->offset - (st->garbage - st->holes_last);
         st->count = Nn; st->offset = live_before_append;
         st->garbage = 0u; st->garbage_prev = 0u; st->holes_last = 0u;
-        st->first_live = 0u; st->fl_dirty = 0u;  // the first live surfel of the union moves to slot 0
+        st->first_live = 0u; st->fl_dirty2[0] = 0u; st->fl_dirty2[1] = 0u;  // the first live surfel of the union moves to slot 0
         if (host_stat)
             __hip_atomic_store(host_stat, ((unsigned long long)st->stat_frames << 32) | (unsigned long long)Nn, __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_SYSTEM);
