@@ -554,7 +554,7 @@ int launch_prep(sm_ctx *s, const uint8_t *rgb, const uint16_t *raw, const uint8_
     s->n_prep_blocks = 0;
     if (clear_keys && s->want_list) {
         const uint64_t ntl = ((uint64_t)s->count_bound + TILE - 1) / TILE;
-        tp.nfb = (uint32_t)std::min<uint64_t>(std::max<uint64_t>((ntl + 127) / 128, 1), 64);
+        tp.nfb = (uint32_t)std::min<uint64_t>(std::max<uint64_t>((ntl + 1023) / 1024, 1), 64);     // one tile per thread (k_prep: 1 024 threads)
         tp.st = s->d_state; tp.tb = s->d_tb; tp.tile_flags = s->d_tile_flags; tp.wave_cnt = s->d_wave_cnt; tp.prep_part = s->d_prep_part;
         s->n_prep_blocks = tp.nfb;
     }
@@ -571,7 +571,7 @@ int launch_prep(sm_ctx *s, const uint8_t *rgb, const uint16_t *raw, const uint8_
         }
         if (tp.nfb) {
             const uint64_t ntl = ((uint64_t)s->count_bound + TILE - 1) / TILE;
-            tp.nfb = (uint32_t)std::min<uint64_t>(std::max<uint64_t>((ntl + 31) / 32, 1), 256);     // 32 tiles per 256-thread workgroup and round
+            tp.nfb = (uint32_t)std::min<uint64_t>(std::max<uint64_t>((ntl + 255) / 256, 1), 128);     // one tile per thread
             if (carry) { tp.grp_cand = s->assoc_args.grp_cand; tp.n_grp = s->assoc_args.n_grp; tp.prev_time = s->assoc_args.fp.time; }
             s->n_prep_blocks = tp.nfb;
         }
@@ -673,8 +673,28 @@ int launch_surfel_pass(sm_ctx *s, const FrameParams &fp, bool timed, bool direct
     // hundred tiles with work), but no more than are RESIDENT once every workgroup has many tiles with work (>= 4 per
     // workgroup: beyond ~8 M slots) -- the surplus would start when the first ones finish and run a second, thin wave
     // (20 M scattered surfels: 160 us with 2 048 workgroups, 140 with 1 536 = 6 per CU, 152 with 5, 172 with 7)
-    const uint64_t tiles_b = ((uint64_t)s->count_bound + TILE - 1) / TILE;
-    const int grid = tiles_b > (uint64_t)4 * MAX_GRID ? std::min(grid_surfels(s), s->pass_grid) : grid_surfels(s);
+    // (the regime is picked from an ESTIMATE of the occupied slots -- the pinned statistic plus a frame's worth of candidates for
+    //  every append enqueued since -- not from count_bound, which after a hundred unsynchronised frames is the capacity)
+    uint64_t slots_est = s->count_bound;
+    {
+        const unsigned long long v = __atomic_load_n(s->h_stat, __ATOMIC_RELAXED);
+        const uint32_t fr = (uint32_t)(v >> 32), slots = (uint32_t)v;
+        if (s->frames_enq >= fr) slots_est = std::min<uint64_t>(slots_est, (uint64_t)slots + (uint64_t)(s->frames_enq - fr) * s->n_odd_pixels);
+    }
+    const uint64_t tiles_b = (slots_est + TILE - 1) / TILE;
+    const bool persistent = tiles_b > (uint64_t)4 * MAX_GRID;
+    // Quarter-tile units (k_surfel_pass<4>: four workgroups per tile sequence) while tiles are few and some of them dense; whole
+    // tiles once every workgroup owns many (the scattered 20 M-surfel model: ~50 listed slots per tile, batches of 8 tiles)
+    static const int split_env = std::getenv("SM_PASS_SPLIT") ? std::atoi(std::getenv("SM_PASS_SPLIT")) : 0;
+    const int split = split_env == 1 || split_env == 4 ? split_env : persistent ? 1 : 4;
+    int grid = persistent ? std::min(grid_surfels(s), s->pass_grid) : grid_surfels(s);
+    if (split == 4) {
+        static const int seq_env = std::getenv("SM_PASS_SEQ") ? std::atoi(std::getenv("SM_PASS_SEQ")) : 0;
+        // (all of them resident: 2 048 workgroups were 17.5 us where 1 536 are 14.1 -- the last quarter started when the first left)
+        const int max_seq = seq_env > 0 ? std::min(seq_env, MAX_GRID / 4) : 3 * MAX_GRID / 16;       // 384 sequences = 1 536 workgroups, six per CU
+        const uint64_t tiles_all = ((uint64_t)s->count_bound + TILE - 1) / TILE;
+        grid = 4 * (int)std::min<uint64_t>(std::max<uint64_t>(tiles_all, 1), (uint64_t)max_seq);
+    }
     // fixup workers: the cap repair strides over the tiles; with direct append they first count the frame's candidate pixels, one group each
     const int fgrid = two ? (int)sm_ctx::N_CREW
                     : direct ? std::max(std::min(grid, s->fix_grid), (int)std::min<uint32_t>(s->n_grp, MAX_GRID)) : std::min(grid, s->fix_grid);
@@ -697,9 +717,14 @@ int launch_surfel_pass(sm_ctx *s, const FrameParams &fp, bool timed, bool direct
         ca.n_grp = s->n_grp; ca.cg = s->cand_group; ca.n_pix_blocks = s->n_pix_blocks;
         ca.depthT = s->d_depthT; ca.xs = s->d_xs; ca.ys = s->d_ys; ca.blk_cand = s->d_blk_cand; ca.grp_cand = s->d_grp_cand;
     }
-    hipLaunchKernelGGL(k_surfel_pass, dim3(grid + (two ? (int)s->n_grp : 0)), dim3(256), 0, s->stream, s->M, s->d_state, fp, s->d_dcT, s->d_cm, s->d_dm /* km */,
-                       s->d_wave_cnt, s->d_tb, s->d_tile_flags, s->d_lazy_part, s->d_alive, s->d_tile_dead, sub, s->d_keyT, s->d_undo, tile_bound,
-                       s->d_frame_sub, ca, s->d_pass_trace);
+    if (split == 4)
+        hipLaunchKernelGGL(k_surfel_pass<4>, dim3(grid + (two ? (int)s->n_grp : 0)), dim3(256), 0, s->stream, s->M, s->d_state, fp, s->d_dcT, s->d_cm, s->d_dm /* km */,
+                           s->d_wave_cnt, s->d_tb, s->d_tile_flags, s->d_lazy_part, s->d_alive, s->d_tile_dead, sub, s->d_keyT, s->d_undo, tile_bound,
+                           s->d_frame_sub, ca, s->d_pass_trace);
+    else
+        hipLaunchKernelGGL(k_surfel_pass<1>, dim3(grid + (two ? (int)s->n_grp : 0)), dim3(256), 0, s->stream, s->M, s->d_state, fp, s->d_dcT, s->d_cm, s->d_dm /* km */,
+                           s->d_wave_cnt, s->d_tb, s->d_tile_flags, s->d_lazy_part, s->d_alive, s->d_tile_dead, sub, s->d_keyT, s->d_undo, tile_bound,
+                           s->d_frame_sub, ca, s->d_pass_trace);
     HIPCK(hipGetLastError());
     if (mark(s, 2, timed) || mark(s, 3, timed)) return SM_E_HIP;
     FixArgs x;
@@ -1081,9 +1106,9 @@ int enqueue_frame(sm_ctx *s, const uint8_t *d_rgb, const uint16_t *d_raw, const 
     s->want_list = fusing && !compact_now;
     // a held-back association rides on this frame's k_prep launch if this is again a fusing frame; anything else (the frame
     // after reset, ...) needs its results first
-    // (a compacting frame too: its k_prep launch has no tile flags to make -- unless the fixup step is pending as well: the doubled
-    //  words of DevState it leaves set are cleared by the NEXT pass's launch, which a compacting frame does not have)
-    s->merge_assoc = s->assoc_pending && fusing && s->defer_ok && !(s->fix_pending && compact_now);
+    // (a compacting frame too: its k_prep launch has no tile flags to make; the doubled words of DevState a merged publisher
+    //  leaves set are cleared by k_cull_finalize there, by the next pass's launch otherwise)
+    s->merge_assoc = s->assoc_pending && fusing && s->defer_ok;
     int rc = SM_OK;
     if (s->assoc_pending && !s->merge_assoc && (rc = flush_assoc(s))) return rc;
     rc = begin_frame(s, d_rgb, d_raw, d_sem, pose, &fp);
@@ -1177,7 +1202,7 @@ int sm_default_config(sm_config *c, int width, int height, float fx, float fy, f
     c->conflict_cap = 1;
     c->device = 0;
     c->enable_timing = 0;
-    c->compact_period = 16;
+    c->compact_period = 32;
     return SM_OK;
 }
 
@@ -1328,7 +1353,7 @@ sm_ctx *sm_create(const sm_config *c)
             // on a model where every tile has work (20 M scattered surfels: ~10 tiles per workgroup) that is a second pass at an
             // eighth of the occupancy.  Grid = what is resident; tiles go round-robin.  (SM_PASS_WG_PER_CU overrides.)
             int pc = 0;
-            if (cus > 0 && hipOccupancyMaxActiveBlocksPerMultiprocessor(&pc, k_surfel_pass, 256, 0) == hipSuccess && pc > 0) {
+            if (cus > 0 && hipOccupancyMaxActiveBlocksPerMultiprocessor(&pc, k_surfel_pass<1>, 256, 0) == hipSuccess && pc > 0) {
                 int want = std::max(1, pc - 1);      // the occupancy API over-reports by one block per CU here (measured; MI355X_MICROARCH.md)
                 if (const char *e = std::getenv("SM_PASS_WG_PER_CU")) want = std::max(1, std::atoi(e));
                 s->pass_grid = std::max(256, std::min(cus * want, MAX_GRID));
@@ -1385,10 +1410,10 @@ void sm_destroy(sm_ctx *s)
         (void)hipFree(s->d_pass_trace);
     }
     if (s->d_ap_trace) {
-        const int n = s->ap_trace_n[0] + s->ap_trace_n[1] + s->ap_trace_n[2];
+        const int n = s->ap_trace_n[0] + s->ap_trace_n[1] + s->ap_trace_n[2] + s->ap_trace_n[3];
         std::vector<unsigned long long> h((size_t)std::max(std::min(n, 65536), 0) * 2 + 3);
         if (n > 0 && hipMemcpy(h.data() + 3, s->d_ap_trace, (h.size() - 3) * 8, hipMemcpyDeviceToHost) == hipSuccess) {
-            h[0] = (unsigned long long)s->ap_trace_n[0]; h[1] = (unsigned long long)s->ap_trace_n[1]; h[2] = (unsigned long long)s->ap_trace_n[2];
+            h[0] = (unsigned long long)s->ap_trace_n[0] | ((unsigned long long)s->ap_trace_n[3] << 32); h[1] = (unsigned long long)s->ap_trace_n[1]; h[2] = (unsigned long long)s->ap_trace_n[2];
             char path[512];
             snprintf(path, sizeof path, "%s.assoc_prep.bin", std::getenv("SM_PASS_TRACE") ? std::getenv("SM_PASS_TRACE") : "pass_trace");
             if (FILE *f = fopen(path, "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }

@@ -377,6 +377,8 @@ __global__ __launch_bounds__(1024) void k_cull_finalize(DevState *__restrict__ s
         st->first_moving = (compact && s_first != 0xFFFFFFFFu) ? min(s_first, ntiles) : ntiles;
         st->compact_ticket = 0u;
         st->first_live = first_live;
+        st->fl_dirty2[0] = 0u; st->fl_dirty2[1] = 0u;    // (a two-launch frame's publisher, merged into this frame's preparation launch, left them to the next pass -- there is none here)
+        st->slow_done[0] = 0u; st->slow_done[1] = 0u;
         st->holes_last = 0u;
         if (compact) {
             st->count = kept;                             // src/GlobalModel.cpp:575

@@ -113,6 +113,10 @@ __device__ __forceinline__ void cand_count_group_lean(uint32_t g, const CandArgs
     if (threadIdx.x == 0) ca.grp_cand[g] = gsum;
 }
 
+// A workgroup barrier that orders LDS traffic only: no fence on global memory, so a load issued before it (the next unit's
+// prefetch) stays in flight across it.  Every barrier of the pass separates LDS producers from LDS consumers.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 struct PassAcc { uint32_t vis, killed, nconf; };
 
 // ---------------------------------------------------------------------------------------------
@@ -142,6 +146,9 @@ struct PassLds {
 };
 
 // ---- phase B + the tiles' bookkeeping for the `nb` tiles of the batch (workgroup-uniform; leaves the list and the masks empty)
+// SPLIT: a workgroup's unit of work is one SPLIT-th of a tile (TILE_WORDS / SPLIT consecutive words; its index within the tile
+// travels in bits 8.. of the batch entry's flags): the bookkeeping touches only the unit's words.
+template <int SPLIT>
 __device__ __forceinline__ void pass_flush(const SurfelSet &set, DevState *__restrict__ st, const FrameParams &fp,
                                            const uint2 *__restrict__ dcT, uint64_t *__restrict__ cm, uint64_t *__restrict__ km,
                                            uint4 *__restrict__ wave_cnt, uint64_t *__restrict__ alive,
@@ -151,7 +158,7 @@ __device__ __forceinline__ void pass_flush(const SurfelSet &set, DevState *__res
 {
     float4 *__restrict__ pc = set.pos_conf;
     const uint32_t tid = threadIdx.x;
-    __syncthreads();                                   // the list, the batch table
+    lds_barrier();                                     // the list, the batch table
     const uint32_t n_act = L.n;
     // the exact tests (pass_words / splat_one, per lane) over the dense list, two entries per thread at a time
     // (a single round of four entries per thread, staged so that a full tile pays each round trip once, was measured: 79
@@ -231,12 +238,12 @@ __device__ __forceinline__ void pass_flush(const SurfelSet &set, DevState *__res
         }
     }
     acc.vis += wave_sum_u32(my_vis);
-    __syncthreads();
+    lds_barrier();
     // ---- per tile of the batch: masks, alive words, dead count, quarter-tile conflict counts (a wave per tile, one lane per word)
     for (uint32_t b = wave; b < nb; b += 4u) {
-        const uint32_t tile = L.btile[b], fl = L.bflag[b];
+        const uint32_t tile = L.btile[b], fl = L.bflag[b], upart = fl >> 8;
         uint32_t nc = 0, ng = 0;
-        if (lane < TILE_WORDS) {
+        if (lane < TILE_WORDS && (SPLIT == 1 || (uint32_t)lane / (uint32_t)(TILE_WORDS / SPLIT) == upart)) {
             const uint32_t word = tile * TILE_WORDS + (uint32_t)lane;
             const uint64_t c = (uint64_t)L.cm[b][2 * lane] | ((uint64_t)L.cm[b][2 * lane + 1] << 32);
             const uint64_t kk = (uint64_t)L.km[b][2 * lane] | ((uint64_t)L.km[b][2 * lane + 1] << 32);
@@ -261,7 +268,9 @@ __device__ __forceinline__ void pass_flush(const SurfelSet &set, DevState *__res
         const uint32_t q0 = lane_bcast(q, 0), q1 = lane_bcast(q, 4), q2 = lane_bcast(q, 8), q3 = lane_bcast(q, 12);
         const uint32_t killed = wave_sum_u32(ng);
         if (lane == 0) {
-            wave_cnt[tile] = make_uint4(q0, q1, q2, q3);
+            if (SPLIT == 1) wave_cnt[tile] = make_uint4(q0, q1, q2, q3);
+            else if (SPLIT == 4) ((uint32_t *)&wave_cnt[tile])[upart] = upart == 0u ? q0 : upart == 1u ? q1 : upart == 2u ? q2 : q3;
+            else ((uint2 *)&wave_cnt[tile])[upart] = upart == 0u ? make_uint2(q0, q1) : make_uint2(q2, q3);
             if (killed) atomicAdd(&tile_dead[tile], killed);
             // Something of this tile went into the index map, so it can be fused in this frame: stamp the tile's box with the frame's
             // time.  (k_associate_direct leaves the time word to this kernel; "drawn at t" is never older than the last update of any
@@ -274,32 +283,37 @@ __device__ __forceinline__ void pass_flush(const SurfelSet &set, DevState *__res
         acc.nconf += q0 + q1 + q2 + q3;
     }
     if (tid == 0) L.n = 0u;
-    __syncthreads();
+    lds_barrier();
 }
 
 // ---- phase A of one tile: the cheap superset test over its 1 024 slots (wave <-> four consecutive words, loads in flight
 // together); the slots that need the exact tests join the workgroup's list, which is flushed first if they would not fit.
-// `it` counts the workgroup's visited tiles; `nb` the tiles in the current batch.
+// `it` counts the workgroup's visited tiles; `nb` the tiles in the current batch.  SPLIT / upart: the workgroup takes the
+// upart-th SPLIT-th of the tile (RW = 4 / SPLIT words per wave).
+template <int SPLIT>
 __device__ __forceinline__ void pass_tile_append(const SurfelSet &set, DevState *__restrict__ st, const FrameParams &fp,
                                                  const uint2 *__restrict__ dcT, uint64_t *__restrict__ cm, uint64_t *__restrict__ km,
                                                  uint4 *__restrict__ wave_cnt, uint64_t *__restrict__ alive,
                                                  uint32_t *__restrict__ tile_dead, uint64_t *__restrict__ keyT, float *__restrict__ undo,
                                                  uint32_t N, uint32_t exempt, uint32_t tile, uint32_t wave, bool sk0, bool sk1,
                                                  bool any_dead, int lane, PassAcc &acc, uint32_t *__restrict__ tb, PassLds &L, uint32_t it,
-                                                 uint32_t &nb, uint32_t &n_list)
+                                                 uint32_t &nb, uint32_t &n_list, uint32_t upart,
+                                                 const float4 *pre = nullptr /* SPLIT == 4: the wave's word, loaded by the caller while the previous unit was at work */)
 {
+    constexpr int RW = 4 / SPLIT;                      // words per wave
     const float4 *__restrict__ pc = set.pos_conf;
     const uint32_t tid = threadIdx.x;
-    float4 v[4];
-    uint64_t valid[4];
+    const uint32_t w0 = upart * (uint32_t)(TILE_WORDS / SPLIT) + wave * (uint32_t)RW;      // the wave's first word within the tile
+    float4 v[RW];
+    uint64_t valid[RW];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const uint32_t k = (tile * TILE_WORDS + wave * 4u + (uint32_t)r) * 64u + (uint32_t)lane;
-        v[r] = pc[min(k, N - 1u)];
+    for (int r = 0; r < RW; ++r) {
+        const uint32_t k = (tile * TILE_WORDS + w0 + (uint32_t)r) * 64u + (uint32_t)lane;
+        v[r] = (RW == 1 && pre) ? *pre : pc[min(k, N - 1u)];
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const uint32_t word = tile * TILE_WORDS + wave * 4u + (uint32_t)r;
+    for (int r = 0; r < RW; ++r) {
+        const uint32_t word = tile * TILE_WORDS + w0 + (uint32_t)r;
         const uint64_t base = (uint64_t)word * 64u;
         uint64_t range = 0ull;
         if (base < N) { const uint64_t rem = (uint64_t)N - base; range = rem >= 64 ? ~0ull : ((1ull << rem) - 1ull); }
@@ -307,10 +321,10 @@ __device__ __forceinline__ void pass_tile_append(const SurfelSet &set, DevState 
     }
     if (tid == 0) L.pend[(it + 1u) % 3u] = 0u;         // (last read two tiles ago: every thread has passed a barrier since)
     const float zs_max = fp.depth_cutoff * 1.5f;       // splat_one's far limit
-    uint64_t m[4];
+    uint64_t m[RW];
     uint32_t cnt = 0;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
+    for (int r = 0; r < RW; ++r) {
         bool act = false;
         // (a wave-uniform early-out on the camera-frame depth alone -- a third of the transform, then a ballot -- was measured:
         //  no gain at KITTI size, -5 % on the scattered 20 M-surfel model where no word is behind the camera as a whole)
@@ -327,33 +341,33 @@ __device__ __forceinline__ void pass_tile_append(const SurfelSet &set, DevState 
         cnt += (uint32_t)__popcll(m[r]);
     }
     if (lane == 0 && cnt) atomicAdd(&L.pend[it % 3u], cnt);
-    __syncthreads();                                   // this tile's demand; the previous tile's entries
+    lds_barrier();                                     // this tile's demand; the previous tile's entries
     // The list length the decision uses is a REGISTER every thread advances identically (n_list), not L.n: the waves that are
     // through with the test start appending (atomicAdd on L.n) while others still evaluate it -- read from LDS, two waves could
     // see different lengths, disagree on flushing and part ways at the barriers inside (seen as a one-in-ten-runs surplus of
     // ~126 surfels on an 8-context run and a one-off abort in a compaction).  L.pend[it % 3] is stable until two tiles on.
     const uint32_t need = L.pend[it % 3u];
     if (n_list + need > (uint32_t)TILE || nb == (uint32_t)PASS_BATCH) {               // workgroup-uniform
-        pass_flush(set, st, fp, dcT, cm, km, wave_cnt, alive, tile_dead, keyT, undo, N, exempt, nb, wave, lane, acc, tb, L);
+        pass_flush<SPLIT>(set, st, fp, dcT, cm, km, wave_cnt, alive, tile_dead, keyT, undo, N, exempt, nb, wave, lane, acc, tb, L);
         nb = 0u;
         n_list = 0u;
         // (the tile's 16 KB again, from the cache: keeping them in registers across the flush cost the kernel 29 VGPRs -- 99
         //  instead of 70 -- and with them two waves per SIMD)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const uint32_t k = (tile * TILE_WORDS + wave * 4u + (uint32_t)r) * 64u + (uint32_t)lane;
+        for (int r = 0; r < RW; ++r) {
+            const uint32_t k = (tile * TILE_WORDS + w0 + (uint32_t)r) * 64u + (uint32_t)lane;
             v[r] = pc[min(k, N - 1u)];
         }
     }
-    if (tid == 0) { L.btile[nb] = tile; L.bflag[nb] = (sk0 ? 1u : 0u) | (sk1 ? 2u : 0u) | (any_dead ? 4u : 0u); }
+    if (tid == 0) { L.btile[nb] = tile; L.bflag[nb] = (sk0 ? 1u : 0u) | (sk1 ? 2u : 0u) | (any_dead ? 4u : 0u) | (upart << 8); }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
+    for (int r = 0; r < RW; ++r) {
         uint32_t base = 0;
         if (lane == 0 && m[r]) base = atomicAdd(&L.n, (uint32_t)__popcll(m[r]));
         base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
         if ((m[r] >> lane) & 1ull) {
             const uint32_t at = base + (uint32_t)__popcll(m[r] & ((1ull << lane) - 1ull));
-            L.list[at] = (nb << 10) | ((wave * 4u + (uint32_t)r) * 64u + (uint32_t)lane);
+            L.list[at] = (nb << 10) | ((w0 + (uint32_t)r) * 64u + (uint32_t)lane);
             L.pos[at] = v[r];
         }
     }
@@ -362,7 +376,11 @@ __device__ __forceinline__ void pass_tile_append(const SurfelSet &set, DevState 
 }
 
 // The frame's preparation launch evaluated the tile skip flags (one byte per tile, loaded together with DevState).
-// Workgroup <-> tile round-robin.
+// Workgroup <-> tile round-robin.  SPLIT = 4: four consecutive workgroups share a sequence of tiles, a quarter each (ca.n_pass
+// is a multiple of SPLIT).  The newest ~150 tiles of a KITTI model hold ~900 surfels in view each; as ONE workgroup's list that
+// is four rounds of the exact tests on four waves while most of the chip has nothing left to do (tools/pass_trace.py: such a
+// workgroup left 9 us after its cheap test, the launch with it) -- as four workgroups' lists it is one round each.
+template <int SPLIT>
 __global__ __launch_bounds__(256) void k_surfel_pass(Model M, DevState *__restrict__ st, FrameParams fp,
                                                      const uint2 *__restrict__ dcT, uint64_t *__restrict__ cm,
                                                      uint64_t *__restrict__ km, uint4 *__restrict__ wave_cnt,
@@ -398,7 +416,8 @@ __global__ __launch_bounds__(256) void k_surfel_pass(Model M, DevState *__restri
     // newest tiles -- the surfels the camera is looking at, i.e. the tiles with all the work -- are the highest ones, so the
     // mapping is reversed: block 0 takes the highest tile of the grid, and a workgroup with several tiles starts with its
     // highest (the flags of its first 64 tiles sit one per lane whatever the order).
-    const uint32_t tile_grid = ca.n_pass, bid = ca.n_pass - 1u - blockIdx.x;
+    const uint32_t wid = ca.n_pass - 1u - blockIdx.x;                    // (its partial sums and sub-counters go by this)
+    const uint32_t tile_grid = ca.n_pass / (uint32_t)SPLIT, bid = wid / (uint32_t)SPLIT, upart = wid % (uint32_t)SPLIT;
     __shared__ uint32_t s_a[4], s_b[4], s_c[4];
     __shared__ PassLds s_pass;
     const int lane = threadIdx.x & 63;
@@ -427,6 +446,38 @@ __global__ __launch_bounds__(256) void k_surfel_pass(Model M, DevState *__restri
         if (threadIdx.x == 0) s_pass.n = 0u;
         __syncthreads();
     }
+    if (SPLIT == 4 && desc && n_it) {
+        // Quarter-tile units, the workgroup's units one behind the other -- with the NEXT unit's word already on its way while
+        // this one is tested (a unit is one 16-byte load per thread; the barriers inside do not wait for it, lds_barrier)
+        {
+            const uint64_t tl = (uint64_t)bid + (uint64_t)lane * tile_grid;
+            const uint32_t f = tl < ntiles ? m_flag : 3u;
+            skip0 = __ballot((f & 1u) != 0u);
+            skip1 = __ballot((f & 2u) != 0u);
+        }
+        uint64_t vis = ~(skip0 & skip1) & (n_it >= 64u ? ~0ull : ((1ull << n_it) - 1ull));
+        const float4 *__restrict__ pc = set.pos_conf;
+        const uint32_t wofs = (upart * (uint32_t)(TILE_WORDS / SPLIT) + wave) * 64u + (uint32_t)lane;       // this thread's slot within a tile
+        int sl = vis ? 63 - __clzll((long long)vis) : -1;
+        float4 vn = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (sl >= 0) vn = pc[min((bid + (uint32_t)sl * tile_grid) * (uint32_t)TILE + wofs, N - 1u)];
+        while (sl >= 0) {                               // workgroup-uniform
+            vis &= ~(1ull << sl);
+            const int sl_next = vis ? 63 - __clzll((long long)vis) : -1;
+            const float4 vcur = vn;
+            if (sl_next >= 0) vn = pc[min((bid + (uint32_t)sl_next * tile_grid) * (uint32_t)TILE + wofs, N - 1u)];
+            const uint32_t tile = bid + (uint32_t)sl * tile_grid;
+            const bool sk0 = (skip0 >> sl) & 1ull, sk1 = (skip1 >> sl) & 1ull;
+            const bool tr_now = tr && tr_first;
+            tr_first = false;
+            if (tr_now && threadIdx.x == 0) { tr[1] = wall_clock64(); tr[4] = tile; }
+            pass_tile_append<SPLIT>(set, st, fp, dcT, cm, km, wave_cnt, alive, tile_dead, keyT, undo, N, exempt, tile, wave, sk0, sk1,
+                                    lane_bcast(m_dead, sl) != 0u, lane, acc, tb, s_pass, n_visited, n_batch, n_list, upart, &vcur);
+            ++n_visited;
+            if (tr_now && threadIdx.x == 0) { tr[2] = wall_clock64(); tr[5] = s_pass.n; }
+            sl = sl_next;
+        }
+    } else
     for (uint32_t it = 0; it < n_it; ++it) {
         const uint32_t iter = desc ? n_it - 1u - it : it;
         const uint32_t tile = bid + iter * tile_grid;
@@ -445,24 +496,24 @@ __global__ __launch_bounds__(256) void k_surfel_pass(Model M, DevState *__restri
             const bool tr_now = tr && tr_first;
             tr_first = false;
             if (tr_now && threadIdx.x == 0) { tr[1] = wall_clock64(); tr[4] = tile; }
-            pass_tile_append(set, st, fp, dcT, cm, km, wave_cnt, alive, tile_dead, keyT, undo, N, exempt, tile, wave, sk0, sk1,
-                             lane_bcast(m_dead, sl) != 0u, lane, acc, tb, s_pass, n_visited, n_batch, n_list);
+            pass_tile_append<SPLIT>(set, st, fp, dcT, cm, km, wave_cnt, alive, tile_dead, keyT, undo, N, exempt, tile, wave, sk0, sk1,
+                                    lane_bcast(m_dead, sl) != 0u, lane, acc, tb, s_pass, n_visited, n_batch, n_list, upart);
             ++n_visited;
             if (tr_now && threadIdx.x == 0) { tr[2] = wall_clock64(); tr[5] = s_pass.n; }
         }
     }
     if (n_batch)                                       // workgroup-uniform
-        pass_flush(set, st, fp, dcT, cm, km, wave_cnt, alive, tile_dead, keyT, undo, N, exempt, n_batch, wave, lane, acc, tb, s_pass);
+        pass_flush<SPLIT>(set, st, fp, dcT, cm, km, wave_cnt, alive, tile_dead, keyT, undo, N, exempt, n_batch, wave, lane, acc, tb, s_pass);
     __syncthreads();
     if (lane == 0) { s_a[wave] = acc.vis; s_b[wave] = acc.killed; s_c[wave] = acc.nconf; }
     __syncthreads();
     if (threadIdx.x == 0) {
         const uint32_t nv = s_a[0] + s_a[1] + s_a[2] + s_a[3], nk = s_b[0] + s_b[1] + s_b[2] + s_b[3];
-        part[bid] = make_uint4(nv, sskip, nk, cskip);
+        part[wid] = make_uint4(nv, sskip, nk, cskip);
         const uint32_t nc = s_c[0] + s_c[1] + s_c[2] + s_c[3];
-        if (nc) atomicAdd(&conf_sub[(bid & 63u) * SUB_STRIDE], nc);      // 64 counters, <= 32 adders each: one load per lane to read the total
-        if (nv) atomicAdd(&frame_sub[(bid & 63u) * SUB_STRIDE], nv);
-        if (nk) atomicAdd(&frame_sub[SUB_SET + (bid & 63u) * SUB_STRIDE], nk);
+        if (nc) atomicAdd(&conf_sub[(wid & 63u) * SUB_STRIDE], nc);      // 64 counters, <= 32 adders each: one load per lane to read the total
+        if (nv) atomicAdd(&frame_sub[(wid & 63u) * SUB_STRIDE], nv);
+        if (nk) atomicAdd(&frame_sub[SUB_SET + (wid & 63u) * SUB_STRIDE], nk);
         if (tr) {
             uint32_t hw;
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));

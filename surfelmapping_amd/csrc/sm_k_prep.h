@@ -105,7 +105,6 @@ __device__ __forceinline__ void tile_prep_block(const FrameParams &fp, const Til
 {
     __shared__ uint32_t s_sk[2][16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int j = lane >> 3, c = lane & 7;                       // tile within the wave's 8, box corner
     // Concurrent with the previous frame's association (k_assoc_prep): the slot count that association will publish is
     // offset + (its candidate pixels); tiles it can still change must not be skipped on stale bounds.  Those are the tiles
     // from the old end on (appends) and the tiles that frame drew into the index map (a fuse moves a surfel: its box may
@@ -121,30 +120,31 @@ __device__ __forceinline__ void tile_prep_block(const FrameParams &fp, const Til
         first_new_tile = off / (uint32_t)TILE;
     }
     const uint32_t ntiles = (N + TILE - 1) / TILE;
-    const uint32_t per_wg = (blockDim.x >> 6) * 8u, blk = blockIdx.x - first_block;
-    uint32_t cskip = 0, sskip = 0;                               // lane c == 0 of every tile accumulates
-    for (uint32_t base = blk * per_wg; base < ntiles; base += tp.nfb * per_wg) {   // workgroup-uniform
-        const uint32_t t = base + (uint32_t)wave * 8u + (uint32_t)j;
-        const bool in = t < ntiles;
-        const uint32_t *bd = tp.tb + (size_t)(in ? t : 0u) * 8;
-        const uint32_t b0 = bd[0], b1 = bd[1], b2 = bd[2], b3 = bd[3], b4 = bd[4], b5 = bd[5], b6 = bd[6], b7 = bd[7];
-        const float3 p = xform3(fp.t_inv, (c & 1) ? ord2f(b4) : ord2f(~b0), (c & 2) ? ord2f(b5) : ord2f(~b1),
-                                (c & 4) ? ord2f(b6) : ord2f(~b2));
-        const bool fin = (p.x - p.x == 0.0f) && (p.y - p.y == 0.0f) && (p.z - p.z == 0.0f);
-        const float gd = plane_guard(fp, ord2f(~b0), ord2f(~b1), ord2f(~b2), ord2f(b4), ord2f(b5), ord2f(b6));
-        const bool r_ = fp.fx * p.x + (fp.cx - fp.cols - 2.0f) * p.z > gd;
-        const bool lc = fp.fx * p.x + (fp.cx - fp.stereo_border + 2.0f) * p.z < -gd;
-        const bool ls = fp.fx * p.x + (fp.cx + 2.0f) * p.z < -gd;
-        const bool be = fp.fy * p.y + (fp.cy - fp.rows - 2.0f) * p.z > gd;
-        const bool ab = fp.fy * p.y + (fp.cy + 2.0f) * p.z < -gd;
-        float zmin = p.z, zmax = p.z;
+    // ONE tile per thread, its eight box corners one after the other.  (Round 2 spread the corners over eight lanes -- an eighth of
+    // the arithmetic per lane -- which at 7 000 tiles made this 256 workgroups of k_assoc_prep's grid: together with the
+    // association and the image tiles more than the chip holds at once, and the last image tiles started 7 us into an 11 us
+    // launch.  The arithmetic is ~200 instructions per tile either way; this form is 29 workgroups.)
+    const uint32_t per_wg = blockDim.x, blk = blockIdx.x - first_block;
+    uint32_t cskip = 0, sskip = 0;
+    for (uint32_t t = blk * per_wg + threadIdx.x; t < ntiles; t += tp.nfb * per_wg) {
+        const uint4 lo = ((const uint4 *)tp.tb)[(size_t)t * 2], hi = ((const uint4 *)tp.tb)[(size_t)t * 2 + 1];
+        const uint32_t b0 = lo.x, b1 = lo.y, b2 = lo.z, b3 = lo.w, b4 = hi.x, b5 = hi.y, b6 = hi.z, b7 = hi.w;
+        const float x0 = ord2f(~b0), y0 = ord2f(~b1), z0 = ord2f(~b2), x1 = ord2f(b4), y1 = ord2f(b5), z1 = ord2f(b6);
+        const float gd = plane_guard(fp, x0, y0, z0, x1, y1, z1);
+        bool finite = true, right = true, left_c = true, left_s = true, below = true, above = true;
+        float zmin = 0.f, zmax = 0.f;
 #pragma unroll
-        for (int o = 1; o < 8; o <<= 1) { zmin = fminf(zmin, __shfl_xor(zmin, o)); zmax = fmaxf(zmax, __shfl_xor(zmax, o)); }
-        const int sh = j * 8;                                      // "all 8 corners" = the tile's byte of the ballot is 0xFF
-        const bool finite = ((__ballot(fin) >> sh) & 0xFFull) == 0xFFull;
-        const bool right = ((__ballot(r_) >> sh) & 0xFFull) == 0xFFull, left_c = ((__ballot(lc) >> sh) & 0xFFull) == 0xFFull;
-        const bool left_s = ((__ballot(ls) >> sh) & 0xFFull) == 0xFFull, below = ((__ballot(be) >> sh) & 0xFFull) == 0xFFull;
-        const bool above = ((__ballot(ab) >> sh) & 0xFFull) == 0xFFull;
+        for (int c = 0; c < 8; ++c) {
+            const float3 p = xform3(fp.t_inv, (c & 1) ? x1 : x0, (c & 2) ? y1 : y0, (c & 4) ? z1 : z0);
+            finite = finite && (p.x - p.x == 0.0f) && (p.y - p.y == 0.0f) && (p.z - p.z == 0.0f);
+            right = right && (fp.fx * p.x + (fp.cx - fp.cols - 2.0f) * p.z > gd);
+            left_c = left_c && (fp.fx * p.x + (fp.cx - fp.stereo_border + 2.0f) * p.z < -gd);
+            left_s = left_s && (fp.fx * p.x + (fp.cx + 2.0f) * p.z < -gd);
+            below = below && (fp.fy * p.y + (fp.cy - fp.rows - 2.0f) * p.z > gd);
+            above = above && (fp.fy * p.y + (fp.cy + 2.0f) * p.z < -gd);
+            zmin = c ? fminf(zmin, p.z) : p.z;
+            zmax = c ? fmaxf(zmax, p.z) : p.z;
+        }
         uint32_t f = 0;
         if (fp.use_bounds && b3 == 0u) {
             if (b0 == 0u && b4 == 0u) {
@@ -157,12 +157,10 @@ __device__ __forceinline__ void tile_prep_block(const FrameParams &fp, const Til
             }
         }
         if (tp.grp_cand && (t >= first_new_tile || ((b0 | b4) != 0u && ord2f(b7) >= (float)tp.prev_time))) f = 0u;
-        if (in && c == 0) {
-            const uint32_t tn = min((uint32_t)TILE, N - t * TILE);
-            tp.tile_flags[t] = (uint8_t)f;
-            if (f & 1u) { tp.wave_cnt[t] = make_uint4(0u, 0u, 0u, 0u); cskip += tn; }
-            if (f & 2u) sskip += tn;
-        }
+        const uint32_t tn = min((uint32_t)TILE, N - t * TILE);
+        tp.tile_flags[t] = (uint8_t)f;
+        if (f & 1u) { tp.wave_cnt[t] = make_uint4(0u, 0u, 0u, 0u); cskip += tn; }
+        if (f & 2u) sskip += tn;
     }
     cskip = wave_sum_u32(cskip); sskip = wave_sum_u32(sskip);
     if (lane == 0) { s_sk[0][wave] = cskip; s_sk[1][wave] = sskip; }

@@ -282,13 +282,17 @@ def test_async_frames_overlap_the_depth_filter_chain():
     assert o.counts()["count"] > 5000
 
 
-@pytest.mark.parametrize("env", [{"SM_COMPACT_TICKETS": "1"}, {"SM_DEFER_ASSOC": "0"}, {"SM_PASS_TRACE": "@tmp"}])
+@pytest.mark.parametrize("env", [{"SM_COMPACT_TICKETS": "1"}, {"SM_DEFER_ASSOC": "0"}, {"SM_PASS_TRACE": "@tmp"},
+                                 {"SM_TWO_LAUNCH": "0"}, {"SM_PASS_SPLIT": "1"}])
 def test_kernel_variants_behind_switches_stay_bit_exact(env):
     """The switches that are left after round 3's pruning (the rejected kernel variants are gone).  SM_COMPACT_TICKETS=1: the
     in-place compaction hands its moving tiles out from a ticket counter (the form used as soon as two contexts share a GPU: no
     co-residency assumption).  SM_DEFER_ASSOC=0: every asynchronous frame launches its own association instead of handing it
     to the next frame's preparation launch (k_assoc_prep).  SM_PASS_TRACE: the per-workgroup time stamps of tools/pass_trace.py
-    must not change a result.  Each runs the deferred-compaction and fuzz tests in a child process."""
+    must not change a result.  SM_TWO_LAUNCH=0: the fixup step (publisher, cap repair, candidate count) keeps its own launch
+    between the pass and the association instead of riding on the next frame's preparation launch.  SM_PASS_SPLIT=1: k_surfel_pass
+    takes whole tiles per workgroup on small models too (the default there is a quarter tile; large models use whole tiles
+    anyway).  Each runs the deferred-compaction and fuzz tests in a child process."""
     import subprocess
     import sys
     import tempfile

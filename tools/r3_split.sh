@@ -1,0 +1,23 @@
+#!/bin/bash
+# quarter-tile units in k_surfel_pass: parity subset under both forms, then A/B bench lines.  usage: tools/r3_split.sh <tag>
+tag=${1:-r3split}
+timeout -k 10 600 python -m pytest tests/test_kat.py tests/test_gpu_parity.py tests/test_deferred_compaction.py tests/test_fuzz_gpu.py tests/test_shard_stream.py -m gpu -x -q > gpurun_out/${tag}_pytest.log 2>&1; rc=$?
+tail -n 3 gpurun_out/${tag}_pytest.log; [ $rc -ne 0 ] && exit 1
+SM_PASS_SPLIT=4 timeout -k 10 600 python -m pytest tests/test_configs_full_size.py tests/test_rig.py -m gpu -x -q > gpurun_out/${tag}_pytest4.log 2>&1; rc=$?
+tail -n 3 gpurun_out/${tag}_pytest4.log; [ $rc -ne 0 ] && exit 1
+SM_PASS_SPLIT=1 timeout -k 10 600 python -m pytest tests/test_kat.py tests/test_deferred_compaction.py tests/test_fuzz_gpu.py -m gpu -x -q > gpurun_out/${tag}_pytest1.log 2>&1; rc=$?
+tail -n 3 gpurun_out/${tag}_pytest1.log; [ $rc -ne 0 ] && exit 1
+run() { # name, env..., -- bench args
+  name=$1; shift
+  env "$@" timeout -k 10 300 python bench.py $BARGS --only-headline --no-cpu-baseline > gpurun_out/${tag}_$name.json 2>> gpurun_out/${tag}_bench.err || return 1
+  python - gpurun_out/${tag}_$name.json $name <<PY
+import json,sys
+d=json.load(open(sys.argv[1])); k=d['kernels']
+print(sys.argv[2], "value", round(d["value"]), round(d["ms_per_step"]*1e3,2), "us", {n:round(v['ms']*1e3,1) for n,v in k.items() if n in('k_assoc_prep','k_surfel_pass','k_pass_fixup')})
+PY
+}
+for cfg in "20 5" "100 10"; do set -- $cfg; BARGS="--steps $1 --warmup $2"
+  run s1_$1 SM_PASS_SPLIT=1 && run s4_$1 SM_PASS_SPLIT=4 && run s4q384_$1 SM_PASS_SPLIT=4 SM_PASS_SEQ=384 && run s4q256_$1 SM_PASS_SPLIT=4 SM_PASS_SEQ=256 || exit 1
+done
+BARGS="--workload hd20m --steps 40 --warmup 5"
+run hd_s1 SM_PASS_SPLIT=1 && run hd_s4 SM_PASS_SPLIT=4
