@@ -369,6 +369,7 @@ struct sm_ctx {
     // two-launch frame: the fixup step (publisher, cap repair) of a frame whose association is held back rides on the same
     // launch as that association; the candidate count moved into the pass's launch
     bool two_launch = false;           // this context uses it (defer_ok, SM_TWO_LAUNCH != 0)
+    uint32_t est_fr0 = 0, est_slots0 = 0, est_rate = 0xFFFFFFFFu;   // launch_surfel_pass's estimate of the slots per frame (from the pinned statistic)
     bool fix_pending = false;          // the last frame's fixup has not run yet
     FixArgs fix_args{};
     static constexpr uint32_t N_CREW = 32;
@@ -679,7 +680,13 @@ int launch_surfel_pass(sm_ctx *s, const FrameParams &fp, bool timed, bool direct
     {
         const unsigned long long v = __atomic_load_n(s->h_stat, __ATOMIC_RELAXED);
         const uint32_t fr = (uint32_t)(v >> 32), slots = (uint32_t)v;
-        if (s->frames_enq >= fr) slots_est = std::min<uint64_t>(slots_est, (uint64_t)slots + (uint64_t)(s->frames_enq - fr) * s->n_odd_pixels);
+        // growth per frame as the device has reported it (between two reports at least 8 frames apart), at most a frame's candidates
+        if (fr < s->est_fr0 || slots < s->est_slots0) { s->est_fr0 = fr; s->est_slots0 = slots; }      // (a compaction, a reset: the rate stands)
+        else if (fr >= s->est_fr0 + 8u) {
+            s->est_rate = std::min<uint32_t>((slots - s->est_slots0) / (fr - s->est_fr0) + 1u, s->n_odd_pixels);
+            s->est_fr0 = fr; s->est_slots0 = slots;
+        }
+        if (s->frames_enq >= fr) slots_est = std::min<uint64_t>(slots_est, (uint64_t)slots + (uint64_t)(s->frames_enq - fr) * s->est_rate);
     }
     const uint64_t tiles_b = (slots_est + TILE - 1) / TILE;
     const bool persistent = tiles_b > (uint64_t)4 * MAX_GRID;
