@@ -2400,7 +2400,7 @@ int sm_shard_frame_device(sm_ctx *s, const uint8_t *d_rgb, const uint16_t *d_dep
     s->want_list = false;
     if (rc <= 0) return rc;
     fp.compact_now = 0u;
-    fp.conflict_cap = 0xFFFFFFFFu;            // evaluated over all ranks by k_shard_settle
+    fp.conflict_cap = 0xFFFFFFFFu;            // applied over all ranks below (k_shard_cap_pack / k_shard_cap_repair), not per shard
     fp.shard_slots = 1;
     note_cull(s, false);
     s->keys_are_slots = true;
