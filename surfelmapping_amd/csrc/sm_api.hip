@@ -308,7 +308,7 @@ struct sm_ctx {
     uint8_t *d_tile_flags_nx = nullptr; uint4 *d_wave_cnt_nx = nullptr; uint2 *d_prep_part_nx = nullptr;   // the other frame's (two-launch frame: its publisher runs next to this frame's flag workgroups)
     uint32_t *d_conf_part = nullptr;   // per-workgroup partial counters (instead of same-address atomics)
     uint2 *d_compact_part = nullptr;
-    uint4 *d_lazy_part = nullptr;      // partials of k_cull_lazy_frame / k_surfel_pass (visible, splat-skipped, killed, conflict-skipped)
+    uint4 *d_lazy_part = nullptr;      // partials of k_surfel_pass (visible, splat-skipped, killed, conflict-skipped)
     bool lazy_part_live = false;       // the next append folds d_lazy_part (not d_compact_part) into the counters
     // one pass over the surfels per frame (k_surfel_pass + k_pass_fixup) on the frames whose cull only marks the dead
     uint4 *d_wave_cnt = nullptr;       // conflicts per quarter tile (one word per wave)
@@ -320,7 +320,7 @@ struct sm_ctx {
     bool ev_direct[EV_RING] = {};      // ... and appended directly
     bool ev_merged[EV_RING] = {};      // the frame's preparation launch was k_assoc_prep (it carried the previous frame's association)
     bool ev_deferred[EV_RING] = {};    // the frame's own association was held back (no kernel between its marks 4 and 5)
-    // tile skip flags of the frame, evaluated by extra workgroups of k_prep (when k_prep runs after the previous frame: no second stream)
+    // tile skip flags of the frame, evaluated by extra workgroups of the preparation launch
     uint2 *d_prep_part = nullptr;
     uint32_t n_prep_blocks = 0;        // flag workgroups the frame's k_prep ran (0: the pass kernel evaluates the flags itself)
     bool want_list = false;            // set by enqueue_frame before begin_frame launches k_prep
@@ -1029,7 +1029,7 @@ int begin_frame(sm_ctx *s, const uint8_t *d_rgb, const uint16_t *d_raw, const ui
     // The reference frame and the frame after reset() do not draw the index map: its textures keep what the last
     // predictIndices left (src/SurfelMapping.cpp:142-169), so the key map is neither cleared nor exchanged then.
     const bool will_splat = fusing;
-    // frame parity: the conflict sub-counters (and, where a second stream exists, the frame planes) alternate between two
+    // frame parity: the conflict sub-counters, the frame planes and the per-frame scratch of the fixup step alternate between two
     // sets, so that the pre-processing of frame f+1 never touches what frame f still reads
     s->plane_set ^= 1;
     s->conf_sub_set = s->plane_set;
@@ -1107,7 +1107,7 @@ int enqueue_frame(sm_ctx *s, const uint8_t *d_rgb, const uint16_t *d_raw, const 
     if (s->ss_on) { g_err = "context is configured for sharding: use the sm_shard_* entry points"; return SM_E_ARG; }
     FrameParams fp;
     // the cull's kind is decided first: a frame whose cull only marks the dead lets k_prep evaluate the tile skip flags for
-    // the one-pass surfel kernel (not when k_prep runs ahead of the previous frame on the second stream)
+    // the one-pass surfel kernel
     const bool fusing = s->ref_set && s->tick != 0 && !s->pending_cull;
     const bool compact_now = fusing ? decide_compact(s) : true;
     s->want_list = fusing && !compact_now;

@@ -587,7 +587,7 @@ __global__ __launch_bounds__(PIX_BLOCK) void k_append_scan(Model M, DevState *__
                                                            uint32_t n_compact_part, uint64_t *__restrict__ alive,
                                                            uint32_t *__restrict__ tile_dead,
                                                            unsigned long long *__restrict__ host_stat,
-                                                           const uint4 *__restrict__ lazy_part /* k_cull_lazy_frame's / k_surfel_pass's partials (then compact_part is unused) */,
+                                                           const uint4 *__restrict__ lazy_part /* k_surfel_pass's partials (then compact_part is unused) */,
                                                            const uint2 *__restrict__ fix_part /* k_pass_fixup's (visible added, resurrected), read when the cap bound; or null */,
                                                            uint32_t n_fix_part)
 {
