@@ -54,6 +54,11 @@ METRIC = "frames/sec per GPU, 1242x375 KITTI-shaped RGB-D+semantic, full associa
 # ------------------------------------------------------------------------------------------------
 # synthetic frames (CPU only; forked workers never touch a GPU)
 # ------------------------------------------------------------------------------------------------
+
+def ordinal(n):
+    """16 -> '16th', 32 -> '32nd'"""
+    return f"{n}{'th' if 10 <= n % 100 <= 20 else {1: 'st', 2: 'nd', 3: 'rd'}.get(n % 10, 'th')}"
+
 def rig_trajectory(n, rank, world, step=0.8):
     """Camera `rank` of a `world`-camera rig: same forward motion, yaw offset rank*360/world deg
     (BASELINE configs[4] / SURVEY 8d config 5); world == 1 is the plain KITTI trajectory."""
@@ -626,7 +631,7 @@ def bench_single(args, cam, K, Wm, workers, emit):
                                + (" + depth pre-processing p0b..p0e" if args.preprocess else ""),
                    "frames": f"{Wm}..{Wm + K - 1}", "multi_gpu": "single stream",
                    "host_sync": "per frame" if args.sync_every_frame else "none inside the timed region",
-                   "compaction": (f"deferred: culled surfels keep their slots, every {args.compact_period}th cull compacts "
+                   "compaction": (f"deferred: culled surfels keep their slots, every {ordinal(args.compact_period)} cull compacts "
                                   f"({int((log['n_static'] < log['n_slots']).sum()) if len(log) else 0} of {K} timed frames moved surfels)")
                                  if args.compact_period > 1 else "every frame",
                    "surfels_start": int(log["n_before"][0]) if len(log) else 0, "surfels_end": int(counts["count"])},
