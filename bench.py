@@ -225,7 +225,7 @@ def kernel_table(log, tim, P, K, warmup, compact_period, workload):
         kern[name] = {"ms": ms, "MB": mb, "GBs": (mb / 1e3) / (ms * 1e-3) if ms > 0 else None, "launches": n}
         launches[name] = n
     if K - n_op > 0:
-        kern["k_scan_cull+k_cull_finalize"] = {"ms": tim["k_scan_cull"] * K / max(K - n_op, 1), "MB": None, "GBs": None, "launches": K - n_op}
+        kern["k_scan_cull+k_cull_finalize"] = {"ms": tim.get("k_scan_own", 0.0), "MB": None, "GBs": None, "launches": K - n_op}
     # HBM bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this very command
     # (profiles/README.md), gfx950-corrected per kernel by tools/prof_summary.py
     tj = None

@@ -100,6 +100,7 @@ typedef struct sm_timings {
      * (k_assoc_prep); k_prep_own / k_associate_direct then average only over the frames that launched those kernels alone */
     float k_assoc_prep, k_prep_own;
     uint32_t frames_merged, frames_assoc_alone;
+    float k_scan_own;         /* k_scan_cull + k_cull_finalize, averaged over the frames that ran k_conflict */
 } sm_timings;
 
 /* Per-frame counters written by the device at the end of every fusing frame (ring of

@@ -69,7 +69,7 @@ class SmTimings(C.Structure):
                         ("k_cull_lazy", C.c_float), ("frames_compact", C.c_uint32)] + [(n, C.c_float) for n in (
         "k_surfel_pass", "k_pass_fixup", "k_conflict_own", "k_associate_direct", "k_associate_own", "k_append_own")] + [
         ("frames_one_pass", C.c_uint32), ("frames_direct", C.c_uint32), ("k_assoc_prep", C.c_float), ("k_prep_own", C.c_float),
-        ("frames_merged", C.c_uint32), ("frames_assoc_alone", C.c_uint32)]
+        ("frames_merged", C.c_uint32), ("frames_assoc_alone", C.c_uint32), ("k_scan_own", C.c_float)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

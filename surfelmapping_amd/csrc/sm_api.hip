@@ -1993,6 +1993,7 @@ int sm_stage_timings(sm_ctx *s, sm_timings *out)
     double seg[7] = {0}, run = 0, ovh = 0, cull[2] = {0, 0};
     double own[6] = {0};          // pass, fixup (one-pass frames) | conflict (others) | associate (direct) | associate, append (others)
     double prep2[2] = {0, 0};     // k_prep alone | k_assoc_prep
+    double scan_own = 0;          // k_scan_cull + k_cull_finalize on the frames that ran k_conflict
     uint32_t nfr = 0, ncls[2] = {0, 0}, n_op = 0, n_dir = 0, n_merged = 0, n_alone = 0;
     for (uint64_t f = first; f < s->ev_frames; ++f) {
         const int slot = (int)(f % EV_RING);
@@ -2010,7 +2011,7 @@ int sm_stage_timings(sm_ctx *s, sm_timings *out)
         for (int k = 0; k < 7; ++k) seg[k] += loc[k];
         cull[s->ev_compacted[slot] ? 1 : 0] += loc[3];
         ncls[s->ev_compacted[slot] ? 1 : 0]++;
-        if (s->ev_one_pass[slot]) { own[0] += loc[1]; own[1] += loc[3]; n_op++; } else own[2] += loc[1];
+        if (s->ev_one_pass[slot]) { own[0] += loc[1]; own[1] += loc[3]; n_op++; } else { own[2] += loc[1]; scan_own += loc[2]; }
         if (s->ev_direct[slot]) { n_dir++; if (!s->ev_deferred[slot]) { own[3] += loc[4]; n_alone++; } } else { own[4] += loc[4]; own[5] += loc[6]; }
         prep2[s->ev_merged[slot] ? 1 : 0] += loc[0];
         if (s->ev_merged[slot]) n_merged++;
@@ -2035,6 +2036,7 @@ int sm_stage_timings(sm_ctx *s, sm_timings *out)
         out->frames_compact = ncls[1];
         auto avg = [&](double sum, uint32_t n) { return n ? (float)std::max(0.0, sum / n - oh) : 0.0f; };
         out->k_surfel_pass = avg(own[0], n_op); out->k_pass_fixup = avg(own[1], n_op); out->k_conflict_own = avg(own[2], nfr - n_op);
+        out->k_scan_own = avg(scan_own, nfr - n_op);
         out->k_associate_direct = avg(own[3], n_alone); out->k_associate_own = avg(own[4], nfr - n_dir); out->k_append_own = avg(own[5], nfr - n_dir);
         out->frames_one_pass = n_op; out->frames_direct = n_dir;
         out->k_assoc_prep = avg(prep2[1], n_merged); out->k_prep_own = avg(prep2[0], nfr - n_merged);
