@@ -686,10 +686,14 @@ int launch_surfel_pass(sm_ctx *s, const FrameParams &fp, bool timed, bool direct
             s->est_rate = std::min<uint32_t>((slots - s->est_slots0) / (fr - s->est_fr0) + 1u, s->n_odd_pixels);
             s->est_fr0 = fr; s->est_slots0 = slots;
         }
-        if (s->frames_enq >= fr) slots_est = std::min<uint64_t>(slots_est, (uint64_t)slots + (uint64_t)(s->frames_enq - fr) * s->est_rate);
+        // (a compaction comes at least every `compact_period` frames: the slots do not grow for longer than that)
+        const uint32_t ahead = std::min<uint32_t>(s->frames_enq - fr, (uint32_t)std::max(s->cfg.compact_period, 1));
+        if (s->frames_enq >= fr) slots_est = std::min<uint64_t>(slots_est, (uint64_t)slots + (uint64_t)ahead * s->est_rate);
     }
     const uint64_t tiles_b = (slots_est + TILE - 1) / TILE;
-    const bool persistent = tiles_b > (uint64_t)4 * MAX_GRID;
+    static const int pers_env = std::getenv("SM_PASS_PERSIST_TILES") ? std::atoi(std::getenv("SM_PASS_PERSIST_TILES")) : 0;
+    // (8 192 / 16 384 / never on 100 and 200 KITTI frames: 38.7 / 38.4 / 38.5 us per frame -- the two forms are level there)
+    const bool persistent = tiles_b > (uint64_t)(pers_env > 0 ? pers_env : 8 * MAX_GRID);
     // Quarter-tile units (k_surfel_pass<4>: four workgroups per tile sequence) while tiles are few and some of them dense; whole
     // tiles once every workgroup owns many (the scattered 20 M-surfel model: ~50 listed slots per tile, batches of 8 tiles)
     static const int split_env = std::getenv("SM_PASS_SPLIT") ? std::atoi(std::getenv("SM_PASS_SPLIT")) : 0;
