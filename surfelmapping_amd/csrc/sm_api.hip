@@ -692,8 +692,9 @@ int launch_surfel_pass(sm_ctx *s, const FrameParams &fp, bool timed, bool direct
     }
     const uint64_t tiles_b = (slots_est + TILE - 1) / TILE;
     static const int pers_env = std::getenv("SM_PASS_PERSIST_TILES") ? std::atoi(std::getenv("SM_PASS_PERSIST_TILES")) : 0;
-    // (8 192 / 16 384 / never on 100 and 200 KITTI frames: 38.7 / 38.4 / 38.5 us per frame -- the two forms are level there)
-    const bool persistent = tiles_b > (uint64_t)(pers_env > 0 ? pers_env : 8 * MAX_GRID);
+    // (8 192 / 16 384 / never on 100 and 200 KITTI frames: 38.7 / 38.4 / 38.5 us per frame -- the two forms are level there, and a
+    //  scattered model pays 1.5x for quarter tiles at 20 M surfels: the lower threshold stays)
+    const bool persistent = tiles_b > (uint64_t)(pers_env > 0 ? pers_env : 4 * MAX_GRID);
     // Quarter-tile units (k_surfel_pass<4>: four workgroups per tile sequence) while tiles are few and some of them dense; whole
     // tiles once every workgroup owns many (the scattered 20 M-surfel model: ~50 listed slots per tile, batches of 8 tiles)
     static const int split_env = std::getenv("SM_PASS_SPLIT") ? std::atoi(std::getenv("SM_PASS_SPLIT")) : 0;
