@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define SM_API_VERSION 1
+#define SM_API_VERSION 3   /* bumped whenever a struct or an entry point changes (3: round 3 -- asynchronous host path, rig step, sm_timings::k_scan_own; the staged shard entry points are gone) */
 
 /* error codes (reference: void returns + CheckGlDieOnError(); bool for map IO) */
 enum {

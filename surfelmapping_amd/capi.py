@@ -12,6 +12,7 @@ import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libsurfelmapping_hip.so")
+API_VERSION = 3                # SM_API_VERSION of include/sm_c_api.h
 
 SM_OK, SM_E_ARG, SM_E_CAPACITY, SM_E_UNSUPPORTED, SM_E_HIP, SM_E_NO_DEVICE = 0, -1, -2, -3, -4, -5
 TEX_DEPTH_METRIC, TEX_DEPTH_FILTERED, TEX_LAST = 0, 1, 2
@@ -157,6 +158,9 @@ def load():
     L = C.CDLL(LIB_PATH)
     vp, u32p = C.c_void_p, C.POINTER(C.c_uint32)
     L.sm_api_version.restype = C.c_int
+    if L.sm_api_version() != API_VERSION:     # a stale build: the struct layouts below would not match
+        raise ImportError(f"{LIB_PATH} has API version {L.sm_api_version()}, this binding expects {API_VERSION}: rebuild it "
+                          "(python -c 'import __graft_entry__ as g; g.build()')")
     L.sm_last_error.restype = C.c_char_p
     L.sm_default_config.argtypes = [C.POINTER(SmConfig), C.c_int, C.c_int] + [C.c_float] * 4
     L.sm_create.restype = vp
