@@ -90,7 +90,8 @@ typedef struct sm_timings {
     float k_cull_lazy;        /* k_cull_lazy, averaged over the frames that only marked the dead */
     uint32_t frames_compact;  /* how many of `frames` compacted */
     /* the frame forms of the default path, each kernel averaged over the frames that ran it:
-     * one-pass frames (the cull only marks the dead): k_surfel_pass (conflict + cull + splat) and k_pass_fixup;
+     * one-pass frames (the cull only marks the dead): k_surfel_pass (conflict + cull + splat) and k_pass_fixup (0 where the
+     * fixup step rides on the next frame's preparation launch: the two-launch frame of asynchronous streams);
      * direct-append frames: k_associate_direct (association + fuse + append); the other frames run k_conflict
      * (+ k_scan_cull + k_cull_finalize + k_compact) and k_associate + k_append_scan */
     float k_surfel_pass, k_pass_fixup, k_conflict_own;
