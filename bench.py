@@ -128,16 +128,21 @@ def launch_ranks(args, argv):
         kids = sorted((json.loads(o.strip().splitlines()[-1]) for o in outs), key=lambda d: d["rank"])
         print(json.dumps({"launch_dry_run": True, "n_gpus": n, "ranks": [k["rank"] for k in kids], "children": kids}))
         return
-    lines = [ln for ln in outs[0].splitlines() if ln.strip()]
-    if len(lines) != 1:
-        sys.stderr.write(f"bench.py: rank 0 printed {len(lines)} lines, expected one\n")
+    # rank 0's JSON line is the run's one line of stdout; anything else a rank (or a library inside it) wrote to stdout goes to
+    # stderr, so that a banner cannot cost the measurement
+    result = None
+    for r, out in enumerate(outs):
+        for ln in out.splitlines():
+            if not ln.strip():
+                continue
+            if r == 0 and ln.lstrip().startswith("{") and '"metric"' in ln:
+                result = ln
+            else:
+                sys.stderr.write(f"[rank {r} stdout] {ln}\n")
+    if result is None:
+        sys.stderr.write("bench.py: rank 0 printed no result line\n")
         raise SystemExit(1)
-    stray = [r for r in range(1, n) if outs[r].strip()]
-    if stray:
-        sys.stderr.write(f"bench.py: ranks {stray} wrote to stdout\n")
-        raise SystemExit(1)
-    print(lines[0])
-
+    print(result)
 
 def dry_run_rank(rank, world, local_rank):
     """--launch-dry-run: what a child would bind to, plus a gloo all-reduce over the ranks (proves the rendezvous the launcher
@@ -384,20 +389,30 @@ def bench_ranks(args, cam, rank, world, local_rank, K, Wm, workers, emit):
     if world == 1:                         # --force-dist outside a launcher: a one-rank rendezvous of its own
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", str(_free_port()))
+    # --rehearse-one-gpu: every rank on GPU 0, torch.distributed over gloo, the core's collectives staged through the host
+    # (sharded.GlooCollective) -- the whole multi-process flow where RCCL cannot run (it refuses two ranks on one device)
+    reh = args.rehearse_one_gpu
+    if reh:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    if reh:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    else:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    tdev = torch.device("cpu") if reh else dev     # where the handful of scalars torch.distributed reduces live
     from surfelmapping_amd import capi
     from surfelmapping_amd import dist as smd
     from surfelmapping_amd import sharded as smsh
-    os.environ.setdefault("SM_COMPACT_TICKETS", "0")     # this process's contexts never run at the same time
+    if not reh:
+        os.environ.setdefault("SM_COMPACT_TICKETS", "0")     # this process's contexts never run at the same time (rehearsal: the ranks share the GPU, the core finds out by itself)
 
     def barrier():
         dist.barrier()
         torch.cuda.synchronize()
 
     def max_over_ranks(x):
-        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        t = torch.tensor([x], dtype=torch.float64, device=tdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t[0])
 
@@ -415,8 +430,12 @@ def bench_ranks(args, cam, rank, world, local_rank, K, Wm, workers, emit):
     # camera's latest view): one step after the warm-up, one after the timed frames -- the second is timed, outside `value`
     sm_inc = capi.SurfelMap(capi.make_config(**cam, preprocess=0, device=local_rank, max_sqrt_vertices=msv_global))
     rig = smd.RigMapper(sm, smsh.TorchComm(device_index=local_rank), P)
-    rig.enable_native("rccl", bcast_id())
-    nranks_rig = sm.shard_rccl_nranks()
+    if reh:
+        rig.enable_native(smsh.GlooCollective(sm))
+        nranks_rig = None
+    else:
+        rig.enable_native("rccl", bcast_id())
+        nranks_rig = sm.shard_rccl_nranks()
     gc.collect(); gc.disable()
     for k in range(Wm):
         sm.process_frame_device(*dptr[k])
@@ -434,10 +453,10 @@ def bench_ranks(args, cam, rank, world, local_rank, K, Wm, workers, emit):
     gc.enable()
     elapsed = max_over_ranks(own)
     log = sm.read_frame_log(K)
-    fu = torch.tensor([float(log["fused_count"].sum()), float(log["unstable_count"].sum())], dtype=torch.float64, device=dev)
+    fu = torch.tensor([float(log["fused_count"].sum()), float(log["unstable_count"].sum())], dtype=torch.float64, device=tdev)
     dist.all_reduce(fu, op=dist.ReduceOp.SUM)
     F_total, U_total = float(fu[0]), float(fu[1])
-    own_t = torch.tensor([own], dtype=torch.float64, device=dev)
+    own_t = torch.tensor([own], dtype=torch.float64, device=tdev)
     dist.broadcast(own_t, src=0)
     plain_ms = float(own_t[0]) / K * 1e3           # rank 0's camera IS the shared stream: the plain single-GPU time of those frames
     # ---- consolidation into a single GlobalModel (sm_rig_consolidate: all-gathers + per-slice cleanPoints, inside the core)
@@ -454,7 +473,8 @@ def bench_ranks(args, cam, rank, world, local_rank, K, Wm, workers, emit):
     global_count, view_conflicts = rig.consolidate_native(sm_global)
     torch.cuda.synchronize()
     gather_ms = max_over_ranks((time.perf_counter() - g0) * 1e3)
-    sm.shard_rccl_finalize()
+    if not reh:
+        sm.shard_rccl_finalize()
     counts = sm.counts()
     sm_global.close()
     sm.close()
@@ -462,8 +482,8 @@ def bench_ranks(args, cam, rank, world, local_rank, K, Wm, workers, emit):
     sharded_leg = None
     if not args.no_sharded_leg:
         ss = capi.SurfelMap(capi.make_config(**cam, **cfg))
-        shard = smsh.StreamShard(ss, rank, world, "rccl", bcast_id())
-        nranks_sh = ss.shard_rccl_nranks()
+        shard = smsh.StreamShard(ss, rank, world, smsh.GlooCollective(ss)) if reh else smsh.StreamShard(ss, rank, world, "rccl", bcast_id())
+        nranks_sh = None if reh else ss.shard_rccl_nranks()
         dsh = stage_frames(ss, shared, P)
         gc.collect(); gc.disable()
         for k in range(Wm):
@@ -480,10 +500,11 @@ def bench_ranks(args, cam, rank, world, local_rank, K, Wm, workers, emit):
         gc.enable()
         s_el = max_over_ranks(s_own)
         sc = ss.counts()
-        chk = torch.tensor([sc["count"], sc["conflict_count"], sc["unstable_count"]], dtype=torch.int64, device=dev)
+        chk = torch.tensor([sc["count"], sc["conflict_count"], sc["unstable_count"]], dtype=torch.int64, device=tdev)
         lo, hi = chk.clone(), chk.clone()
         dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
-        ss.shard_rccl_finalize()
+        if not reh:
+            ss.shard_rccl_finalize()
         ss.close()
         del shard
         sharded_leg = {"config": f"BASELINE configs[3]: ONE KITTI 1242x375 stream sharded over {world} GPUs (slot-addressed shards; per frame an "
@@ -493,7 +514,7 @@ def bench_ranks(args, cam, rank, world, local_rank, K, Wm, workers, emit):
                        "plain_single_gpu_ms_per_step": plain_ms, "sharded_over_plain": (s_el / K * 1e3) / plain_ms,
                        "counters_identical_on_all_ranks": bool(torch.equal(lo, hi)), "surfels_end": int(sc["count"]),
                        "plain_surfels_end_rank0": None, "rccl_nranks": nranks_sh}
-        c0 = torch.tensor([counts["count"]], dtype=torch.int64, device=dev)
+        c0 = torch.tensor([counts["count"]], dtype=torch.int64, device=tdev)
         dist.broadcast(c0, src=0)
         sharded_leg["plain_surfels_end_rank0"] = int(c0[0])
         sharded_leg["same_surfel_count_as_plain"] = int(c0[0]) == int(sc["count"])
@@ -518,8 +539,10 @@ def bench_ranks(args, cam, rank, world, local_rank, K, Wm, workers, emit):
                                                  "new_surfels_exchanged": int(step_new), "global_model_surfels": int(step_total)},
                                  "global_model_surfels": int(global_count), "conflicts_per_view": [int(c) for c in view_conflicts]},
                    "host_sync": "none inside the timed region", "surfels_end_rank0": int(counts["count"])},
-        "rccl": {"nranks": nranks_rig, "world_size": world, "backend": "RCCL bound by the HIP core (ncclCommInitRank / ncclCommCount); torch.distributed "
-                                                                         "only hands the communicator id round"},
+        "rccl": ({"nranks": None, "world_size": world, "backend": "REHEARSAL on one GPU: torch.distributed gloo, the core's collectives staged through "
+                                                                    "the host (sharded.GlooCollective); not a measurement of anything"} if reh else
+                 {"nranks": nranks_rig, "world_size": world, "backend": "RCCL bound by the HIP core (ncclCommInitRank / ncclCommCount); torch.distributed "
+                                                                          "only hands the communicator id round"}),
         "surfels_fused_per_sec": (F_total + U_total) / elapsed,
         "fused_F": {"total": F_total, "per_sec": F_total / elapsed, "per_frame": F_total / (K * world)},
         "new_U": {"total": U_total, "per_sec": U_total / elapsed, "per_frame": U_total / (K * world)},
@@ -717,6 +740,8 @@ def main():
     ap.add_argument("--seed-surfels", type=int, default=20_000_000)
     ap.add_argument("--force-dist", action="store_true", help="rehearse the multi-GPU code path with one rank (torch.distributed + RCCL up)")
     ap.add_argument("--no-sharded-leg", action="store_true", help="N ranks: skip the ONE-stream-over-N-GPUs leg (configs[3])")
+    ap.add_argument("--rehearse-one-gpu", action="store_true",
+                    help="N ranks, all on GPU 0, gloo + host-staged collectives: rehearses the N-process flow on a 1-GPU box (not a measurement)")
     ap.add_argument("--compact-period", type=int, default=32,
                     help="deferred compaction: culled surfels keep their slots, every Nth cull squeezes them out (1: every frame)")
     ap.add_argument("--no-fuse-leg", action="store_true")

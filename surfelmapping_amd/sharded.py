@@ -114,6 +114,32 @@ class ThreadCollective:
         return 0
 
 
+class GlooCollective:
+    """The collective of sm_shard_set_collective for ranks that are PROCESSES joined by a torch.distributed group whose backend
+    works on host memory ('gloo'): staged through the host like ThreadCollective.  For rehearsing the multi-process path where
+    RCCL cannot run -- several ranks on one GPU (`bench.py --gpus N --rehearse-one-gpu`, tests/test_dist_gpu.py); production
+    uses RCCL on the context's stream (SurfelMap.shard_rccl_init)."""
+
+    def __init__(self, sm, group=None):
+        import torch.distributed as dist
+        self.sm, self.dist, self.group = sm, dist, group
+        self.world = dist.get_world_size(group)
+
+    def __call__(self, send, recv, count, op):
+        import torch
+        from .capi import SM_COLL_GATHER, SM_COLL_MIN
+        a = self.sm.device_download(send, count * 8, np.uint64)          # waits for the context's stream
+        t = torch.from_numpy(a.view(np.int64).copy())                     # (keys < 2^63: order kept; sums wrap like u64)
+        if op == SM_COLL_GATHER:
+            parts = [torch.empty_like(t) for _ in range(self.world)]
+            self.dist.all_gather(parts, t, group=self.group)
+            t = torch.cat(parts)                                          # rank q's words at recv + q * count
+        else:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN if op == SM_COLL_MIN else self.dist.ReduceOp.SUM, group=self.group)
+        self.sm.device_upload(recv, np.ascontiguousarray(t.numpy().view(np.uint64)))
+        return 0
+
+
 class StreamShard:
     """One rank of ONE camera stream sharded over `world` GPUs, in-stream form: every rank calls
     process_frame with the same arguments; counters are identical on all ranks after every frame.

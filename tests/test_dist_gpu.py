@@ -129,3 +129,27 @@ def test_other_process_on_the_gpu_is_detected(tmp_path):
             p.kill()
     time.sleep(0.2)
     assert sm.gpu_process_count() <= during - 1
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_bench_starts_two_ranks_and_they_agree_rehearsal_on_one_gpu():
+    """`python bench.py --gpus 2` as the driver calls it, rehearsed on the one GPU this box has: the parent starts two fresh
+    ranks, they rendezvous (gloo here -- RCCL refuses two ranks on one device -- with the core's collectives staged through
+    the host, sharded.GlooCollective), run the rig leg, both consolidations and the sharded leg as two PROCESSES, and rank 0
+    prints the one line.  What must hold whatever the transport: n_gpus = 2, the sharded stream's counters identical on both
+    ranks and equal to the plain single-GPU run of the same frames, a single GlobalModel out of both consolidations."""
+    import json
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse-one-gpu", "--steps", "6", "--warmup", "3",
+                        "--workers", "1", "--launch-timeout", "600"], cwd=ROOT, capture_output=True, text=True, timeout=800)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[-1500:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 6
+    sh = d["sharded_leg"]
+    assert sh["counters_identical_on_all_ranks"] is True
+    assert sh["same_surfel_count_as_plain"] is True
+    mg = d["config"]["multi_gpu"]
+    assert mg["global_model_surfels"] > 0 and mg["incremental"]["global_model_surfels"] > 0
+    assert mg["incremental"]["new_surfels_exchanged"] > 0
