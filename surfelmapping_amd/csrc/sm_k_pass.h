@@ -1,4 +1,4 @@
-// sm_k_pass.h -- the frames that only mark the dead: k_surfel_pass (p2 + p3 + p4 + p6 in one read of the model) and k_pass_fixup (frame state, candidate counts, the W*H cap's repair).
+// sm_k_pass.h -- the frames that only mark the dead: k_surfel_pass (p2 + p3 + p4 + p6 in one read of the model; candidate counts behind it) and the fixup step (frame state, the W*H cap's repair: k_pass_fixup, or the first workgroups of the next k_assoc_prep).
 // Part of sm_kernels.h (included there, in order, inside namespace sm); shader citations: /root/reference/src/Shaders/<file>:<line>.
 #pragma once
 
@@ -10,13 +10,14 @@
 //
 // The "first W*H conflicts only" rule (conflictVbo holds W*H records, src/GlobalModel.cpp:54-57) needs the
 // conflict total, which exists only after the pass: the pass therefore treats EVERY conflict as effective and
-// leaves what k_pass_fixup needs to take the surplus back, exactly, should the cap bind:
+// leaves what the fixup step (fixup_repair) needs to take the surplus back, exactly, should the cap bind:
 //   cm[word]        conflicts of the 64 slots of `word` (valid, not the id-0 surfel)
 //   km[word]        slots this pass killed BECAUSE of a conflict (alive and conf > 0 before, conf - 1 <= 0)
-//   wave_cnt[tile]  conflicts per 256-slot quarter of the tile (uint4; one word per wave, no barrier)
+//   wave_cnt[tile]  conflicts per 256-slot quarter of the tile (uint4)
 //   undo[slot]      the confidence a surviving, decremented surfel had before (restoring by +1.0f would
 //                   not be exact for every float)
-// Each wave settles four consecutive 64-slot words on its own: no LDS, no barrier inside a tile.
+// A tile (or a quarter of one) is settled in two phases through LDS: pass_tile_append (cheap superset test, lane compaction)
+// and pass_flush (the exact tests over up to PASS_BATCH tiles' listed slots, then the tiles' bookkeeping).
 // ---------------------------------------------------------------------------------------------
 // data.vert:33-52,87-88: is pixel q a candidate (a valid measurement on the checkerboard)?  Exactly the tests local_surfel
 // applies before it does any arithmetic (frame path, i.e. not the raw cloud of the frame after reset()).
