@@ -376,6 +376,88 @@ __device__ __forceinline__ void pass_tile_append(const SurfelSet &set, DevState 
     n_list += need;
 }
 
+// ---- phase A of up to FOUR quarter-tile units at once (k_surfel_pass<4>): the same quarter `upart` of four DIFFERENT tiles of the
+// workgroup's sequence, one word per wave and unit -- the four 16-byte loads of a thread go out together.  (One unit after the
+// other, even with the next unit's word prefetched, every unit was a dependent load -> test -> LDS append -> barrier: a
+// workgroup with three visited units spent 4.5 us in phase A.)  tiles[r], and bit r of sk0m / sk1m / deadm, describe unit r < nun.
+__device__ __forceinline__ void pass_units4_append(const SurfelSet &set, DevState *__restrict__ st, const FrameParams &fp,
+                                                   const uint2 *__restrict__ dcT, uint64_t *__restrict__ cm, uint64_t *__restrict__ km,
+                                                   uint4 *__restrict__ wave_cnt, uint64_t *__restrict__ alive,
+                                                   uint32_t *__restrict__ tile_dead, uint64_t *__restrict__ keyT, float *__restrict__ undo,
+                                                   uint32_t N, uint32_t exempt, const uint32_t (&tiles)[4], uint32_t nun, uint32_t sk0m,
+                                                   uint32_t sk1m, uint32_t deadm, uint32_t wave, int lane, PassAcc &acc,
+                                                   uint32_t *__restrict__ tb, PassLds &L, uint32_t it, uint32_t &nb, uint32_t &n_list, uint32_t upart)
+{
+    const float4 *__restrict__ pc = set.pos_conf;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t wofs = upart * (uint32_t)(TILE_WORDS / 4) + wave;       // the wave's word within a tile
+    float4 v[4];
+    uint64_t valid[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const uint32_t k = (tiles[r] * TILE_WORDS + wofs) * 64u + (uint32_t)lane;       // (tiles[r >= nun] repeats a valid tile)
+        v[r] = pc[min(k, N - 1u)];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const uint32_t word = tiles[r] * TILE_WORDS + wofs;
+        const uint64_t base = (uint64_t)word * 64u;
+        uint64_t range = 0ull;
+        if ((uint32_t)r < nun && base < N) { const uint64_t rem = (uint64_t)N - base; range = rem >= 64 ? ~0ull : ((1ull << rem) - 1ull); }
+        valid[r] = range & (((deadm >> r) & 1u) ? alive[word] : ~0ull);
+    }
+    if (tid == 0) L.pend[(it + 1u) % 3u] = 0u;
+    const float zs_max = fp.depth_cutoff * 1.5f;       // splat_one's far limit
+    uint64_t m[4];
+    uint32_t cnt = 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const bool sk0 = (sk0m >> r) & 1u, sk1 = (sk1m >> r) & 1u;
+        bool act = false;
+        if ((valid[r] >> lane) & 1ull) {
+            const float3 ph = xform3(fp.t_inv, v[r].x, v[r].y, v[r].z);
+            const float rz = __builtin_amdgcn_rcpf(ph.z);
+            const float ua = (fp.fx * ph.x) * rz + fp.cx, va = (fp.fy * ph.y) * rz + fp.cy;
+            const bool out_img = ua < -2.0f || ua > fp.cols + 2.0f || va < -2.0f || va > fp.rows + 2.0f;      // (false for NaN)
+            const bool rej_c = sk0 || ph.z <= fp.min_depth || ph.z >= fp.max_depth || out_img;              // conflict.vert:25-49 cannot pass
+            const bool rej_s = sk1 || ph.z >= zs_max || ph.z <= 0.0f || out_img;                             // index_map.vert:38-64 cannot pass
+            act = !rej_c || !rej_s || (!sk0 && !(v[r].w > 0.0f));
+        }
+        m[r] = __ballot(act);
+        cnt += (uint32_t)__popcll(m[r]);
+    }
+    if (lane == 0 && cnt) atomicAdd(&L.pend[it % 3u], cnt);
+    lds_barrier();                                     // the group's demand; the previous group's entries
+    const uint32_t need = L.pend[it % 3u];             // (<= 4 x 256 = the list's capacity)
+    if (n_list + need > (uint32_t)TILE || nb + nun > (uint32_t)PASS_BATCH) {          // workgroup-uniform (registers only: see pass_tile_append)
+        pass_flush<4>(set, st, fp, dcT, cm, km, wave_cnt, alive, tile_dead, keyT, undo, N, exempt, nb, wave, lane, acc, tb, L);
+        nb = 0u;
+        n_list = 0u;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const uint32_t k = (tiles[r] * TILE_WORDS + wofs) * 64u + (uint32_t)lane;
+            v[r] = pc[min(k, N - 1u)];
+        }
+    }
+    if (tid < nun) {
+        L.btile[nb + tid] = tid == 0u ? tiles[0] : tid == 1u ? tiles[1] : tid == 2u ? tiles[2] : tiles[3];
+        L.bflag[nb + tid] = ((sk0m >> tid) & 1u) | (((sk1m >> tid) & 1u) << 1) | (((deadm >> tid) & 1u) << 2) | (upart << 8);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        uint32_t base = 0;
+        if (lane == 0 && m[r]) base = atomicAdd(&L.n, (uint32_t)__popcll(m[r]));
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        if ((m[r] >> lane) & 1ull) {
+            const uint32_t at = base + (uint32_t)__popcll(m[r] & ((1ull << lane) - 1ull));
+            L.list[at] = ((nb + (uint32_t)r) << 10) | (wofs * 64u + (uint32_t)lane);
+            L.pos[at] = v[r];
+        }
+    }
+    nb += nun;
+    n_list += need;
+}
+
 // The frame's preparation launch evaluated the tile skip flags (one byte per tile, loaded together with DevState).
 // Workgroup <-> tile round-robin.  SPLIT = 4: four consecutive workgroups share a sequence of tiles, a quarter each (ca.n_pass
 // is a multiple of SPLIT).  The newest ~150 tiles of a KITTI model hold ~900 surfels in view each; as ONE workgroup's list that
@@ -448,8 +530,7 @@ __global__ __launch_bounds__(256) void k_surfel_pass(Model M, DevState *__restri
         __syncthreads();
     }
     if (SPLIT == 4 && desc && n_it) {
-        // Quarter-tile units, the workgroup's units one behind the other -- with the NEXT unit's word already on its way while
-        // this one is tested (a unit is one 16-byte load per thread; the barriers inside do not wait for it, lds_barrier)
+        // Quarter-tile units, four of the workgroup's visited tiles at a time (pass_units4_append)
         {
             const uint64_t tl = (uint64_t)bid + (uint64_t)lane * tile_grid;
             const uint32_t f = tl < ntiles ? m_flag : 3u;
@@ -457,26 +538,28 @@ __global__ __launch_bounds__(256) void k_surfel_pass(Model M, DevState *__restri
             skip1 = __ballot((f & 2u) != 0u);
         }
         uint64_t vis = ~(skip0 & skip1) & (n_it >= 64u ? ~0ull : ((1ull << n_it) - 1ull));
-        const float4 *__restrict__ pc = set.pos_conf;
-        const uint32_t wofs = (upart * (uint32_t)(TILE_WORDS / SPLIT) + wave) * 64u + (uint32_t)lane;       // this thread's slot within a tile
-        int sl = vis ? 63 - __clzll((long long)vis) : -1;
-        float4 vn = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (sl >= 0) vn = pc[min((bid + (uint32_t)sl * tile_grid) * (uint32_t)TILE + wofs, N - 1u)];
-        while (sl >= 0) {                               // workgroup-uniform
-            vis &= ~(1ull << sl);
-            const int sl_next = vis ? 63 - __clzll((long long)vis) : -1;
-            const float4 vcur = vn;
-            if (sl_next >= 0) vn = pc[min((bid + (uint32_t)sl_next * tile_grid) * (uint32_t)TILE + wofs, N - 1u)];
-            const uint32_t tile = bid + (uint32_t)sl * tile_grid;
-            const bool sk0 = (skip0 >> sl) & 1ull, sk1 = (skip1 >> sl) & 1ull;
+        while (vis) {                                   // workgroup-uniform: the next (up to) four visited tiles, newest first
+            uint32_t tiles[4], nun = 0, sk0m = 0, sk1m = 0, deadm = 0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (vis) {
+                    const int sl = 63 - __clzll((long long)vis);
+                    vis &= ~(1ull << sl);
+                    tiles[r] = bid + (uint32_t)sl * tile_grid;
+                    sk0m |= (uint32_t)((skip0 >> sl) & 1ull) << r;
+                    sk1m |= (uint32_t)((skip1 >> sl) & 1ull) << r;
+                    deadm |= (lane_bcast(m_dead, sl) != 0u ? 1u : 0u) << r;
+                    nun = (uint32_t)r + 1u;
+                } else
+                    tiles[r] = tiles[0];
+            }
             const bool tr_now = tr && tr_first;
             tr_first = false;
-            if (tr_now && threadIdx.x == 0) { tr[1] = wall_clock64(); tr[4] = tile; }
-            pass_tile_append<SPLIT>(set, st, fp, dcT, cm, km, wave_cnt, alive, tile_dead, keyT, undo, N, exempt, tile, wave, sk0, sk1,
-                                    lane_bcast(m_dead, sl) != 0u, lane, acc, tb, s_pass, n_visited, n_batch, n_list, upart, &vcur);
+            if (tr_now && threadIdx.x == 0) { tr[1] = wall_clock64(); tr[4] = tiles[0]; }
+            pass_units4_append(set, st, fp, dcT, cm, km, wave_cnt, alive, tile_dead, keyT, undo, N, exempt, tiles, nun, sk0m, sk1m, deadm,
+                               wave, lane, acc, tb, s_pass, n_visited, n_batch, n_list, upart);
             ++n_visited;
             if (tr_now && threadIdx.x == 0) { tr[2] = wall_clock64(); tr[5] = s_pass.n; }
-            sl = sl_next;
         }
     } else
     for (uint32_t it = 0; it < n_it; ++it) {
