@@ -237,7 +237,7 @@ def kernel_table(log, tim, P, K, warmup, compact_period, workload):
     for tpath in (os.path.join(ROOT, "profiles", f"traffic_{workload}_s{K}_w{warmup}.json"), os.path.join(ROOT, "profiles", f"traffic_{workload}.json")):
         if os.path.exists(tpath):
             cand = json.load(open(tpath))
-            if cand.get("steps") == K and cand.get("warmup") == warmup and cand.get("compact_period", 32) == compact_period:
+            if cand.get("steps") == K and cand.get("warmup") == warmup and cand.get("compact_period", 24) == compact_period:
                 tj = cand
                 break
     for name in kern:
@@ -742,7 +742,7 @@ def main():
     ap.add_argument("--no-sharded-leg", action="store_true", help="N ranks: skip the ONE-stream-over-N-GPUs leg (configs[3])")
     ap.add_argument("--rehearse-one-gpu", action="store_true",
                     help="N ranks, all on GPU 0, gloo + host-staged collectives: rehearses the N-process flow on a 1-GPU box (not a measurement)")
-    ap.add_argument("--compact-period", type=int, default=32,
+    ap.add_argument("--compact-period", type=int, default=24,
                     help="deferred compaction: culled surfels keep their slots, every Nth cull squeezes them out (1: every frame)")
     ap.add_argument("--no-fuse-leg", action="store_true")
     ap.add_argument("--no-steady-leg", action="store_true")

@@ -53,8 +53,8 @@ typedef struct sm_config {
     int32_t device;                /* HIP device ordinal */
     int32_t enable_timing;         /* 1: record hipEvents per stage (sm_stage_timings) */
     int32_t disable_tile_bounds;   /* 1: never skip tiles by their bounding box (A/B switch; results are identical) */
-    int32_t compact_period;        /* 32: deferred compaction -- a cull only marks the surfels it removes (they keep their slots)
-                                      and every 32nd cull squeezes the dead slots out in one in-place pass; also whenever dead
+    int32_t compact_period;        /* 24: deferred compaction -- a cull only marks the surfels it removes (they keep their slots)
+                                      and every 24th cull squeezes the dead slots out in one in-place pass; also whenever dead
                                       slots could make a frame exceed MAX_VERTICES.  0/1: compact at every cull like the
                                       reference.  Counts, ids and the stored model are identical for every period. */
 } sm_config;

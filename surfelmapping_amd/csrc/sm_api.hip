@@ -1214,7 +1214,7 @@ int sm_default_config(sm_config *c, int width, int height, float fx, float fy, f
     c->conflict_cap = 1;
     c->device = 0;
     c->enable_timing = 0;
-    c->compact_period = 32;
+    c->compact_period = 24;
     return SM_OK;
 }
 

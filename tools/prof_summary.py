@@ -78,7 +78,7 @@ def main():
     ap.add_argument("--out", default=None)
     ap.add_argument("--steps", type=int, default=None, help="recorded in the json (bench.py --steps of the profiled command)")
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--compact-period", type=int, default=32, help="recorded in the json (bench.py --compact-period of the profiled command)")
+    ap.add_argument("--compact-period", type=int, default=24, help="recorded in the json (bench.py --compact-period of the profiled command)")
     ap.add_argument("--simds", type=int, default=1024, help="SIMDs of the device (MI355X: 256 CUs x 4)")
     ap.add_argument("--mhz", type=float, default=2400.0, help="shader clock used to turn durations into cycles")
     a = ap.parse_args()
