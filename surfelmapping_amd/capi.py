@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libsurfelmapping_hip.so")
+LIB_PATH = os.environ.get("SM_HIP_LIB") or os.path.join(_PKG, "libsurfelmapping_hip.so")      # (SM_HIP_LIB: another build of the core, for A/B runs)
 API_VERSION = 3                # SM_API_VERSION of include/sm_c_api.h
 
 SM_OK, SM_E_ARG, SM_E_CAPACITY, SM_E_UNSUPPORTED, SM_E_HIP, SM_E_NO_DEVICE = 0, -1, -2, -3, -4, -5

@@ -27,7 +27,8 @@ if __name__ == "__main__":
     sm.close()
     a = np.fromfile(prefix + ".assoc_prep.bin", dtype=np.uint64).astype(np.int64)
     n_assoc, n_flag, n_img = a[:3]
-    a = a[3:].reshape(-1, 2)
+    n_fix, n_assoc = int(n_assoc >> 32), int(n_assoc & 0xFFFFFFFF)     # two-launch frame: publisher + repair crew open the grid
+    a = a[3:].reshape(-1, 2)[n_fix:]
     a0 = a[:, 0].min()
     en, ex = (a[:, 0] - a0) / 100.0, (a[:, 1] - a0) / 100.0
     print(f"k_assoc_prep<chain>: {n_img} chain tiles + {n_assoc} association + {n_flag} flag workgroups, launch span {ex.max():.2f} us")
