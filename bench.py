@@ -299,11 +299,11 @@ def run_leg(capi, cam, frames, K, Wm, cfg_kw, *, events=True, mode="device", see
     sm = capi.SurfelMap(capi.make_config(**cam, **cfg_kw, enable_timing=0))
     prime(sm)
     dptr = stage_frames(sm, frames, P) if mode.startswith("device") else None
-    if mode == "host_async":            # a reader that decodes into pinned buffers of the library (sm_host_alloc); here one set per frame
+    if mode == "host_async":            # a reader that decodes into pinned frame blocks of the library (sm_host_alloc_frame); here one per frame
         pinned = []
         for rgb, depth, sem, pose in frames:
-            a, b, c = sm.host_array(rgb.shape, rgb.dtype), sm.host_array(depth.shape, depth.dtype), sm.host_array(sem.shape, sem.dtype)
-            a[...] = rgb; b[...] = depth; c[...] = sem
+            a, b, c = sm.host_frame()
+            a[...] = rgb.reshape(a.shape); b[...] = depth.reshape(b.shape); c[...] = sem.reshape(c.shape)
             pinned.append((a, b, c, pose))
         frames = pinned
     step = step_fn(sm, dptr)

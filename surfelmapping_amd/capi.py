@@ -12,7 +12,7 @@ import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SM_HIP_LIB") or os.path.join(_PKG, "libsurfelmapping_hip.so")      # (SM_HIP_LIB: another build of the core, for A/B runs)
-API_VERSION = 3                # SM_API_VERSION of include/sm_c_api.h
+API_VERSION = 4                # SM_API_VERSION of include/sm_c_api.h
 
 SM_OK, SM_E_ARG, SM_E_CAPACITY, SM_E_UNSUPPORTED, SM_E_HIP, SM_E_NO_DEVICE = 0, -1, -2, -3, -4, -5
 TEX_DEPTH_METRIC, TEX_DEPTH_FILTERED, TEX_LAST = 0, 1, 2
@@ -21,7 +21,7 @@ TEX_DEPTH_METRIC, TEX_DEPTH_FILTERED, TEX_LAST = 0, 1, 2
 SYMBOLS = (
     "sm_api_version", "sm_last_error", "sm_default_config", "sm_create", "sm_destroy",
     "sm_process_frame", "sm_process_frame_device", "sm_process_frame_async",
-    "sm_inputs_consumed", "sm_host_alloc", "sm_host_free", "sm_sync", "sm_clean_points", "sm_clean_points_ex", "sm_clean_points_cb", "sm_reset",
+    "sm_inputs_consumed", "sm_host_alloc", "sm_host_alloc_frame", "sm_host_free", "sm_sync", "sm_clean_points", "sm_clean_points_ex", "sm_clean_points_cb", "sm_reset",
     "sm_get_counts", "sm_download_model_aos", "sm_upload_model_aos", "sm_save_map", "sm_load_map",
     "sm_download_index_map", "sm_download_raw_cloud", "sm_download_depth", "sm_render_image", "sm_set_frame", "sm_set_tick",
     "sm_stage_conflict", "sm_stage_cull", "sm_stage_splat", "sm_stage_associate_fuse",
@@ -174,6 +174,7 @@ def load():
     L.sm_host_alloc.restype = vp
     L.sm_host_alloc.argtypes = [vp, C.c_size_t]
     L.sm_host_free.argtypes = [vp, vp]
+    L.sm_host_alloc_frame.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
     L.sm_sync.argtypes = [vp]
     L.sm_clean_points.argtypes = [vp, vp, vp, vp]
     L.sm_clean_points_ex.argtypes = [vp, vp, vp, vp, C.c_int]
@@ -296,6 +297,17 @@ class SurfelMap:
             raise SurfelMapError("sm_host_alloc", SM_E_HIP, self._L.sm_last_error().decode())
         buf = (C.c_ubyte * n).from_address(p)
         return np.frombuffer(buf, dtype=dtype).reshape(shape)
+
+    def host_frame(self):
+        """(rgb (H, W, 3) u8, depth (H, W) u16, semantic (H, W) u8): numpy views of ONE pinned block (sm_host_alloc_frame) --
+        process_frame_async copies such a frame with a single transfer"""
+        a, b, c = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        self._chk(self._L.sm_host_alloc_frame(self._h, C.byref(a), C.byref(b), C.byref(c)), "sm_host_alloc_frame")
+        H, W = self.H, self.W
+        rgb = np.frombuffer((C.c_ubyte * (H * W * 3)).from_address(a.value), dtype=np.uint8).reshape(H, W, 3)
+        dep = np.frombuffer((C.c_ubyte * (H * W * 2)).from_address(b.value), dtype=np.uint16).reshape(H, W)
+        sem = np.frombuffer((C.c_ubyte * (H * W)).from_address(c.value), dtype=np.uint8).reshape(H, W)
+        return rgb, dep, sem
 
     def inputs_consumed(self):
         self._chk(self._L.sm_inputs_consumed(self._h), "sm_inputs_consumed")

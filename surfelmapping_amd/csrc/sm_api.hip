@@ -277,9 +277,12 @@ struct sm_ctx {
     // frame f computes; images in buffers of sm_host_alloc are copied from in place, others through pinned staging
     static constexpr int IN_RING = 3;
     struct InSlot { uint8_t *rgb = nullptr, *sem = nullptr; uint16_t *depth = nullptr; unsigned char *h_stage = nullptr;
-                    hipEvent_t ev_in = nullptr, ev_in2 = nullptr, ev_free = nullptr; bool used = false; };
+                    hipEvent_t ev_in = nullptr, ev_free = nullptr; bool used = false; };
     InSlot in[IN_RING];
-    hipStream_t stream_in = nullptr, stream_in2 = nullptr;    // two copy streams: the colour image on one DMA engine, depth + semantic on another
+    hipStream_t stream_in = nullptr;   // ONE copy stream.  (Two -- colour on one engine, depth + class on another -- were 80 instead of 89 us per frame on
+                                       // one box of the pool and stalled for 10-16 ms every few dozen frames on others; tools/h2d_probe.hip: per frame, three
+                                       // copies on two streams 68 us + stalls, on one stream 87, ONE copy of the whole frame 58 = the PCIe rate.)
+    size_t in_off_depth = 0, in_off_sem = 0, in_bytes = 0;   // a frame's images as ONE block: colour | depth | class, 16-byte aligned (sm_host_alloc_frame)
     uint32_t in_next = 0;
     const uint16_t *in_last_depth = nullptr; const uint8_t *in_last_sem = nullptr;     // device copies of the last depth / semantic image given
     int in_depth_slot = -1, in_sem_slot = -1;                                          // ... and the input sets that hold them
@@ -1236,6 +1239,9 @@ sm_ctx *sm_create(const sm_config *c)
     s->cfg = *c;
     if (c->device >= 0 && c->device < MAX_DEV) { std::lock_guard<std::mutex> lk(g_compact_mu); g_ctx_on_dev[c->device]++; }
     s->W = c->width; s->H = c->height; s->P = c->width * c->height;
+    s->in_off_depth = ((size_t)s->P * 3 + 15) & ~(size_t)15;
+    s->in_off_sem = s->in_off_depth + (((size_t)s->P * 2 + 15) & ~(size_t)15);
+    s->in_bytes = s->in_off_sem + (size_t)s->P;
     s->cap = (uint32_t)c->max_sqrt_vertices * (uint32_t)c->max_sqrt_vertices;
     for (int i = 0; i < 16; ++i) s->curr_pose[i] = s->last_pose[i] = (i % 5 == 0) ? 1.0f : 0.0f;
     const size_t P = (size_t)s->P, cap = s->cap;
@@ -1398,16 +1404,13 @@ void sm_destroy(sm_ctx *s)
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     if (s->ss_comm) (void)sm_shard_rccl_finalize(s);         // a communicator the caller did not finalize
     if (s->stream_in) (void)hipStreamSynchronize(s->stream_in);
-    if (s->stream_in2) (void)hipStreamSynchronize(s->stream_in2);
     for (auto &sl : s->in) {
-        if (sl.ev_in2) (void)hipEventDestroy(sl.ev_in2);
-        (void)hipFree(sl.rgb); (void)hipFree(sl.sem); (void)hipFree(sl.depth);
+        (void)hipFree(sl.rgb);          // (one block: depth and class follow the colour image)
         if (sl.h_stage) (void)hipHostFree(sl.h_stage);
         if (sl.ev_in) (void)hipEventDestroy(sl.ev_in);
         if (sl.ev_free) (void)hipEventDestroy(sl.ev_free);
     }
     if (s->stream_in) (void)hipStreamDestroy(s->stream_in);
-    if (s->stream_in2) (void)hipStreamDestroy(s->stream_in2);
     for (void *hp : s->host_allocs) (void)hipHostFree(hp);
     if (s->d_pass_trace) {
         // SM_PASS_TRACE=<prefix>: the last k_surfel_pass launch's per-workgroup record (wall_clock64 at entry / first tile /
@@ -1504,13 +1507,22 @@ void *sm_host_alloc(sm_ctx *s, size_t bytes)
     return p;
 }
 
+int sm_host_alloc_frame(sm_ctx *s, uint8_t **rgb, uint16_t **depth_mm, uint8_t **semantic)
+{
+    if (!s || !rgb || !depth_mm || !semantic) { g_err = "sm_host_alloc_frame: null argument"; return SM_E_ARG; }
+    unsigned char *blk = static_cast<unsigned char *>(sm_host_alloc(s, s->in_bytes));
+    if (!blk) return SM_E_HIP;
+    *rgb = blk; *depth_mm = reinterpret_cast<uint16_t *>(blk + s->in_off_depth); *semantic = blk + s->in_off_sem;
+    return SM_OK;
+}
+
 int sm_host_free(sm_ctx *s, void *p)
 {
     if (!s || !p) return SM_E_ARG;
     auto it = std::find(s->host_allocs.begin(), s->host_allocs.end(), p);
     if (it == s->host_allocs.end()) { g_err = "sm_host_free: not a buffer of sm_host_alloc"; return SM_E_ARG; }
     HIPCK(hipSetDevice(s->cfg.device));
-    if (s->stream_in) { HIPCK(hipStreamSynchronize(s->stream_in)); HIPCK(hipStreamSynchronize(s->stream_in2)); }
+    if (s->stream_in) HIPCK(hipStreamSynchronize(s->stream_in));
     s->host_allocs.erase(it);
     for (size_t i = 0; i < s->pinned.size(); ++i)
         if (s->pinned[i].first == p) { s->pinned.erase(s->pinned.begin() + (long)i); break; }
@@ -1525,10 +1537,10 @@ int sm_process_frame_async(sm_ctx *s, const uint8_t *rgb, const uint16_t *depth_
     const size_t P = (size_t)s->P;
     if (!s->stream_in) {
         HIPCK(hipStreamCreateWithFlags(&s->stream_in, hipStreamNonBlocking));
-        HIPCK(hipStreamCreateWithFlags(&s->stream_in2, hipStreamNonBlocking));
         for (auto &sl : s->in) {
-            HIPCK(hipEventCreateWithFlags(&sl.ev_in2, hipEventDisableTiming));
-            HIPCK(hipMalloc((void **)&sl.rgb, P * 3)); HIPCK(hipMalloc((void **)&sl.depth, P * 2)); HIPCK(hipMalloc((void **)&sl.sem, P));
+            unsigned char *blk = nullptr;
+            HIPCK(hipMalloc((void **)&blk, s->in_bytes));
+            sl.rgb = blk; sl.depth = reinterpret_cast<uint16_t *>(blk + s->in_off_depth); sl.sem = blk + s->in_off_sem;
             HIPCK(hipEventCreateWithFlags(&sl.ev_in, hipEventDisableTiming));
             HIPCK(hipEventCreateWithFlags(&sl.ev_free, hipEventDisableTiming));
         }
@@ -1545,29 +1557,36 @@ int sm_process_frame_async(sm_ctx *s, const uint8_t *rgb, const uint16_t *depth_
         for (auto &pr : s->pinned) if (q >= pr.first && q + n <= pr.first + pr.second) return true;
         return false;
     };
-    size_t off = 0;
-    auto copy_in = [&](void *dst, const void *src, size_t n, hipStream_t cs) -> int {
-        if (!is_pinned(src, n)) {
-            // pageable caller memory: through this set's pinned staging (one host memcpy; the previous copy out of it -- three
-            // frames ago -- must have completed)
-            if (!sl.h_stage) HIPCK(hipHostMalloc((void **)&sl.h_stage, P * 6, hipHostMallocDefault));
-            if (sl.used && off == 0) { HIPCK(hipEventSynchronize(sl.ev_in)); HIPCK(hipEventSynchronize(sl.ev_in2)); }
-            memcpy(sl.h_stage + off, src, n);
-            src = sl.h_stage + off;
+    const unsigned char *rgb_b = rgb, *dep_b = reinterpret_cast<const unsigned char *>(depth_mm);
+    int rc = SM_OK;
+    if (depth_mm && semantic && dep_b == rgb_b + s->in_off_depth && semantic == rgb_b + s->in_off_sem && is_pinned(rgb, s->in_bytes)) {
+        // a frame block of sm_host_alloc_frame: ONE copy
+        HIPCK(hipMemcpyAsync(sl.rgb, rgb, s->in_bytes, hipMemcpyHostToDevice, s->stream_in));
+    } else if (!is_pinned(rgb, P * 3) || (depth_mm && !is_pinned(depth_mm, P * 2)) || (semantic && !is_pinned(semantic, P))) {
+        // pageable caller memory: through this set's pinned staging in the frame-block layout (host memcpys; the previous copy out
+        // of it -- three frames ago -- must have completed), then ONE copy of what was given
+        if (!sl.h_stage) HIPCK(hipHostMalloc((void **)&sl.h_stage, s->in_bytes, hipHostMallocDefault));
+        if (sl.used) HIPCK(hipEventSynchronize(sl.ev_in));
+        memcpy(sl.h_stage, rgb, P * 3);
+        if (depth_mm) memcpy(sl.h_stage + s->in_off_depth, depth_mm, P * 2);
+        if (semantic) memcpy(sl.h_stage + s->in_off_sem, semantic, P);
+        if (depth_mm && semantic) HIPCK(hipMemcpyAsync(sl.rgb, sl.h_stage, s->in_bytes, hipMemcpyHostToDevice, s->stream_in));
+        else {
+            HIPCK(hipMemcpyAsync(sl.rgb, sl.h_stage, P * 3, hipMemcpyHostToDevice, s->stream_in));
+            if (depth_mm) HIPCK(hipMemcpyAsync(sl.depth, sl.h_stage + s->in_off_depth, P * 2, hipMemcpyHostToDevice, s->stream_in));
+            if (semantic) HIPCK(hipMemcpyAsync(sl.sem, sl.h_stage + s->in_off_sem, P, hipMemcpyHostToDevice, s->stream_in));
         }
-        off += n;
-        HIPCK(hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, cs));
-        return SM_OK;
-    };
-    int rc = copy_in(sl.rgb, rgb, P * 3, s->stream_in);
+    } else {
+        // separate pinned buffers (sm_host_alloc): copied from in place, one after the other
+        HIPCK(hipMemcpyAsync(sl.rgb, rgb, P * 3, hipMemcpyHostToDevice, s->stream_in));
+        if (depth_mm) HIPCK(hipMemcpyAsync(sl.depth, depth_mm, P * 2, hipMemcpyHostToDevice, s->stream_in));
+        if (semantic) HIPCK(hipMemcpyAsync(sl.sem, semantic, P, hipMemcpyHostToDevice, s->stream_in));
+    }
     // a null depth / semantic keeps the previous texture (src/SurfelMapping.cpp:124-128)
-    if (!rc && depth_mm) { rc = copy_in(sl.depth, depth_mm, P * 2, s->stream_in2); s->in_last_depth = sl.depth; s->in_depth_slot = slot; }
-    if (!rc && semantic) { rc = copy_in(sl.sem, semantic, P, s->stream_in2); s->in_last_sem = sl.sem; s->in_sem_slot = slot; }
-    if (rc) return rc;
+    if (depth_mm) { s->in_last_depth = sl.depth; s->in_depth_slot = slot; }
+    if (semantic) { s->in_last_sem = sl.sem; s->in_sem_slot = slot; }
     HIPCK(hipEventRecord(sl.ev_in, s->stream_in));
-    HIPCK(hipEventRecord(sl.ev_in2, s->stream_in2));
     HIPCK(hipStreamWaitEvent(s->stream, sl.ev_in, 0));
-    HIPCK(hipStreamWaitEvent(s->stream, sl.ev_in2, 0));
     rc = enqueue_frame(s, sl.rgb, s->in_last_depth ? s->in_last_depth : s->d_depth_raw, s->in_last_sem ? s->in_last_sem : s->d_sem, pose16);
     HIPCK(hipEventRecord(sl.ev_free, s->stream));
     sl.used = true;
@@ -1582,7 +1601,6 @@ int sm_inputs_consumed(sm_ctx *s)
     if (!s) return SM_E_ARG;
     HIPCK(hipSetDevice(s->cfg.device));
     if (s->stream_in) HIPCK(hipStreamSynchronize(s->stream_in));
-    if (s->stream_in2) HIPCK(hipStreamSynchronize(s->stream_in2));
     return SM_OK;
 }
 

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), f"{name} declared in include/sm_c_api.h but not exported"
     assert sorted(capi.SYMBOLS) == declared
-    assert L.sm_api_version() == 3
+    assert L.sm_api_version() == 4
 
 
 def test_config_struct_matches_header_defaults():

@@ -460,13 +460,15 @@ def test_raw_feedback_cloud_matches_oracle():
 
 
 def test_async_host_buffers_match_oracle():
-    """sm_process_frame_async: host images, no host wait -- the copy of frame f+1 overlaps frame f on two copy streams (three
-    device input sets).  Pinned buffers of the library (sm_host_alloc) and pageable arrays (staged inside the call), a null
+    """sm_process_frame_async: host images, no host wait -- the copy of frame f+1 overlaps frame f on a copy stream (three
+    device input sets).  Pinned frame blocks and separate pinned buffers of the library (sm_host_alloc_frame / sm_host_alloc) and
+    pageable arrays (staged inside the call), a null
     depth / semantic (keeps the previous texture, src/SurfelMapping.cpp:124-128), with the depth filter chain and without."""
     for pre in (0, 1):
         seq = moving_boxes_sequence(SMALL, 14, seed=8) if pre else synth.make_sequence(SMALL, synth.kitti_trajectory(14), seed=8, noise_mm=3.0)
         o, h = pair(SMALL, preprocess=pre, stereo_border=20.0, max_sqrt_vertices=700, fuse_thresh=0.03, compact_period=4)
-        ring = [tuple(h.host_array(x.shape, x.dtype) for x in seq[0][:3]) for _ in range(3)]       # a reader's three pinned buffer sets
+        # a reader's three pinned buffer sets: two as frame blocks (one transfer per frame), one as three separate buffers
+        ring = [h.host_frame(), tuple(h.host_array(x.shape, x.dtype) for x in seq[0][:3]), h.host_frame()]
         for k, (rgb, d, s_, p) in enumerate(seq):
             dd, ss = (None, None) if k == 6 else (d, s_)          # frame 6: rgb only
             o.process_frame(rgb, seq[k - 1][1] if k == 6 else d, seq[k - 1][2] if k == 6 else s_, p)
@@ -475,7 +477,7 @@ def test_async_host_buffers_match_oracle():
                 if k >= 6:
                     h.inputs_consumed()
                 for dst, src in zip(bufs, (rgb, d, s_)):
-                    np.copyto(dst, src)
+                    np.copyto(dst, src.reshape(dst.shape))
                 h.process_frame_async(bufs[0], None if dd is None else bufs[1], None if ss is None else bufs[2], p)
             else:
                 h.process_frame_async(np.ascontiguousarray(rgb), dd, ss, p)

@@ -16,8 +16,8 @@ if __name__ == "__main__":
         if mode == "hostalloc":
             fr2 = []
             for rgb, d, s, p in frames:
-                a, b, c = sm.host_array(rgb.shape, rgb.dtype), sm.host_array(d.shape, d.dtype), sm.host_array(s.shape, s.dtype)
-                a[...] = rgb; b[...] = d; c[...] = s
+                a, b, c = sm.host_frame()
+                a[...] = rgb.reshape(a.shape); b[...] = d.reshape(b.shape); c[...] = s.reshape(c.shape)
                 fr2.append((a, b, c, p))
             frames_use = fr2
         else:
@@ -42,3 +42,21 @@ if __name__ == "__main__":
         print(mode, "frames/s", round((n - 5) / el), "us/frame", round(el / (n - 5) * 1e6, 1), "| host per call median", round(np.median(calls) * 1e6, 1), "max", round(max(calls) * 1e6, 1),
               "| enqueue total", round(t_enq * 1e6 / (n - 5), 1))
         sm.close()
+    # the box's own H2D rate for one frame's worth of bytes (pinned and pageable), for reading the figures above
+    try:
+        import torch
+        nbytes = cam["width"] * cam["height"] * 6
+        dst = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+        for kind in ("pinned", "pageable"):
+            src = torch.empty(nbytes, dtype=torch.uint8).pin_memory() if kind == "pinned" else torch.empty(nbytes, dtype=torch.uint8)
+            for _ in range(3):
+                dst.copy_(src, non_blocking=True)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(20):
+                dst.copy_(src, non_blocking=True)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / 20
+            print(f"H2D {kind}: {nbytes / 1e6:.1f} MB in {dt * 1e6:.0f} us = {nbytes / dt / 1e9:.1f} GB/s")
+    except Exception as e:      # noqa: BLE001
+        print("H2D probe skipped:", e)
