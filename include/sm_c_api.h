@@ -260,6 +260,9 @@ int sm_export_model_device(sm_ctx *s, void **d_aos, uint32_t *n);
 int sm_append_model_aos_device(sm_ctx *s, const float *d_src12, uint32_t n);
 int sm_device_download(sm_ctx *s, void *dst_host, const void *src_device, size_t bytes);
 
+/* diagnostic: how many frames so far took the rare path of the two-launch frame (their association waited, inside its launch, for
+ * the publisher and the cap repair: conflicts > W*H, or the "id 0" surfel died).  Synchronises. */
+int sm_debug_slow_frames(sm_ctx *s, uint32_t *n);
 /* Diagnostic: processes that hold compute queues on this context's GPU according to the KFD driver's tables (>= 1: this
  * one included), or -1 if /sys/class/kfd is not readable.  The in-place compaction switches to its ticket-ordered form
  * (no co-residency assumption) whenever the value is > 1 or a second context of this process shares the GPU; the value is

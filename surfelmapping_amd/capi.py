@@ -21,7 +21,7 @@ TEX_DEPTH_METRIC, TEX_DEPTH_FILTERED, TEX_LAST = 0, 1, 2
 SYMBOLS = (
     "sm_api_version", "sm_last_error", "sm_default_config", "sm_create", "sm_destroy",
     "sm_process_frame", "sm_process_frame_device", "sm_process_frame_async",
-    "sm_inputs_consumed", "sm_host_alloc", "sm_host_alloc_frame", "sm_host_free", "sm_sync", "sm_clean_points", "sm_clean_points_ex", "sm_clean_points_cb", "sm_reset",
+    "sm_inputs_consumed", "sm_host_alloc", "sm_host_alloc_frame", "sm_host_free", "sm_debug_slow_frames", "sm_sync", "sm_clean_points", "sm_clean_points_ex", "sm_clean_points_cb", "sm_reset",
     "sm_get_counts", "sm_download_model_aos", "sm_upload_model_aos", "sm_save_map", "sm_load_map",
     "sm_download_index_map", "sm_download_raw_cloud", "sm_download_depth", "sm_render_image", "sm_set_frame", "sm_set_tick",
     "sm_stage_conflict", "sm_stage_cull", "sm_stage_splat", "sm_stage_associate_fuse",
@@ -175,6 +175,7 @@ def load():
     L.sm_host_alloc.argtypes = [vp, C.c_size_t]
     L.sm_host_free.argtypes = [vp, vp]
     L.sm_host_alloc_frame.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
+    L.sm_debug_slow_frames.argtypes = [vp, u32p]
     L.sm_sync.argtypes = [vp]
     L.sm_clean_points.argtypes = [vp, vp, vp, vp]
     L.sm_clean_points_ex.argtypes = [vp, vp, vp, vp, C.c_int]
@@ -308,6 +309,12 @@ class SurfelMap:
         dep = np.frombuffer((C.c_ubyte * (H * W * 2)).from_address(b.value), dtype=np.uint16).reshape(H, W)
         sem = np.frombuffer((C.c_ubyte * (H * W)).from_address(c.value), dtype=np.uint8).reshape(H, W)
         return rgb, dep, sem
+
+    def debug_slow_frames(self) -> int:
+        """frames that took the rare path of the two-launch frame so far (diagnostic; synchronises)"""
+        n = C.c_uint32()
+        self._chk(self._L.sm_debug_slow_frames(self._h, C.byref(n)), "sm_debug_slow_frames")
+        return int(n.value)
 
     def inputs_consumed(self):
         self._chk(self._L.sm_inputs_consumed(self._h), "sm_inputs_consumed")

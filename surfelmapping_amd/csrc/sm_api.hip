@@ -2301,6 +2301,16 @@ int ss_compact(sm_ctx *s)
 
 extern "C" {
 
+int sm_debug_slow_frames(sm_ctx *s, uint32_t *n)
+{
+    if (!s || !n) return SM_E_ARG;
+    HIPCK(hipSetDevice(s->cfg.device));
+    int rc = pull_state(s);
+    if (rc) return rc;
+    *n = s->h_state->slow_frames;
+    return SM_OK;
+}
+
 int sm_gpu_process_count(sm_ctx *s)
 {
     if (!s) return SM_E_ARG;

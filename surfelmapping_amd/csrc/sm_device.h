@@ -65,6 +65,7 @@ struct DevState {
     uint32_t stat_frames;     // frames whose append has completed (tag of the host-visible slot statistic)
     uint32_t first_live;      // slot of the first live surfel = the reference's surfel id 0 (conflict.geom:15, data.vert:142)
     uint32_t fl_dirty2[2];    // k_surfel_pass saw that surfel die (word of the frame's parity, FrameParams::par): the publisher looks for its successor
+    uint32_t slow_frames;     // diagnostic: frames whose merged publisher found work the association had to wait for (sm_debug_slow_frames)
     uint32_t slow_done[2];    // two-launch frame, rare path (the conflict cap binds / "id 0" died): publisher + repair crew workgroups that are through (by frame parity)
     // ---- direct append (k_associate_direct): the frame's statistics are completed one kernel later
     uint32_t pend;            // 1: the last frame's new / fused counts, dead-slot total and log entry are still to be completed

@@ -860,6 +860,7 @@ __device__ __forceinline__ void fixup_publisher(DevState *__restrict__ st, const
             __hip_atomic_store(x.host_stat, ((unsigned long long)st->stat_frames << 32) | (unsigned long long)N, __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_SYSTEM);
         if (MERGED && (cap_binds || dirty)) {       // somebody waits for this
+            st->slow_frames = st->slow_frames + 1u;
             __hip_atomic_fetch_add(&st->slow_done[fp.par], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         }
     }

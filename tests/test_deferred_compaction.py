@@ -3,6 +3,7 @@ the next compacting cull (every `compact_period`-th one) moves the survivors.  T
 model, every counter and the index map must not depend on when the compaction happens: all variants are compared
 with the CPU oracle (which compacts at every cull like the reference, src/GlobalModel.cpp:517-579) bit for bit."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -198,6 +199,9 @@ def test_conflict_cap_binds_in_asynchronous_frames(period):
     same_counts(o, h, "async, cap binding")
     log = h.read_frame_log(16)
     assert (log["conflict_count"] == P).sum() >= 3, log["conflict_count"]
+    if os.environ.get("SM_TWO_LAUNCH") != "0" and os.environ.get("SM_DEFER_ASSOC") != "0":
+        # the frames whose cap bound went through the two-launch frame's wait: their association ran in the same launch as the repair
+        assert h.debug_slow_frames() >= 3
     assert_models_equal(o.download_model(), h.download_model(), "async, cap binding")
     np.testing.assert_array_equal(o.download_index_map()[0], h.download_index_map()[0])
 
