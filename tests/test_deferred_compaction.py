@@ -206,6 +206,48 @@ def test_conflict_cap_binds_in_asynchronous_frames(period):
     np.testing.assert_array_equal(o.download_index_map()[0], h.download_index_map()[0])
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("cap", [0, 1])
+def test_id_zero_dies_in_asynchronous_frames(cap):
+    """The surfel the reference addresses as id 0 (conflict.geom:15, data.vert:142) is dead on arrival (conf 0, an uploaded
+    model) and so are its successors: the pass sees it die, the publisher has to find the next live slot BEFORE the frame's
+    association may use the exemption -- in the two-launch frame both run in the same launch and the association waits.  Frames
+    are enqueued without host waits, with the W*H cap off and (binding) on."""
+    cam = dict(width=48, height=32, fx=40.0, fy=40.0, cx=23.5, cy=15.5)
+    o, h = pair(cam, stereo_border=0.0, conflict_cap=cap, max_sqrt_vertices=200, compact_period=1000, fuse_thresh=0.05)
+    rng = np.random.default_rng(23)
+    n = 6000
+    m = synth.seeded_model(n, tick=1, seed=4)
+    m[:, 0] = rng.uniform(-1.5, 1.5, n)
+    m[:, 1] = rng.uniform(-1.0, 1.0, n)
+    m[:, 2] = rng.uniform(3.0, 6.0, n)
+    m[:, 3] = rng.uniform(0.5, 3.5, n)
+    m[:40, 3] = 0.0                      # id 0 and the 39 slots behind it are dead already
+    m[40, 3] = 0.7                       # the first live one dies at its first conflict: the exemption moves twice
+    o.upload_model(m); h.upload_model(m)
+    rgb = rng.integers(0, 255, (32, 48, 3), dtype=np.uint8)
+    sem = np.zeros((32, 48), np.uint8)
+    far = np.full((32, 48), 20000, np.uint16)
+    mid = np.full((32, 48), 4500, np.uint16)
+    P = 48 * 32
+    frames = [far, mid, far, far, mid, far]
+    bufs = []
+    for d in frames:
+        dr, dd, ds = h.device_alloc(P * 3), h.device_alloc(P * 2), h.device_alloc(P)
+        h.device_upload(dr, rgb); h.device_upload(dd, d); h.device_upload(ds, sem)
+        bufs.append((dr, dd, ds))
+    for d in frames:
+        o.process_frame(rgb, d, sem, IDENT)
+    for b in bufs:
+        h.process_frame_device(*b, IDENT)
+    h.sync()
+    same_counts(o, h, f"async, id 0 dies, cap={cap}")
+    if os.environ.get("SM_TWO_LAUNCH") != "0" and os.environ.get("SM_DEFER_ASSOC") != "0":
+        assert h.debug_slow_frames() >= 1
+    assert_models_equal(o.download_model(), h.download_model(), f"async, id 0 dies, cap={cap}")
+    np.testing.assert_array_equal(o.download_index_map()[0], h.download_index_map()[0])
+
+
 @pytest.mark.parametrize("period,thresh", [(3, 0.05), (8, 0.0), (1000, 0.05)])
 def test_async_frames_hand_their_association_to_the_next_frame(period, thresh):
     """Asynchronous plain streams hold a frame's association back and launch it together with the next frame's image
