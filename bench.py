@@ -199,6 +199,7 @@ def kernel_table(log, tim, P, K, warmup, compact_period, workload):
     logd["P"] = P
     kb = kernel_bytes(logd)
     n_op, n_dir, n_comp = int(tim.get("frames_one_pass", 0)), int(tim.get("frames_direct", 0)), int(tim.get("frames_compact", 0))
+    Kt = min(K, int(tim.get("frames", K)) or K)      # the event ring holds the last 256 frames: launch counts are of those
     moved = log["n_static"] < log["n_slots"] if len(log) else np.zeros(0, bool)      # frames that compacted
     # (one-pass <=> not compacted on the default path; direct <=> one-pass and k_prep evaluated the tile flags)
     sel_op = ~moved if n_op else np.zeros(len(log), bool)
@@ -210,17 +211,17 @@ def kernel_table(log, tim, P, K, warmup, compact_period, workload):
         sel_mrg[1:] = sel_dir[:-1]                        # frame k's launch carries frame k-1's association
         sel_mrg[0] = n_mrg > int(sel_mrg.sum())           # (the last warm-up frame's, if the counts say so)
         kb["k_assoc_prep"] = kb["k_prep"] + np.concatenate([kb["k_associate_direct"][:1], kb["k_associate_direct"][:-1]])
-    rows = [("k_prep", tim.get("k_prep_own", tim["k_prep"]) if n_mrg else tim["k_prep"], ~sel_mrg, K - n_mrg),
+    rows = [("k_prep", tim.get("k_prep_own", tim["k_prep"]) if n_mrg else tim["k_prep"], ~sel_mrg, Kt - n_mrg),
             ("k_assoc_prep", tim.get("k_assoc_prep", 0.0), sel_mrg, n_mrg),
             ("k_surfel_pass", tim.get("k_surfel_pass", 0.0), sel_op, n_op),
             ("k_pass_fixup", tim.get("k_pass_fixup", 0.0), sel_op, n_op),
             ("k_associate_direct", tim.get("k_associate_direct", 0.0), sel_dir, n_alone),
-            ("k_conflict", tim.get("k_conflict_own", 0.0), ~sel_op, K - n_op),
+            ("k_conflict", tim.get("k_conflict_own", 0.0), ~sel_op, Kt - n_op),
             ("k_compact", tim.get("k_compact_own", 0.0), moved, n_comp),
-            ("k_associate", tim.get("k_associate_own", 0.0), ~sel_dir, K - n_dir),
-            ("k_append", tim.get("k_append_own", 0.0), ~sel_dir, K - n_dir)]
-    if K - n_op - n_comp > 0:      # lazy culls outside the one-pass form
-        rows.append(("k_cull_lazy", tim.get("k_cull_lazy", 0.0), ~moved & ~sel_op, K - n_op - n_comp))
+            ("k_associate", tim.get("k_associate_own", 0.0), ~sel_dir, Kt - n_dir),
+            ("k_append", tim.get("k_append_own", 0.0), ~sel_dir, Kt - n_dir)]
+    if Kt - n_op - n_comp > 0:      # lazy culls outside the one-pass form
+        rows.append(("k_cull_lazy", tim.get("k_cull_lazy", 0.0), ~moved & ~sel_op, Kt - n_op - n_comp))
     kern, launches = {}, {}
     for name, ms, sel, n in rows:
         if n <= 0:
@@ -229,8 +230,8 @@ def kernel_table(log, tim, P, K, warmup, compact_period, workload):
         mb = float(b[sel].mean()) / 1e6 if len(log) and sel.any() else 0.0
         kern[name] = {"ms": ms, "MB": mb, "GBs": (mb / 1e3) / (ms * 1e-3) if ms > 0 else None, "launches": n}
         launches[name] = n
-    if K - n_op > 0:
-        kern["k_scan_cull+k_cull_finalize"] = {"ms": tim.get("k_scan_own", 0.0), "MB": None, "GBs": None, "launches": K - n_op}
+    if Kt - n_op > 0:
+        kern["k_scan_cull+k_cull_finalize"] = {"ms": tim.get("k_scan_own", 0.0), "MB": None, "GBs": None, "launches": Kt - n_op}
     # HBM bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this very command
     # (profiles/README.md), gfx950-corrected per kernel by tools/prof_summary.py
     tj = None
