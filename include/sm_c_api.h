@@ -293,7 +293,10 @@ int sm_shard_rccl_finalize(sm_ctx *s);
 /* ranks of the context's RCCL communicator as RCCL itself reports them (ncclCommCount), or a negative SM_E_* */
 int sm_shard_rccl_nranks(sm_ctx *s);
 /* SurfelMapping::processFrame (src/SurfelMapping.cpp:115-251) on every rank with the same arguments; the _device form
- * takes device pointers and only enqueues (sm_sync to wait) */
+ * takes device pointers and only enqueues (sm_sync to wait).  A frame is a sequence of collectives every rank must enter: an
+ * error return from one rank (a failed launch or a failed RCCL call -- nothing a frame's data can cause) leaves the others inside
+ * a collective and the communicator undefined; treat it as fatal for the stream and destroy the contexts on all ranks.  (The
+ * rig's exchanges, which do run fallible local steps between collectives, carry a status word instead: sm_rig_consolidate.) */
 int sm_shard_frame_device(sm_ctx *s, const uint8_t *d_rgb, const uint16_t *d_depth_mm, const uint8_t *d_semantic, const float *pose16);
 int sm_shard_frame(sm_ctx *s, const uint8_t *rgb, const uint16_t *depth_mm, const uint8_t *semantic, const float *pose16);
 /* squeeze the dead slots out now (collective; frames do it every compact_period-th time by themselves) */
