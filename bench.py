@@ -254,6 +254,10 @@ def kernel_table(log, tim, P, K, warmup, compact_period, workload):
                 "ms_per_launch": kern[dom]["ms"], "alg_bytes_per_launch": kern[dom]["MB"] * 1e6,
                 "launches": launches[dom], "valu_issue_util": t.get("valu_issue_util"),
                 "traffic_source": (os.path.relpath(tpath, ROOT) if tj else None)}
+    # for information: the same kernel priced with the bytes the counters saw instead of the algorithmic ones (`frac` stays the
+    # contract's figure; this one says how close the launch runs to the memory system with everything it actually moves)
+    if roofline["traffic"] and kern[dom]["ms"] > 0:
+        roofline["traffic_frac"] = roofline["traffic"] / (kern[dom]["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
     return kern, launches, roofline
 
 
