@@ -435,12 +435,40 @@ def bench_ranks(args, cam, rank, world, local_rank, K, Wm, workers, emit):
     # camera's latest view): one step after the warm-up, one after the timed frames -- the second is timed, outside `value`
     sm_inc = capi.SurfelMap(capi.make_config(**cam, preprocess=0, device=local_rank, max_sqrt_vertices=msv_global))
     rig = smd.RigMapper(sm, smsh.TorchComm(device_index=local_rank), P)
-    if reh:
-        rig.enable_native(smsh.GlooCollective(sm))
-        nranks_rig = None
-    else:
-        rig.enable_native("rccl", bcast_id())
+    # The core binds RCCL itself; should that fail on any rank (all ranks decide together), the collectives fall back to torch's own
+    # group, staged through the host: `value` has no collective in it, only the consolidations and the sharded leg get slower
+    rccl_note = None
+
+    def native_collective(ctx):
+        nonlocal rccl_note
+        if reh:
+            return smsh.GlooCollective(ctx), None
+        ok, err = 1, ""
+        the_id = bcast_id()
+        try:
+            ctx.rig_configure(rank, world)
+            if os.environ.get("SM_BENCH_FAIL_RCCL"):      # (test hook: take the fallback)
+                raise RuntimeError("SM_BENCH_FAIL_RCCL")
+            ctx.shard_rccl_init(the_id)
+        except Exception as e:      # noqa: BLE001
+            ok, err = 0, repr(e)
+        flag = torch.tensor([ok], dtype=torch.int64, device=tdev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag[0]) == 1:
+            return "rccl-bound", None
+        if ok:
+            ctx.shard_rccl_finalize()
+        rccl_note = f"RCCL binding failed on a rank ({err or 'another rank'}): collectives through torch.distributed, host-staged"
+        sys.stderr.write("bench.py: " + rccl_note + "\n")
+        return smsh.TorchCollective(ctx, device=dev), None
+
+    coll, _ = native_collective(sm)
+    if coll == "rccl-bound":
+        rig._native = True                 # (configured and bound above)
         nranks_rig = sm.shard_rccl_nranks()
+    else:
+        rig.enable_native(coll)
+        nranks_rig = None
     gc.collect(); gc.disable()
     for k in range(Wm):
         sm.process_frame_device(*dptr[k])
@@ -478,7 +506,7 @@ def bench_ranks(args, cam, rank, world, local_rank, K, Wm, workers, emit):
     global_count, view_conflicts = rig.consolidate_native(sm_global)
     torch.cuda.synchronize()
     gather_ms = max_over_ranks((time.perf_counter() - g0) * 1e3)
-    if not reh:
+    if not reh and coll == "rccl-bound":
         sm.shard_rccl_finalize()
     counts = sm.counts()
     sm_global.close()
@@ -487,8 +515,12 @@ def bench_ranks(args, cam, rank, world, local_rank, K, Wm, workers, emit):
     sharded_leg = None
     if not args.no_sharded_leg:
         ss = capi.SurfelMap(capi.make_config(**cam, **cfg))
-        shard = smsh.StreamShard(ss, rank, world, smsh.GlooCollective(ss)) if reh else smsh.StreamShard(ss, rank, world, "rccl", bcast_id())
-        nranks_sh = None if reh else ss.shard_rccl_nranks()
+        if reh or rccl_note:
+            shard = smsh.StreamShard(ss, rank, world, smsh.TorchCollective(ss, device=None if reh else dev))
+            nranks_sh = None
+        else:
+            shard = smsh.StreamShard(ss, rank, world, "rccl", bcast_id())
+            nranks_sh = ss.shard_rccl_nranks()
         dsh = stage_frames(ss, shared, P)
         gc.collect(); gc.disable()
         for k in range(Wm):
@@ -508,7 +540,7 @@ def bench_ranks(args, cam, rank, world, local_rank, K, Wm, workers, emit):
         chk = torch.tensor([sc["count"], sc["conflict_count"], sc["unstable_count"]], dtype=torch.int64, device=tdev)
         lo, hi = chk.clone(), chk.clone()
         dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
-        if not reh:
+        if nranks_sh is not None:
             ss.shard_rccl_finalize()
         ss.close()
         del shard
@@ -546,8 +578,8 @@ def bench_ranks(args, cam, rank, world, local_rank, K, Wm, workers, emit):
                    "host_sync": "none inside the timed region", "surfels_end_rank0": int(counts["count"])},
         "rccl": ({"nranks": None, "world_size": world, "backend": "REHEARSAL on one GPU: torch.distributed gloo, the core's collectives staged through "
                                                                     "the host (sharded.GlooCollective); not a measurement of anything"} if reh else
-                 {"nranks": nranks_rig, "world_size": world, "backend": "RCCL bound by the HIP core (ncclCommInitRank / ncclCommCount); torch.distributed "
-                                                                          "only hands the communicator id round"}),
+                 {"nranks": nranks_rig, "world_size": world, "backend": rccl_note or "RCCL bound by the HIP core (ncclCommInitRank / ncclCommCount); "
+                                                                          "torch.distributed only hands the communicator id round"}),
         "surfels_fused_per_sec": (F_total + U_total) / elapsed,
         "fused_F": {"total": F_total, "per_sec": F_total / elapsed, "per_frame": F_total / (K * world)},
         "new_U": {"total": U_total, "per_sec": U_total / elapsed, "per_frame": U_total / (K * world)},

@@ -114,15 +114,16 @@ class ThreadCollective:
         return 0
 
 
-class GlooCollective:
-    """The collective of sm_shard_set_collective for ranks that are PROCESSES joined by a torch.distributed group whose backend
-    works on host memory ('gloo'): staged through the host like ThreadCollective.  For rehearsing the multi-process path where
-    RCCL cannot run -- several ranks on one GPU (`bench.py --gpus N --rehearse-one-gpu`, tests/test_dist_gpu.py); production
-    uses RCCL on the context's stream (SurfelMap.shard_rccl_init)."""
+class TorchCollective:
+    """The collective of sm_shard_set_collective for ranks that are PROCESSES joined by a torch.distributed group: staged through the
+    host like ThreadCollective, the reduction itself by torch (`device` None: host tensors, i.e. a gloo group; a torch device:
+    tensors there, i.e. torch's own NCCL / RCCL group).  For rehearsing the multi-process path where the core's RCCL binding cannot
+    run -- several ranks on one GPU (`bench.py --gpus N --rehearse-one-gpu`, tests/test_dist_gpu.py) -- and as bench.py's fallback
+    should that binding fail to initialise; production uses RCCL on the context's stream (SurfelMap.shard_rccl_init)."""
 
-    def __init__(self, sm, group=None):
+    def __init__(self, sm, group=None, device=None):
         import torch.distributed as dist
-        self.sm, self.dist, self.group = sm, dist, group
+        self.sm, self.dist, self.group, self.device = sm, dist, group, device
         self.world = dist.get_world_size(group)
 
     def __call__(self, send, recv, count, op):
@@ -130,14 +131,19 @@ class GlooCollective:
         from .capi import SM_COLL_GATHER, SM_COLL_MIN
         a = self.sm.device_download(send, count * 8, np.uint64)          # waits for the context's stream
         t = torch.from_numpy(a.view(np.int64).copy())                     # (keys < 2^63: order kept; sums wrap like u64)
+        if self.device is not None:
+            t = t.to(self.device)
         if op == SM_COLL_GATHER:
             parts = [torch.empty_like(t) for _ in range(self.world)]
             self.dist.all_gather(parts, t, group=self.group)
             t = torch.cat(parts)                                          # rank q's words at recv + q * count
         else:
             self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN if op == SM_COLL_MIN else self.dist.ReduceOp.SUM, group=self.group)
-        self.sm.device_upload(recv, np.ascontiguousarray(t.numpy().view(np.uint64)))
+        self.sm.device_upload(recv, np.ascontiguousarray(t.cpu().numpy().view(np.uint64)))
         return 0
+
+
+GlooCollective = TorchCollective      # (host tensors: the name the rehearsal uses)
 
 
 class StreamShard:
