@@ -155,7 +155,8 @@ private:
 #endif
         return t.texture;
     }
-    sm_counts counts() { sm_counts c{}; sm_get_counts(ctx_, &c); return c; }
+    // (sm_sync first: with SM_FACADE_ASYNC frames may still be in flight, and sm_get_counts returns the counters of the last wait)
+    sm_counts counts() { sm_counts c{}; (void)sm_sync(ctx_); sm_get_counts(ctx_, &c); return c; }
     std::vector<float> hostModel_, drawn_, mirror_[3];
     sm_ctx *ctx_;
     bool pending_ = false;

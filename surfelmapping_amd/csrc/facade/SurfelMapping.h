@@ -34,6 +34,11 @@ public:
         c.max_sqrt_vertices = Config::maxSqrtVertices();
         const char *pre = std::getenv("SM_PREPROCESS");
         if (pre) c.preprocess = std::atoi(pre);
+        // SM_FACADE_ASYNC=1: processFrame only enqueues (sm_process_frame_async: the images are staged inside the call, the copy of
+        // frame f+1 overlaps frame f) and every getter waits -- the reference's processFrame ends in glFinish, so this is opt-in: a
+        // device-side error is then reported by the next call that synchronises instead of by processFrame itself
+        const char *as = std::getenv("SM_FACADE_ASYNC");
+        async_ = as && as[0] == '1';
         ctx_ = sm_create(&c);
         if (!ctx_) throw std::runtime_error(std::string("SurfelMapping: ") + sm_last_error());
         globalModel.bind(ctx_);
@@ -68,7 +73,8 @@ public:
         textures[GPUTexture::RGB]->host_u8.assign(rgb, rgb + P * 3);
         if (depth) textures[GPUTexture::DEPTH_RAW]->host_u16.assign(depth, depth + P);
         if (semantic) textures[GPUTexture::SEMANTIC]->host_u8.assign(semantic, semantic + P);
-        int rc = sm_process_frame(ctx_, rgb, depth, semantic, gtPose->data());
+        int rc = async_ ? sm_process_frame_async(ctx_, rgb, depth, semantic, gtPose->data())
+                        : sm_process_frame(ctx_, rgb, depth, semantic, gtPose->data());
         if (rc != SM_OK) std::printf("processFrame: %s\n", sm_last_error());
         historyPoses.push_back(currPose);
     }
@@ -160,7 +166,8 @@ public:
 
     // extras of the HIP core
     sm_ctx *context() { return ctx_; }
-    sm_counts counts() { sm_counts c{}; sm_get_counts(ctx_, &c); return c; }
+    // (sm_sync first: with SM_FACADE_ASYNC frames may still be in flight, and sm_get_counts returns the counters of the last wait)
+    sm_counts counts() { sm_counts c{}; (void)sm_sync(ctx_); sm_get_counts(ctx_, &c); return c; }
 
     Checker *checker;
 
@@ -173,4 +180,5 @@ private:
     std::map<std::string, GPUTexture *> textures;
     std::vector<Eigen::Matrix4f> historyPoses;
     bool beginCleanPoints = false;
+    bool async_ = false;
 };

@@ -26,7 +26,8 @@ def test_facade_compiles_against_c_abi_only(tmp_path):
 
 
 @pytest.mark.gpu
-def test_facade_demo_matches_oracle(tmp_path):
+@pytest.mark.parametrize("facade_async", ["0", "1"])      # SM_FACADE_ASYNC=1: processFrame only enqueues, the getters wait
+def test_facade_demo_matches_oracle(tmp_path, facade_async):
     import oracle_lib as ol
     from surfelmapping_amd import synth
     cam = dict(width=320, height=120, fx=180.0, fy=180.0, cx=159.5, cy=59.5)
@@ -42,7 +43,8 @@ def test_facade_demo_matches_oracle(tmp_path):
     views = tmp_path / "views"
     views.mkdir()
     tex = tmp_path / "textures.bin"
-    r = subprocess.run([exe, str(frames), str(out), str(views), str(tex)], capture_output=True, text=True)
+    r = subprocess.run([exe, str(frames), str(out), str(views), str(tex)], capture_output=True, text=True,
+                       env=dict(os.environ, SM_FACADE_ASYNC=facade_async))
     assert r.returncode == 0, r.stdout + r.stderr
     o = ol.Oracle(ol.make_config(**cam, preprocess=0, max_sqrt_vertices=1000))
     for fr in seq:
